@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — k-mers/s hashed+sketched at k=32 on 150 bp reads (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads-per-step R] [--dist g|u]
+
+A "step" is one pass of the hot path (ntc_submit_device: ntHash -> sample -> count into the
+device-resident t_Counter sketch) over one batch of synthetic reads that is already resident in HBM.
+Default workload = BASELINE.json configs[1]: 100 M synthetic 150 bp reads, k=32, rBits=27, sBits=7,
+as 10 steps x 10 M reads.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank processes its own read-index range of the same size (weak scaling), then the per-GPU sketches
+are merged with one RCCL sum-reduce to rank 0 (inside the timed region).
+
+One JSON line on rank 0: value = total k-mers (sum of F1 over ranks) / max-over-ranks wall time.
+Extra objects: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes) and "cpu_baseline"
+(the oracle's OpenMP restatement on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads-per-step", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--r-bits", type=int, default=27)
+    ap.add_argument("--s-bits", type=int, default=7)
+    ap.add_argument("--dist", choices=["g", "u"], default="g",
+                    help="g: reads from a 100 Mbp random genome, 1%% subs, 0.05%% N; u: i.i.d. uniform ACGT")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, nt_stride):
+    """The oracle's OpenMP restatement of ntRead+ntComp (kind 'port') on a bounded sample of the
+    same read generator, timed on this box's host cores.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    cores = os.cpu_count() or 1
+    n = args.cpu_sample_reads or min(4_000_000, 250_000 * cores)
+    dist = 1 if args.dist == "g" else 0
+    slots = orc.gen_reads(args.seed, 0, n, args.read_len, nt_stride, dist, genome_len=100_000_000)
+    # compact to concatenated reads + offsets (what the reference's parsers hand to ntRead)
+    bases = np.ascontiguousarray(slots.reshape(n, nt_stride)[:, : args.read_len]).reshape(-1)
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(args.read_len))
+    counters = np.zeros((1, 2, 1 << args.r_bits), dtype=np.uint16)
+    warm = max(1, n // 50)
+    orc.sketch_update(counters, bases, offs[: warm + 1], [args.k], 0, args.r_bits, args.s_bits, threads=cores)
+    counters[:] = 0
+    t0 = time.perf_counter()
+    f1 = orc.sketch_update(counters, bases, offs, [args.k], 0, args.r_bits, args.s_bits, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": float(f1[0]) / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": f"{n} reads x {args.read_len} bp (same generator, dist={args.dist}), k={args.k}, "
+                      f"oracle OpenMP ntRead+ntComp, {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import ntcard_amd as nt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    L, k = args.read_len, args.k
+    stride = (L + 3) & ~3
+    if stride == L:
+        stride += 4  # keep at least one separator byte between slots
+    R = args.reads_per_step
+    K, W = args.steps, args.warmup
+    dist_id = 1 if args.dist == "g" else 0
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- resident inputs: K step batches (+1 warmup batch), generated on the device (K0) ----
+    reads_per_rank = R * K
+    first = rank * reads_per_rank
+    batches = []
+    for s in range(K):
+        b = torch.empty(R * stride + 16, dtype=torch.uint8, device=dev)
+        nt.gen_reads_device(b.data_ptr(), args.seed, first + s * R, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
+        batches.append(b)
+    wb = torch.empty(R * stride + 16, dtype=torch.uint8, device=dev)
+    nt.gen_reads_device(wb.data_ptr(), args.seed ^ 0x5eed, 0, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
+
+    # the sketch is a torch tensor so that torch.distributed (RCCL) can reduce it in place
+    sketch = torch.zeros(2 << args.r_bits, dtype=torch.int32, device=dev)
+    f1_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    eng = nt.Engine([k], r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
+                    ext_sketch=sketch, ext_f1=f1_dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        eng.submit_device(wb.data_ptr(), R, L, stride)
+    if world > 1 and W > 0:  # warm the RCCL path too
+        dist.reduce(sketch, dst=0, op=dist.ReduceOp.SUM)
+        dist.reduce(f1_dev, dst=0, op=dist.ReduceOp.SUM)
+    eng.sync()
+    eng.reset()
+    eng.set_profiling(True)
+
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(K):
+        eng.submit_device(batches[s].data_ptr(), R, L, stride)
+    if world > 1:
+        dist.reduce(sketch, dst=0, op=dist.ReduceOp.SUM)
+        dist.reduce(f1_dev, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    ker_ms, launches = eng.kernel_time()
+    _, ph, f1 = eng.finish(counters=False, p_hist=True)
+    total_kmers = int(f1[0])  # after the reduce rank 0 holds the sum over ranks
+
+    if rank == 0:
+        import numpy as np
+        hits = int((ph[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
+        # --- roofline of the dominant kernel (nthash_kernel<0>), per launch, this rank ---
+        per_launch_kmers = total_kmers / max(world, 1) / max(launches, 1)
+        per_launch_hits = hits / max(world, 1) / max(launches, 1)
+        alg_bytes = R * (L + 4) + 4.0 * per_launch_hits  # bases+offset read once, 2 B r/w per sampled hit
+        avg_ms = ker_ms / max(launches, 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "k-mers/s hashed+sketched (whole node) at k=32, 150 bp reads",
+            "value": total_kmers / dt_max,
+            "unit": "k-mers/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt_max * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"{world}x{reads_per_rank} synthetic {L} bp reads (dist={args.dist}, seed={args.seed}), "
+                                   f"k={k}, rBits={args.r_bits}, sBits={args.s_bits}, {K} steps x {R} reads per GPU"
+                                   + (", RCCL sum-reduce of the sketch to rank 0 inside the timed region" if world > 1 else ""),
+                       "k": k, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
+                       "parallelism": f"read-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "nthash_kernel<0>", "avg_launch_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kmers_per_launch": per_launch_kmers},
+            "f1_total": total_kmers,
+            "sampled_increments": hits,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, stride)
+            except Exception as ex:  # the checker is optional for the measurement itself
+                out["cpu_baseline"] = {"value": None, "unit": "k-mers/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {ex}"}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * ntcard_hip.h — C ABI of the MI355X (gfx950) ntHash -> sample -> count engine.
+ *
+ * Drop-in boundary (seam B2).  The reference has no FFI; the seam this library
+ * replaces is the in-process call the record parsers make for every sequence,
+ *     ntRead / stRead(const std::string& seq, const std::vector<unsigned>& kList,
+ *                     uint16_t* t_Counter, size_t totKmer[])      ntcard.cpp:147-171
+ * (call sites ntcard.cpp:182,185,203,205,230,232), together with the state that call mutates,
+ *     uint16_t t_Counter[nK][nSamp=2][1<<rBits]                  ntcard.cpp:437-439
+ *     size_t   totalKmers[nK]  (F1)                              ntcard.cpp:433-435,464-466
+ * its configuration globals opt::{rBits,sBits,sMask,rBuck,nSamp,gap,seedSet} (ntcard.cpp:52-67),
+ * and the consumer of that state, compEst (ntcard.cpp:237-275) + outDefault/outCompact
+ * (ntcard.cpp:277-315).  INTEGRATION.md shows the patch a reference maintainer would apply.
+ *
+ * Conventions: plain C, plain pointers and sizes, no torch/HIP types in signatures (a HIP stream is
+ * passed as void*).  Every function returns 0 on success and a negative ntc_status on failure;
+ * ntc_last_error() returns a thread-local message.  There is NO CPU fallback: if no gfx950 device
+ * or kernel image is available, ntc_create fails with NTC_ERR_DEVICE.
+ */
+#ifndef NTCARD_HIP_H
+#define NTCARD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTC_ABI_VERSION 1
+#define NTC_MAX_K_LIST 32
+
+typedef enum {
+    NTC_OK = 0,
+    NTC_ERR_ARG = -1,      /* bad argument / unsupported configuration              */
+    NTC_ERR_DEVICE = -2,   /* no usable HIP device, or a HIP runtime call failed    */
+    NTC_ERR_MEMORY = -3,   /* host or device allocation failed                      */
+    NTC_ERR_STATE = -4     /* call not valid in the engine's current state          */
+} ntc_status;
+
+typedef struct ntc_engine ntc_engine; /* opaque: owns the device sketch, F1 and staging buffers */
+
+/* Replaces opt::{kList(-k), gap(-g), rBits(-r), sBits(-s)} (ntcard.cpp:52-67,325-363).  The CALLER
+ * applies the "total input < 50 GB => sBits = 7" rule (ntcard.cpp:427-431) before ntc_create.   */
+typedef struct {
+    uint32_t n_k;              /* number of k values (order defines sketch plane order)          */
+    const uint32_t *k;         /* k list; every k >= 1 and <= NTC_MAX_K (see ntc_max_k())        */
+    uint32_t gap;              /* 0, or g: seed = 1^((k-g)/2) 0^g 1^((k-g)/2); needs n_k == 1    */
+    uint32_t r_bits;           /* log2 buckets per sample (reference default 27); 8..30          */
+    uint32_t s_bits;           /* sampling bits (reference: 7 or 11); 2..24                      */
+    int32_t device;            /* HIP device ordinal                                             */
+    void *stream;              /* hipStream_t to run on, or NULL for the device's null stream    */
+    void *ext_sketch;          /* optional caller-owned DEVICE memory for the sketch:
+                                  uint32_t [n_k][2][1<<r_bits]; NULL -> engine allocates.
+                                  (lets a host framework own/merge the buffer, e.g. RCCL reduce) */
+    void *ext_f1;              /* optional caller-owned DEVICE uint64_t [n_k]; NULL -> engine    */
+    uint32_t flags;            /* NTC_FLAG_*                                                      */
+} ntc_config;
+
+#define NTC_FLAG_NONE 0u
+
+uint32_t ntc_abi_version(void);
+uint32_t ntc_max_k(void);
+const char *ntc_last_error(void);
+
+/* ntcard.cpp:437-439 (allocate + zero t_Counter), :433-435 (zero F1) */
+int ntc_create(const ntc_config *cfg, ntc_engine **out);
+void ntc_destroy(ntc_engine *e);                 /* ntcard.cpp:474 */
+int ntc_reset(ntc_engine *e);                    /* re-zero sketch and F1 */
+
+/* ntRead/stRead for a batch of sequences (ntcard.cpp:147-171).  HOST buffers:
+ * bases = concatenated raw sequence bytes exactly as the parsers produced them (any case, any
+ * IUPAC/N byte), offsets[n_reads+1] delimits read i = bases[offsets[i], offsets[i+1]).
+ * The engine copies what it needs before returning (caller keeps ownership).  Thread-safe:
+ * may be called concurrently from several parser threads like the reference's seam.            */
+int ntc_submit(ntc_engine *e, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+
+/* Same for a batch that is already DEVICE-resident in the engine's slot layout: read i occupies
+ * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Asynchronous on
+ * the engine's stream; the buffer must stay valid until ntc_sync/ntc_finish.                    */
+int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
+                      uint32_t stride);
+
+int ntc_sync(ntc_engine *e); /* wait for all submitted work */
+
+/* End of stream: the state compEst/outDefault consume.
+ * t_counter_out: HOST uint16_t [n_k][2][1<<r_bits] (== the reference's t_Counter) or NULL
+ * p_hist_out:    HOST uint32_t [n_k][2][65536], p[s][v] = #buckets of sample s whose counter == v
+ *                (ntcard.cpp:240-247) or NULL
+ * f1_out:        HOST uint64_t [n_k] (totalKmers, ntcard.cpp:464-466) or NULL
+ * May be called repeatedly; does not clear the sketch.                                          */
+int ntc_finish(ntc_engine *e, uint16_t *t_counter_out, uint32_t *p_hist_out, uint64_t *f1_out);
+
+/* Device pointers of the live sketch / F1 (for a host framework's collective) */
+int ntc_device_state(ntc_engine *e, void **d_sketch_u32, uint64_t *n_counters, void **d_f1_u64);
+
+/* Validation kernel (K1d): canonical hash of every window of ONE k for a device-resident slot
+ * batch.  d_hash_out: DEVICE uint64_t [n_reads][max_win], d_count_out: DEVICE uint32_t [n_reads].
+ * Window j of read i is valid iff bit 63.. no: hashes are written compacted in window order and
+ * d_count_out[i] gives how many (== that read's F1 share), mirroring ntHashIterator
+ * (ntHashIterator.hpp:59-86) / stHashIterator when gap != 0.                                     */
+int ntc_hash_dump_device(int32_t device, void *stream, const void *d_slots, uint64_t n_reads,
+                         uint32_t read_len, uint32_t stride, uint32_t k, uint32_t gap,
+                         uint32_t max_win, void *d_hash_out, void *d_count_out);
+
+/* Synthetic workload generator (K0), bit-identical to oracle/orc_gen_reads; DESIGN.md
+ * "Synthetic workloads".  Fills d_slots[n_reads*stride].                                         */
+int ntc_gen_reads_device(int32_t device, void *stream, void *d_slots, uint64_t seed,
+                         uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint32_t stride,
+                         uint32_t dist, uint64_t genome_len);
+
+/* compEst (ntcard.cpp:249-274) from the value histogram of ONE k.  f_out has cov_max+1 doubles
+ * (f_out[0] unused); only i <= cov_max is evaluated (identical values).          */
+int ntc_estimate(const uint32_t *p_hist /* [2][65536] */, uint32_t r_bits, uint32_t s_bits,
+                 uint32_t cov_max, double *F0_out, double *f_out);
+
+/* outDefault body for one k (ntcard.cpp:283,291-294): writes "<prefix>_k<k>.hist" when path is
+ * given verbatim.  Returns 0 or NTC_ERR_ARG if the file cannot be written.                      */
+int ntc_write_hist(const char *path, uint64_t f1, double F0, const double *f, uint32_t cov_max);
+
+/* Timing of the hot kernel as measured with HIP events on the engine's stream (for bench.py's
+ * roofline leg): accumulated milliseconds and launch count since create/reset.                  */
+int ntc_kernel_time(ntc_engine *e, double *ms_total, uint64_t *launches);
+int ntc_set_profiling(ntc_engine *e, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,8 @@
+"""ntcard_amd — MI355X (gfx950) engine for ntCard's ntHash -> sample -> count hot path.
+
+Product code lives in ntcard_amd/csrc (HIP kernels + the C ABI of include/ntcard_hip.h); this
+package is the thin Python mirror of that ABI used by tests and bench.py.
+"""
+from ._abi import ABI_SYMBOLS, LIB_PATH, NtcError  # noqa: F401
+from .engine import (Engine, estimate, gen_reads_device, hash_dump_device, s_bits_for_input,  # noqa: F401
+                     write_hist)

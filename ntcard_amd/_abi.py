@@ -1,0 +1,83 @@
+"""ctypes binding of ntcard_amd/lib/libntcard_hip.so (include/ntcard_hip.h).
+
+There is no CPU fallback: loading fails loudly if the library was not built, and every compute
+entry point fails with NTC_ERR_DEVICE when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libntcard_hip.so")
+
+# every symbol include/ntcard_hip.h declares
+ABI_SYMBOLS = [
+    "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
+    "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
+    "ntc_hash_dump_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
+    "ntc_kernel_time", "ntc_set_profiling",
+]
+
+
+class NtcConfig(C.Structure):
+    _fields_ = [
+        ("n_k", C.c_uint32),
+        ("k", C.POINTER(C.c_uint32)),
+        ("gap", C.c_uint32),
+        ("r_bits", C.c_uint32),
+        ("s_bits", C.c_uint32),
+        ("device", C.c_int32),
+        ("stream", C.c_void_p),
+        ("ext_sketch", C.c_void_p),
+        ("ext_f1", C.c_void_p),
+        ("flags", C.c_uint32),
+    ]
+
+
+class NtcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ntCard: {msg} (status {code})")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ntcard_amd/csrc`). The HIP extension is mandatory; there is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    u32, u64, i32, p = C.c_uint32, C.c_uint64, C.c_int32, C.c_void_p
+    L.ntc_abi_version.restype = u32
+    L.ntc_max_k.restype = u32
+    L.ntc_last_error.restype = C.c_char_p
+    L.ntc_create.argtypes = [C.POINTER(NtcConfig), C.POINTER(p)]
+    L.ntc_destroy.argtypes = [p]
+    L.ntc_destroy.restype = None
+    L.ntc_reset.argtypes = [p]
+    L.ntc_submit.argtypes = [p, p, p, u64]
+    L.ntc_submit_device.argtypes = [p, p, u64, u32, u32]
+    L.ntc_sync.argtypes = [p]
+    L.ntc_finish.argtypes = [p, p, p, p]
+    L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
+    L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
+    L.ntc_gen_reads_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u32, u64]
+    L.ntc_estimate.argtypes = [p, u32, u32, u32, C.POINTER(C.c_double), p]
+    L.ntc_write_hist.argtypes = [C.c_char_p, u64, C.c_double, p, u32]
+    L.ntc_kernel_time.argtypes = [p, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.ntc_set_profiling.argtypes = [p, C.c_int]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_destroy"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise NtcError(rc, lib().ntc_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,498 @@
+// ntc_engine.hip — C-ABI shim (include/ntcard_hip.h) over the gfx950 kernels.
+//
+// Host-side mirror of the reference seam B2: ntc_create = the allocation/zeroing
+// main() does (ntcard.cpp:433-439), ntc_submit = a batch of ntRead/stRead calls
+// (ntcard.cpp:147-171), ntc_finish = the state compEst reads (ntcard.cpp:237-247) + F1
+// (ntcard.cpp:464-466).  No CPU fallback exists: every entry point needs a live HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ntcard_hip.h"
+#include "ntc_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+	do {                                                                                            \
+		hipError_t e__ = (expr);                                                                    \
+		if (e__ != hipSuccess)                                                                      \
+			return fail(NTC_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e__));          \
+	} while (0)
+
+constexpr uint32_t kMaxK = 255;
+constexpr uint32_t kSlotCapMin = 256; // host packing: slot capacity (bytes) for ragged batches
+
+struct DevInfo {
+	int cus = 0;
+};
+
+int device_info(int dev, DevInfo& di)
+{
+	hipDeviceProp_t p;
+	HIP_TRY(hipGetDeviceProperties(&p, dev));
+	di.cus = p.multiProcessorCount;
+	return 0;
+}
+
+size_t smem_for(uint32_t stride) { return (size_t)ntc::kTableBytes + (size_t)ntc::kWavesPerBlock * 64u * stride; }
+
+// grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
+int hash_grid(int dev, uint64_t n_slots, uint32_t stride, unsigned& grid, size_t& smem)
+{
+	DevInfo di;
+	if (int rc = device_info(dev, di)) return rc;
+	smem = smem_for(stride);
+	if (smem > 160 * 1024) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, smem);
+	HIP_TRY(ntc::set_hash_smem_limit(smem));
+	unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
+	uint64_t need = (n_slots + 64 * ntc::kWavesPerBlock - 1) / (64 * ntc::kWavesPerBlock);
+	uint64_t cap = (uint64_t)di.cus * per_cu;
+	grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, cap));
+	return 0;
+}
+
+} // namespace
+
+struct ntc_engine {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::vector<uint32_t> klist;
+	uint32_t gap = 0, r_bits = 27, s_bits = 7;
+	uint32_t* d_sketch = nullptr; // [nk][2][1<<r_bits]
+	unsigned long long* d_f1 = nullptr;
+	bool own_sketch = false, own_f1 = false;
+	uint32_t* d_phist = nullptr; // [nk][2][65536]
+	uint16_t* d_out16 = nullptr; // [2][1<<r_bits] scratch for finish
+	// host-submit staging (grow-only)
+	unsigned char* h_stage = nullptr;
+	uint32_t* h_meta = nullptr;
+	size_t h_stage_cap = 0, h_meta_cap = 0;
+	unsigned char* d_stage = nullptr;
+	uint32_t* d_meta = nullptr;
+	size_t d_stage_cap = 0, d_meta_cap = 0;
+	std::mutex mu;
+	// profiling of the hash kernel (HIP events on the engine stream)
+	bool profiling = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+	double ms_total = 0.0;
+	uint64_t launches = 0;
+
+	uint64_t plane_elems() const { return 2ull << r_bits; }
+};
+
+namespace {
+
+int drain_events(ntc_engine* e)
+{
+	for (auto& pr : e->pending) {
+		float ms = 0.f;
+		HIP_TRY(hipEventSynchronize(pr.second));
+		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+		e->ms_total += ms;
+		e->launches += 1;
+		hipEventDestroy(pr.first);
+		hipEventDestroy(pr.second);
+	}
+	e->pending.clear();
+	return 0;
+}
+
+// launch the hash->sample->count kernel for every k of the list over one device-resident batch
+int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_meta, uint64_t n_slots,
+              uint32_t read_len, uint32_t stride)
+{
+	if (n_slots == 0) return 0;
+	unsigned grid = 0;
+	size_t smem = 0;
+	if (int rc = hash_grid(e->device, n_slots, stride, grid, smem)) return rc;
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		ntc::HashArgs a;
+		std::memset(&a, 0, sizeof a);
+		a.slots = d_slots;
+		a.meta = d_meta;
+		a.n_slots = n_slots;
+		a.stride = stride;
+		a.read_len = read_len;
+		a.k = e->klist[ki];
+		a.r_bits = e->r_bits;
+		a.s_bits = e->s_bits;
+		a.sketch = e->d_sketch + ki * e->plane_elems();
+		a.f1 = e->d_f1 + ki;
+		ntc::build_tables(a.k, a.tab);
+		hipEvent_t ev0 = nullptr, ev1 = nullptr;
+		if (e->profiling) {
+			HIP_TRY(hipEventCreate(&ev0));
+			HIP_TRY(hipEventCreate(&ev1));
+			HIP_TRY(hipEventRecord(ev0, e->stream));
+		}
+		HIP_TRY(ntc::launch_hash(0, a, grid, smem, e->stream));
+		if (e->profiling) {
+			HIP_TRY(hipEventRecord(ev1, e->stream));
+			e->pending.emplace_back(ev0, ev1);
+		}
+	}
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t ntc_abi_version(void) { return NTC_ABI_VERSION; }
+uint32_t ntc_max_k(void) { return kMaxK; }
+const char* ntc_last_error(void) { return g_err.c_str(); }
+
+int ntc_create(const ntc_config* cfg, ntc_engine** out)
+{
+	if (!cfg || !out) return fail(NTC_ERR_ARG, "ntc_create: null argument");
+	*out = nullptr;
+	if (cfg->n_k == 0 || cfg->n_k > NTC_MAX_K_LIST || !cfg->k)
+		return fail(NTC_ERR_ARG, "ntc_create: need 1..%d k values", NTC_MAX_K_LIST);
+	for (uint32_t i = 0; i < cfg->n_k; ++i)
+		if (cfg->k[i] < 1 || cfg->k[i] > kMaxK)
+			return fail(NTC_ERR_ARG, "ntc_create: k=%u outside 1..%u", cfg->k[i], kMaxK);
+	if (cfg->gap != 0) {
+		if (cfg->n_k != 1) return fail(NTC_ERR_ARG, "ntc_create: gap seed does not support multiple k");
+		if (cfg->gap % 2 != cfg->k[0] % 2 || cfg->gap >= cfg->k[0])
+			return fail(NTC_ERR_ARG, "ntc_create: gap size and kmer must have the same modulus");
+		return fail(NTC_ERR_ARG, "ntc_create: gap seeds are not implemented in this build");
+	}
+	if (cfg->r_bits < 8 || cfg->r_bits > 30) return fail(NTC_ERR_ARG, "ntc_create: r_bits %u outside 8..30", cfg->r_bits);
+	if (cfg->s_bits < 2 || cfg->s_bits > 24) return fail(NTC_ERR_ARG, "ntc_create: s_bits %u outside 2..24", cfg->s_bits);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+		return fail(NTC_ERR_DEVICE, "ntc_create: no HIP device available (this library has no CPU fallback)");
+	if (cfg->device < 0 || cfg->device >= ndev) return fail(NTC_ERR_ARG, "ntc_create: device %d of %d", cfg->device, ndev);
+	HIP_TRY(hipSetDevice(cfg->device));
+	ntc_engine* e = new (std::nothrow) ntc_engine();
+	if (!e) return fail(NTC_ERR_MEMORY, "ntc_create: out of host memory");
+	e->device = cfg->device;
+	e->stream = (hipStream_t)cfg->stream;
+	e->klist.assign(cfg->k, cfg->k + cfg->n_k);
+	e->gap = cfg->gap;
+	e->r_bits = cfg->r_bits;
+	e->s_bits = cfg->s_bits;
+	const size_t sk_bytes = e->klist.size() * e->plane_elems() * sizeof(uint32_t);
+	if (cfg->ext_sketch) {
+		e->d_sketch = (uint32_t*)cfg->ext_sketch;
+	} else {
+		if (hipMalloc((void**)&e->d_sketch, sk_bytes) != hipSuccess) {
+			delete e;
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate %zu B sketch on device", sk_bytes);
+		}
+		e->own_sketch = true;
+	}
+	if (cfg->ext_f1) {
+		e->d_f1 = (unsigned long long*)cfg->ext_f1;
+	} else {
+		if (hipMalloc((void**)&e->d_f1, e->klist.size() * 8) != hipSuccess) {
+			ntc_destroy(e);
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate F1 on device");
+		}
+		e->own_f1 = true;
+	}
+	if (hipMalloc((void**)&e->d_phist, e->klist.size() * 2 * 65536 * 4) != hipSuccess) {
+		ntc_destroy(e);
+		return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate histogram on device");
+	}
+	int rc = ntc_reset(e);
+	if (rc) {
+		ntc_destroy(e);
+		return rc;
+	}
+	*out = e;
+	return 0;
+}
+
+void ntc_destroy(ntc_engine* e)
+{
+	if (!e) return;
+	hipSetDevice(e->device);
+	hipStreamSynchronize(e->stream);
+	for (auto& pr : e->pending) {
+		hipEventDestroy(pr.first);
+		hipEventDestroy(pr.second);
+	}
+	if (e->own_sketch && e->d_sketch) hipFree(e->d_sketch);
+	if (e->own_f1 && e->d_f1) hipFree(e->d_f1);
+	if (e->d_phist) hipFree(e->d_phist);
+	if (e->d_out16) hipFree(e->d_out16);
+	if (e->d_stage) hipFree(e->d_stage);
+	if (e->d_meta) hipFree(e->d_meta);
+	if (e->h_stage) hipHostFree(e->h_stage);
+	if (e->h_meta) hipHostFree(e->h_meta);
+	delete e;
+}
+
+int ntc_reset(ntc_engine* e)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_reset: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
+	HIP_TRY(hipMemsetAsync(e->d_f1, 0, e->klist.size() * 8, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (int rc = drain_events(e)) return rc;
+	e->ms_total = 0.0;
+	e->launches = 0;
+	return 0;
+}
+
+int ntc_submit_device(ntc_engine* e, const void* d_slots, uint64_t n_reads, uint32_t read_len, uint32_t stride)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit_device: null engine");
+	if (n_reads == 0) return 0;
+	if (!d_slots || (stride & 3u) || stride < read_len || ((uintptr_t)d_slots & 15u))
+		return fail(NTC_ERR_ARG, "ntc_submit_device: need 16-byte aligned slots, stride %% 4 == 0, stride >= read_len");
+	if (read_len > 0xffffu) return fail(NTC_ERR_ARG, "ntc_submit_device: read_len %u > 65535", read_len);
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride);
+}
+
+int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64_t n_reads)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit: null engine");
+	if (n_reads == 0) return 0;
+	if (!bases || !offsets) return fail(NTC_ERR_ARG, "ntc_submit: null buffer");
+	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
+	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
+	// ---- plan: one slot per read, or chunks with kmax-1 overlap for long sequences ----
+	uint64_t maxlen = 0;
+	bool uniform = true;
+	const uint64_t len0 = offsets[1] - offsets[0];
+	for (uint64_t i = 0; i < n_reads; ++i) {
+		if (offsets[i + 1] < offsets[i]) return fail(NTC_ERR_ARG, "ntc_submit: offsets not monotone at read %llu", (unsigned long long)i);
+		const uint64_t l = offsets[i + 1] - offsets[i];
+		maxlen = std::max(maxlen, l);
+		uniform &= (l == len0);
+	}
+	if (maxlen < kmin) return 0; // nothing can produce a k-mer (ntHashIterator.hpp:61-64)
+	const uint32_t cap_chunk = std::max<uint32_t>(kSlotCapMin, ((2 * kmax + 64) + 3) & ~3u);
+	const bool chunked = maxlen > cap_chunk;
+	const uint32_t stride = chunked ? cap_chunk : (uint32_t)((maxlen + 3) & ~3ull);
+	const uint32_t ch = cap_chunk - (kmax - 1); // window starts per chunk
+	uint64_t n_slots = 0;
+	if (!chunked) {
+		n_slots = n_reads;
+	} else {
+		for (uint64_t i = 0; i < n_reads; ++i) {
+			const uint64_t l = offsets[i + 1] - offsets[i];
+			if (l < kmin) continue;
+			n_slots += l <= cap_chunk ? 1 : (l - (kmax - 1) + ch - 1) / ch;
+		}
+	}
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	// previous batch may still be reading the staging buffers
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	const size_t need = (size_t)n_slots * stride + 16;
+	if (need > e->h_stage_cap) {
+		if (e->h_stage) hipHostFree(e->h_stage);
+		e->h_stage = nullptr;
+		size_t cap = std::max(need, e->h_stage_cap * 2);
+		if (hipHostMalloc((void**)&e->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
+			e->h_stage_cap = 0;
+			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot pin %zu B", cap);
+		}
+		e->h_stage_cap = cap;
+	}
+	if (need > e->d_stage_cap) {
+		if (e->d_stage) hipFree(e->d_stage);
+		e->d_stage = nullptr;
+		size_t cap = std::max(need, e->d_stage_cap * 2);
+		if (hipMalloc((void**)&e->d_stage, cap) != hipSuccess) {
+			e->d_stage_cap = 0;
+			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot allocate %zu B on device", cap);
+		}
+		e->d_stage_cap = cap;
+	}
+	const bool need_meta = chunked || !uniform;
+	if (need_meta && n_slots > e->h_meta_cap) {
+		if (e->h_meta) hipHostFree(e->h_meta);
+		if (e->d_meta) hipFree(e->d_meta);
+		e->h_meta = nullptr;
+		e->d_meta = nullptr;
+		size_t cap = std::max<size_t>(n_slots, e->h_meta_cap * 2);
+		if (hipHostMalloc((void**)&e->h_meta, cap * 4, hipHostMallocDefault) != hipSuccess ||
+		    hipMalloc((void**)&e->d_meta, cap * 4) != hipSuccess) {
+			e->h_meta_cap = 0;
+			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot allocate slot metadata");
+		}
+		e->h_meta_cap = cap;
+	}
+	// ---- pack (the copy the ABI promises: caller's buffers are free on return) ----
+	unsigned char* hs = e->h_stage;
+	uint64_t slot = 0;
+	for (uint64_t i = 0; i < n_reads; ++i) {
+		const uint64_t l = offsets[i + 1] - offsets[i];
+		const char* src = bases + offsets[i];
+		if (!chunked) {
+			unsigned char* dst = hs + slot * stride;
+			std::memcpy(dst, src, l);
+			std::memset(dst + l, '\n', stride - l);
+			if (need_meta) e->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
+			++slot;
+			continue;
+		}
+		if (l < kmin) continue;
+		if (l <= cap_chunk) {
+			unsigned char* dst = hs + slot * stride;
+			std::memcpy(dst, src, l);
+			std::memset(dst + l, '\n', stride - l);
+			e->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
+			++slot;
+			continue;
+		}
+		for (uint64_t start = 0; start + (kmax - 1) < l || start == 0; start += ch) {
+			const uint64_t nbytes = std::min<uint64_t>(cap_chunk, l - start);
+			const bool last = start + cap_chunk >= l;
+			unsigned char* dst = hs + slot * stride;
+			std::memcpy(dst, src + start, nbytes);
+			std::memset(dst + nbytes, '\n', stride - nbytes);
+			e->h_meta[slot] = (uint32_t)nbytes | ((uint32_t)(last ? nbytes : ch) << 16);
+			++slot;
+			if (last) break;
+		}
+	}
+	if (slot != n_slots) return fail(NTC_ERR_STATE, "ntc_submit: internal slot plan mismatch (%llu != %llu)", (unsigned long long)slot, (unsigned long long)n_slots);
+	HIP_TRY(hipMemcpyAsync(e->d_stage, hs, (size_t)n_slots * stride, hipMemcpyHostToDevice, e->stream));
+	if (need_meta) HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, n_slots * 4, hipMemcpyHostToDevice, e->stream));
+	int rc = run_batch(e, e->d_stage, need_meta ? e->d_meta : nullptr, n_slots, (uint32_t)len0, stride);
+	if (rc) return rc;
+	// the pinned staging buffer is reused by the next call; the device copy is ordered on the stream
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+int ntc_sync(ntc_engine* e)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_sync: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return drain_events(e);
+}
+
+int ntc_finish(ntc_engine* e, uint16_t* t_counter_out, uint32_t* p_hist_out, uint64_t* f1_out)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_finish: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	const size_t nk = e->klist.size();
+	const uint64_t per_sample = 1ull << e->r_bits;
+	if (t_counter_out && !e->d_out16) {
+		if (hipMalloc((void**)&e->d_out16, 2 * per_sample * sizeof(uint16_t)) != hipSuccess)
+			return fail(NTC_ERR_MEMORY, "ntc_finish: cannot allocate uint16 staging");
+	}
+	if (p_hist_out || t_counter_out) {
+		HIP_TRY(hipMemsetAsync(e->d_phist, 0, nk * 2 * 65536 * 4, e->stream));
+		for (size_t ki = 0; ki < nk; ++ki) {
+			HIP_TRY(ntc::launch_finalize(e->d_sketch + ki * e->plane_elems(), per_sample,
+			                             e->d_phist + ki * 2 * 65536, t_counter_out ? e->d_out16 : nullptr, e->stream));
+			if (t_counter_out)
+				HIP_TRY(hipMemcpyAsync(t_counter_out + ki * 2 * per_sample, e->d_out16, 2 * per_sample * sizeof(uint16_t),
+				                       hipMemcpyDeviceToHost, e->stream));
+		}
+		if (p_hist_out)
+			HIP_TRY(hipMemcpyAsync(p_hist_out, e->d_phist, nk * 2 * 65536 * 4, hipMemcpyDeviceToHost, e->stream));
+	}
+	if (f1_out) HIP_TRY(hipMemcpyAsync(f1_out, e->d_f1, nk * 8, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return drain_events(e);
+}
+
+int ntc_device_state(ntc_engine* e, void** d_sketch_u32, uint64_t* n_counters, void** d_f1_u64)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_device_state: null engine");
+	if (d_sketch_u32) *d_sketch_u32 = e->d_sketch;
+	if (n_counters) *n_counters = e->klist.size() * e->plane_elems();
+	if (d_f1_u64) *d_f1_u64 = e->d_f1;
+	return 0;
+}
+
+int ntc_hash_dump_device(int32_t device, void* stream, const void* d_slots, uint64_t n_reads, uint32_t read_len,
+                         uint32_t stride, uint32_t k, uint32_t gap, uint32_t max_win, void* d_hash_out,
+                         void* d_count_out)
+{
+	if (!d_slots || !d_hash_out || !d_count_out) return fail(NTC_ERR_ARG, "ntc_hash_dump_device: null buffer");
+	if (k < 1 || k > kMaxK) return fail(NTC_ERR_ARG, "ntc_hash_dump_device: k=%u outside 1..%u", k, kMaxK);
+	if (gap != 0) return fail(NTC_ERR_ARG, "ntc_hash_dump_device: gap seeds are not implemented in this build");
+	if ((stride & 3u) || stride < read_len || ((uintptr_t)d_slots & 15u))
+		return fail(NTC_ERR_ARG, "ntc_hash_dump_device: need 16-byte aligned slots, stride %% 4 == 0, stride >= read_len");
+	if (n_reads == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	unsigned grid = 0;
+	size_t smem = 0;
+	if (int rc = hash_grid(device, n_reads, stride, grid, smem)) return rc;
+	ntc::HashArgs a;
+	std::memset(&a, 0, sizeof a);
+	a.slots = (const unsigned char*)d_slots;
+	a.n_slots = n_reads;
+	a.stride = stride;
+	a.read_len = read_len;
+	a.k = k;
+	a.r_bits = 27;
+	a.s_bits = 7;
+	a.max_win = max_win;
+	a.dump = (uint64_t*)d_hash_out;
+	a.dump_count = (uint32_t*)d_count_out;
+	ntc::build_tables(k, a.tab);
+	HIP_TRY(ntc::launch_hash(1, a, grid, smem, (hipStream_t)stream));
+	return 0;
+}
+
+int ntc_gen_reads_device(int32_t device, void* stream, void* d_slots, uint64_t seed, uint64_t first_read,
+                         uint64_t n_reads, uint32_t read_len, uint32_t stride, uint32_t dist, uint64_t genome_len)
+{
+	if (!d_slots || (stride & 3u) || stride < read_len) return fail(NTC_ERR_ARG, "ntc_gen_reads_device: bad layout");
+	if (dist > 1) return fail(NTC_ERR_ARG, "ntc_gen_reads_device: dist must be 0 (uniform) or 1 (genome)");
+	if (dist == 1 && genome_len < read_len) return fail(NTC_ERR_ARG, "ntc_gen_reads_device: genome shorter than a read");
+	if (n_reads == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(ntc::launch_gen((unsigned char*)d_slots, seed, first_read, n_reads, read_len, stride, dist, genome_len,
+	                        (hipStream_t)stream));
+	return 0;
+}
+
+int ntc_kernel_time(ntc_engine* e, double* ms_total, uint64_t* launches)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_kernel_time: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	if (int rc = drain_events(e)) return rc;
+	if (ms_total) *ms_total = e->ms_total;
+	if (launches) *launches = e->launches;
+	return 0;
+}
+
+int ntc_set_profiling(ntc_engine* e, int enable)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_set_profiling: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	e->profiling = enable != 0;
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,388 @@
+// ntc_kernels.hip — gfx950 (CDNA4) kernels of the ntHash -> sample -> count hot path.
+//
+// Replaces, on the device, the reference's per-sequence loop
+//   ntRead / stRead  (ntcard.cpp:147-171)  ->  ntHashIterator (ntHashIterator.hpp:59-86)
+//   -> NTMC64 base/roll (nthash.hpp:467-492,381-390; NTF64 :242-248, NTR64 :251-257, min :275-279)
+//   -> ntComp (ntcard.cpp:132-145)
+// Work decomposition: one LANE walks one read slot with the rolling
+// recurrence; a wave stages its 64 slots (one contiguous region) through LDS with coalesced
+// 16-byte loads; the per-(in,out)-base seed terms come from a 20-entry table in LDS
+// (bank-conflict-free ds_read_b128 + ds_read_b32, see nthash_tables.hpp).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntc_kernels.hpp"
+
+namespace ntc {
+
+// ---- small device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbit(hi, lo, sh); // ({hi,lo} >> sh)[31:0]
+}
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbyte(hi, lo, sh); // ({hi,lo} >> 8*sh)[31:0]
+}
+__device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+	return __builtin_amdgcn_perm(s0, s1, sel); // byte i = {s0,s1}.byte[sel.byte[i]], 0-3 -> s1
+}
+
+// v_perm tables indexed by (byte & 7): 1:A 3:C 7:G 4:T 5:U, 0/2/6: not a base.
+// (the same low-3-bit trick the reference uses for complements, nthash.hpp:16,32)
+//                          idx:   7     6     5     4            3     2     1     0
+constexpr uint32_t kExpS0 = 0x47ff5554u; // 'G', ff, 'U', 'T'
+constexpr uint32_t kExpS1 = 0x43ff41ffu; // 'C', ff, 'A', ff
+constexpr uint32_t kIn6S0 = 0x8000c0c0u; // code<<6 : G=2, -, U=3, T=3
+constexpr uint32_t kIn6S1 = 0x40000000u; //           C=1, -, A=0, -
+constexpr uint32_t kIn4S0 = 0x20003030u; // code<<4
+constexpr uint32_t kIn4S1 = 0x10000000u;
+
+struct Strands {
+	uint32_t flo, fB, fHd; // forward:  L[0..31], L[32] in bit 31, (H<<1)|H[30]
+	uint32_t rlo, rB, rHd; // reverse:  L[0..31], L[32] in bit 0,  (H<<1)|H[30]
+};
+
+// One rolling step (NTF64 + NTR64, nthash.hpp:242-257) with the seed terms of this (in,out) pair.
+__device__ __forceinline__ void roll(Strands& s, const uint4 t, const uint32_t tbb)
+{
+	// forward: fh' = srol1(fh) ^ Tf
+	const uint32_t nflo = alignbit(s.flo, s.fB, 31) ^ t.x;
+	s.fB = s.flo ^ tbb;
+	s.flo = nflo;
+	s.fHd = alignbit(s.fHd, s.fHd << 1, 31) ^ t.y;
+	// reverse: rh' = srol^-1(rh ^ Tr)
+	const uint32_t xlo = s.rlo ^ t.z;
+	const uint32_t xb = s.rB ^ tbb;
+	s.rlo = alignbit(xb, xlo, 1);
+	s.rB = xlo;
+	const uint32_t xh = s.rHd ^ t.w;
+	s.rHd = alignbit(xh >> 1, xh, 1);
+}
+
+// canonical choice (nthash.hpp:275-279): true when the reverse strand is strictly smaller
+__device__ __forceinline__ bool rev_smaller(const Strands& s)
+{
+	if (s.rHd != s.fHd) return s.rHd < s.fHd;
+	const uint32_t fb = s.fB >> 31, rb = s.rB & 1u;
+	if (fb != rb) return rb < fb;
+	return s.rlo < s.flo;
+}
+
+__device__ __forceinline__ uint64_t assemble(uint32_t lo, uint32_t b32, uint32_t hd)
+{
+	return (uint64_t)lo | ((uint64_t)b32 << 32) | ((uint64_t)(hd >> 1) << 33);
+}
+
+template <int MODE>
+struct Emit;
+
+// ------------------------------------------------------------------------------------------------
+// K1 / K1d: MODE 0 = sketch update, MODE 1 = hash dump (validation)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlockThreads) void nthash_kernel(const HashArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	uint32_t* const tabw = reinterpret_cast<uint32_t*>(smem);
+	const unsigned char* const tabA = smem;                    // kSlots x 16 B
+	const unsigned char* const tabB = smem + kSlots * 16;      // kSlots x 16 B (dword 0 used)
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	{
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.tab);
+		for (int i = tid; i < kSlots * 8; i += kBlockThreads)
+			tabw[i] = src[i];
+	}
+	__syncthreads();
+
+	const uint32_t stride = a.stride;
+	const uint32_t k = a.k;
+	unsigned char* const wdata = smem + kTableBytes + (size_t)wave * 64u * stride;
+	const unsigned char* const mine = wdata + (size_t)lane * stride;
+
+	const uint32_t lo0 = 1u << (31 - a.s_bits);                          // sample 0: m in [lo0, 2*lo0)
+	const int32_t lo1 = (int32_t)(((1u << (a.s_bits - 1)) - 1u) << (32 - a.s_bits)); // sample 1: m in [lo1, 2^31)
+	const uint32_t rmask = (1u << a.r_bits) - 1u;
+	const uint32_t rbuck = 1u << a.r_bits;
+
+	const uint64_t n_wb = (a.n_slots + 63) / 64;
+	uint64_t f1_wave = 0;
+
+	for (uint64_t wb = (uint64_t)blockIdx.x * kWavesPerBlock + wave; wb < n_wb;
+	     wb += (uint64_t)gridDim.x * kWavesPerBlock) {
+		const uint64_t slot0 = wb * 64;
+		const uint32_t nvalid = (uint32_t)((a.n_slots - slot0) < 64 ? (a.n_slots - slot0) : 64);
+		// ---- stage the wave's contiguous slot region into LDS (coalesced 16 B per lane) ----
+		{
+			const unsigned char* src = a.slots + slot0 * stride;
+			const uint32_t bytes = nvalid * stride; // multiple of 4
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t off = lane * 16u; off < bytes; off += 1024u) {
+				if (off + 16u <= bytes) {
+					const uint4 v = *reinterpret_cast<const uint4*>(src + off);
+					*reinterpret_cast<uint4*>(wdata + off) = v;
+				} else {
+					for (uint32_t o = off; o < bytes; o += 4)
+						*reinterpret_cast<uint32_t*>(wdata + o) =
+						    *reinterpret_cast<const uint32_t*>(src + o);
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+		// ---- per-lane read geometry ----
+		uint32_t len = a.read_len, wlim = a.read_len;
+		if (a.meta != nullptr && (uint32_t)lane < nvalid) {
+			const uint32_t m = a.meta[slot0 + lane];
+			len = m & 0xffffu;
+			wlim = m >> 16;
+		}
+		int32_t endq = (int32_t)(len < wlim + k - 1 ? len : wlim + k - 1); // steps q in [0,endq)
+		if ((uint32_t)lane >= nvalid || len < k) endq = 0;
+		int32_t maxq = endq;
+		for (int o = 32; o > 0; o >>= 1) {
+			const int32_t other = __shfl_xor(maxq, o);
+			maxq = other > maxq ? other : maxq;
+		}
+		maxq = __builtin_amdgcn_readfirstlane(maxq);
+
+		Strands s = { 0, 0, 0, 0, 0, 0 };
+		// emission allowed from step `nextok` on: k-1 initially, (bad position)+k after a bad byte
+		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff;
+		uint32_t nemit = 0; // dump mode: windows written so far by this lane
+		const uint64_t myslot = slot0 + lane;
+
+		auto do_emit = [&](int32_t q, bool live) {
+			// sample test on the canonical hash's top bits: top bits of min(fh,rh) == min of top bits
+			const uint32_t m = s.fHd < s.rHd ? s.fHd : s.rHd;
+			if (MODE == 0) {
+				const bool c0 = (m ^ lo0) < lo0;
+				const bool c1 = (int32_t)m >= lo1;
+				if (live && (c0 | c1)) {
+					const uint32_t lo = rev_smaller(s) ? s.rlo : s.flo;
+					const uint32_t idx = (lo & rmask) + (c1 ? rbuck : 0u);
+					atomicAdd(a.sketch + idx, 1u);
+				}
+			} else {
+				if (live) {
+					const bool rv = rev_smaller(s);
+					const uint64_t h = rv ? assemble(s.rlo, s.rB & 1u, s.rHd)
+					                      : assemble(s.flo, s.fB >> 31, s.fHd);
+					if (nemit < a.max_win) a.dump[myslot * a.max_win + nemit] = h;
+					++nemit;
+				}
+			}
+			(void)q;
+		};
+
+		const uint32_t n_groups = (uint32_t)(maxq + 3) >> 2;
+		const uint32_t gA = (k - 1) >> 2; // group that contains step k-1
+		const uint32_t shb = (0u - k) & 3u; // byte phase of the out stream
+		for (uint32_t g = 0; g < n_groups; ++g) {
+			const int32_t q0 = (int32_t)(g << 2);
+			const uint32_t w_in = *reinterpret_cast<const uint32_t*>(mine + q0);
+			const uint32_t sel = w_in & 0x07070707u;
+			const uint32_t bad = (perm(kExpS0, kExpS1, sel) ^ w_in) & 0xdfdfdfdfu; // byte != 0: not ACGTU
+			// lanes that are already shut off (inactive / finished) never force the generic path
+			const bool slow = __any(((bad != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff));
+			if (g > gA && !slow) {
+				// ---- steady state: 4 bases, all with an outgoing base, no dirty byte, no read end ----
+				uint32_t w_out;
+				{
+					const int32_t qo = q0 - (int32_t)k; // >= 0 here
+					const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + (qo & ~3));
+					w_out = shb ? alignbyte(p[1], p[0], shb) : p[0];
+				}
+				const uint32_t idx4 = perm(kIn6S0, kIn6S1, sel) |
+				                      perm(kIn4S0, kIn4S1, w_out & 0x07070707u);
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const uint32_t off = (idx4 >> (8 * b)) & 0xffu;
+					const uint4 t = *reinterpret_cast<const uint4*>(tabA + off);
+					const uint32_t tbb = *reinterpret_cast<const uint32_t*>(tabB + off);
+					roll(s, t, tbb);
+					const int32_t q = q0 + b;
+					const bool live = nextok <= q;
+					f1_wave += __popcll(__ballot(live));
+					do_emit(q, live);
+				}
+			} else {
+				// ---- generic path: window filling, dirty bytes, read ends (per base, any mix) ----
+				const uint32_t in4 = perm(kIn4S0, kIn4S1, sel);
+#pragma unroll 1
+				for (int b = 0; b < 4; ++b) {
+					const int32_t q = q0 + b;
+					if (q >= maxq) break;
+					const uint32_t cin = (in4 >> (8 * b)) & 0xffu; // code<<4
+					if (((bad >> (8 * b)) & 0xffu) != 0u) nextok = nextok == 0x7fffffff ? nextok : q + (int32_t)k;
+					if (q >= endq) nextok = 0x7fffffff;
+					uint32_t off;
+					if (q >= (int32_t)k) {
+						const uint32_t co = mine[q - (int32_t)k] & 7u;
+						const uint32_t cout = (perm(kIn4S0, kIn4S1, co)) & 0xffu; // code<<4
+						off = (cin << 2) | cout;
+					} else {
+						off = kMainSlots * 16 + cin;
+					}
+					const uint4 t = *reinterpret_cast<const uint4*>(tabA + off);
+					const uint32_t tbb = *reinterpret_cast<const uint32_t*>(tabB + off);
+					roll(s, t, tbb);
+					const bool live = nextok <= q;
+					f1_wave += __popcll(__ballot(live));
+					do_emit(q, live);
+				}
+			}
+		}
+		if (MODE == 1 && (uint32_t)lane < nvalid) a.dump_count[myslot] = nemit;
+	}
+	if (MODE == 0 && lane == 0 && f1_wave) atomicAdd(a.f1, (unsigned long long)f1_wave);
+}
+
+template __global__ void nthash_kernel<0>(const HashArgs);
+template __global__ void nthash_kernel<1>(const HashArgs);
+
+// ------------------------------------------------------------------------------------------------
+// K2: finalize — value histogram p[2][65536] of one k plane pair + optional uint16 truncation.
+// (compEst's first loop, ntcard.cpp:240-247; the uint16 wrap of ntcard.cpp:142-143 is the & 0xffff)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ sketch,
+                                                       uint64_t n_per_sample, uint32_t* __restrict__ p_hist,
+                                                       uint16_t* __restrict__ out16)
+{
+	// grid.y = sample
+	const unsigned s = blockIdx.y;
+	const uint32_t* src = sketch + (uint64_t)s * n_per_sample;
+	uint16_t* dst = out16 ? out16 + (uint64_t)s * n_per_sample : nullptr;
+	uint32_t* p = p_hist + s * 65536u;
+	uint32_t zeros = 0;
+	const uint64_t n4 = n_per_sample / 4;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+		const uint32_t c[4] = { v.x & 0xffffu, v.y & 0xffffu, v.z & 0xffffu, v.w & 0xffffu };
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (c[j] == 0)
+				++zeros;
+			else
+				atomicAdd(p + c[j], 1u);
+		}
+		if (dst) {
+			uint2 o;
+			o.x = c[0] | (c[1] << 16);
+			o.y = c[2] | (c[3] << 16);
+			reinterpret_cast<uint2*>(dst)[i] = o;
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1)
+		zeros += __shfl_xor(zeros, o);
+	if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(p, zeros);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: synthetic read generator (spec in DESIGN.md, mirrored by oracle/orc_gen_reads)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+	z += 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ unsigned genome_code(uint64_t gseed, uint64_t g)
+{
+	const uint64_t h = mix64(gseed + (g >> 5));
+	return (unsigned)(h >> (2 * (g & 31))) & 3u;
+}
+
+__global__ __launch_bounds__(256) void gen_reads_kernel(unsigned char* __restrict__ out, uint64_t seed,
+                                                        uint64_t first_read, uint64_t n_reads,
+                                                        uint32_t read_len, uint32_t stride, uint32_t dist,
+                                                        uint64_t genome_len)
+{
+	const uint64_t rseed = mix64(seed);
+	const uint64_t gseed = mix64(seed ^ 0x47454E4F4D45ULL);
+	const uint32_t acgt = 0x54474341u; // 'A','C','G','T' little-endian
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads;
+	     i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t r = first_read + i;
+		unsigned char* dst = out + i * (uint64_t)stride;
+		const uint64_t hr = mix64(rseed + r);
+		uint64_t pos = 0, hs = 0, hm = 0, h = 0;
+		unsigned rev = 0;
+		if (dist != 0) {
+			const uint64_t span = genome_len - read_len + 1;
+			pos = __umul64hi(hr, span);
+			hs = mix64(hr ^ 0xA5A5A5A5A5A5A5A5ULL);
+			rev = (unsigned)(hs & 1u);
+		}
+		for (uint32_t j0 = 0; j0 < stride; j0 += 4) {
+			uint32_t word = 0;
+			for (uint32_t t = 0; t < 4; ++t) {
+				const uint32_t j = j0 + t;
+				uint32_t c = '\n';
+				if (j < read_len) {
+					if (dist == 0) {
+						if ((j & 31) == 0) h = mix64(hr + (j >> 5));
+						c = (acgt >> (8 * ((h >> (2 * (j & 31))) & 3u))) & 0xffu;
+					} else {
+						unsigned code = rev ? 3u - genome_code(gseed, pos + read_len - 1 - j)
+						                    : genome_code(gseed, pos + j);
+						if ((j & 3) == 0) hm = mix64(hs + 1 + (j >> 2));
+						const unsigned u = (unsigned)(hm >> (16 * (j & 3))) & 0xFFFFu;
+						if (u < 655u)
+							c = (acgt >> (8 * ((code + 1u + (u % 3u)) & 3u))) & 0xffu;
+						else if (u < 688u)
+							c = 'N';
+						else
+							c = (acgt >> (8 * code)) & 0xffu;
+					}
+				}
+				word |= c << (8 * t);
+			}
+			*reinterpret_cast<uint32_t*>(dst + j0) = word;
+		}
+	}
+}
+
+// ---- host-side launch helpers (called from ntc_engine.hip) -----------------------------------------
+hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st)
+{
+	if (mode == 0)
+		hipLaunchKernelGGL(nthash_kernel<0>, dim3(grid), dim3(kBlockThreads), smem, st, a);
+	else
+		hipLaunchKernelGGL(nthash_kernel<1>, dim3(grid), dim3(kBlockThreads), smem, st, a);
+	return hipGetLastError();
+}
+
+hipError_t set_hash_smem_limit(size_t smem)
+{
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nthash_kernel<0>),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	if (e != hipSuccess) return e;
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(&nthash_kernel<1>),
+	                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
+                           uint16_t* out16, hipStream_t st)
+{
+	hipLaunchKernelGGL(finalize_kernel, dim3(2048, 2), dim3(256), 0, st, sketch, n_per_sample, p_hist, out16);
+	return hipGetLastError();
+}
+
+hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
+                      uint32_t stride, uint32_t dist, uint64_t glen, hipStream_t st)
+{
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	if (blocks == 0) blocks = 1;
+	hipLaunchKernelGGL(gen_reads_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, seed, first, n, len,
+	                   stride, dist, glen);
+	return hipGetLastError();
+}
+
+} // namespace ntc

@@ -1,0 +1,37 @@
+// ntc_kernels.hpp — argument blocks and launch helpers shared by ntc_kernels.hip / ntc_engine.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nthash_tables.hpp"
+
+namespace ntc {
+
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr int kTableBytes = kSlots * 32; // A (20 x 16 B) + B (20 x 16 B)
+
+struct HashArgs {
+	const unsigned char* slots; // [n_slots][stride] raw read bytes, slot i at i*stride
+	const uint32_t* meta;       // optional [n_slots]: len | (window-start limit << 16); NULL: uniform
+	uint64_t n_slots;
+	uint32_t stride;            // bytes per slot, multiple of 4
+	uint32_t read_len;          // uniform read length when meta == NULL
+	uint32_t k;
+	uint32_t r_bits, s_bits;
+	uint32_t max_win;           // dump mode: capacity per read
+	uint32_t* sketch;           // MODE 0: uint32 [2][1<<r_bits] plane pair of this k
+	unsigned long long* f1;     // MODE 0: F1 of this k
+	uint64_t* dump;             // MODE 1: [n_slots][max_win]
+	uint32_t* dump_count;       // MODE 1: [n_slots]
+	HashTables tab;
+};
+
+hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
+hipError_t set_hash_smem_limit(size_t smem);
+hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
+                           uint16_t* out16, hipStream_t st);
+hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
+                      uint32_t stride, uint32_t dist, uint64_t glen, hipStream_t st);
+
+} // namespace ntc

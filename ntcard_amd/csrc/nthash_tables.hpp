@@ -1,0 +1,76 @@
+// nthash_tables.hpp — host-side derivation of the per-k lookup tables the HIP kernels stage in LDS.
+//
+// Everything is derived from the four base seeds (nthash.hpp:25-28) and the split-rotate rule
+// (nthash.hpp:186-217: low 33 bits and high 31 bits rotate independently); the reference's
+// msTab33r/msTab31l tables (nthash.hpp:66-183) are exactly srol^i(seed) and are NOT copied.
+//
+// Device representation of one strand's 64-bit hash x = L | H<<33 (L: 33 bits, H: 31 bits):
+//   lo : L[0..31]
+//   B  : one bit, L[32]   (forward strand keeps it in bit 31 of a scratch register, reverse in bit 0)
+//   Hd : (H << 1) | H[30] (bit 0 duplicates bit 31, so both 31-bit rotates are 2 VALU ops and
+//                          unsigned compares of Hd order exactly like H)
+// One table entry per (in-base, out-base) pair:
+//   A[slot] = { Tf.lo, Tf.Hd, Tr.lo, Tr.Hd }   (one ds_read_b128)
+//   B[slot] = bit31: Tf.L[32], bit0: Tr.L[32]  (one ds_read_b32)
+// with  Tf = seed(in) ^ srol^k(seed(out))            (NTF64 roll, nthash.hpp:242-248)
+//       Tr = comp(out) ^ srol^k(comp(in))            (NTR64 roll, nthash.hpp:251-257, XOR-before-rotate)
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+namespace ntc {
+
+constexpr uint64_t kSeed[4] = { 0x3c8bfbb395c60474ULL,   // A
+	                            0x3193c18562a02b4cULL,   // C
+	                            0x20323ed082572324ULL,   // G
+	                            0x295549f54be24456ULL }; // T (and U)
+
+// code: A=0 C=1 G=2 T=3; complement = 3 - code
+inline uint64_t seed_of(unsigned code) { return kSeed[code & 3]; }
+inline uint64_t comp_of(unsigned code) { return kSeed[3 - (code & 3)]; }
+
+inline uint64_t srol(uint64_t x, unsigned n)
+{
+	const uint64_t M33 = (1ULL << 33) - 1, M31 = (1ULL << 31) - 1;
+	uint64_t lo = x & M33, hi = x >> 33;
+	unsigned a = n % 33u, b = n % 31u;
+	if (a) lo = ((lo << a) | (lo >> (33u - a))) & M33;
+	if (b) hi = ((hi << b) | (hi >> (31u - b))) & M31;
+	return lo | (hi << 33);
+}
+
+inline uint32_t lo_of(uint64_t x) { return (uint32_t)x; }
+inline uint32_t b32_of(uint64_t x) { return (uint32_t)((x >> 32) & 1u); }
+inline uint32_t hd_of(uint64_t x)
+{
+	uint32_t h = (uint32_t)(x >> 33); // 31 bits
+	return (h << 1) | (h >> 30);
+}
+
+// slots 0..15: in*4+out (steady state); slots 16..19: in with "no out base yet" (window filling)
+constexpr int kMainSlots = 16;
+constexpr int kSlots = 20;
+
+struct alignas(16) HashTables {
+	uint32_t A[kSlots][4]; // {Tf.lo, Tf.Hd, Tr.lo, Tr.Hd}
+	uint32_t B[kSlots][4]; // [0] = bit31:Tf.L[32] | bit0:Tr.L[32]; [1..3] spare (gap tables reuse)
+};
+
+inline void build_tables(unsigned k, HashTables& t)
+{
+	std::memset(&t, 0, sizeof t);
+	for (int slot = 0; slot < kSlots; ++slot) {
+		unsigned in = slot < kMainSlots ? (unsigned)slot >> 2 : (unsigned)slot - kMainSlots;
+		bool has_out = slot < kMainSlots;
+		unsigned out = (unsigned)slot & 3;
+		uint64_t tf = seed_of(in) ^ (has_out ? srol(seed_of(out), k) : 0);
+		uint64_t tr = (has_out ? comp_of(out) : 0) ^ srol(comp_of(in), k);
+		t.A[slot][0] = lo_of(tf);
+		t.A[slot][1] = hd_of(tf);
+		t.A[slot][2] = lo_of(tr);
+		t.A[slot][3] = hd_of(tr);
+		t.B[slot][0] = (b32_of(tf) << 31) | b32_of(tr);
+	}
+}
+
+} // namespace ntc

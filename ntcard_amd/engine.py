@@ -1,0 +1,136 @@
+"""Python mirror of the reference seam over the C ABI (ctypes); torch is plumbing only
+(device memory, streams, torch.distributed for the multi-GPU sketch merge).
+
+Names follow the reference: an `Engine` owns t_Counter and F1 (ntcard.cpp:433-439), `submit*`
+is a batch of ntRead/stRead calls (ntcard.cpp:147-171), `finish` returns what compEst consumes
+(ntcard.cpp:237-247), `estimate` is compEst's recurrence (ntcard.cpp:249-274) and `write_hist`
+is outDefault's body (ntcard.cpp:291-294).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import NtcConfig, NtcError, check
+
+SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
+
+
+def s_bits_for_input(total_bytes, requested=11):
+    """The reference's size rule (ntcard.cpp:427-431); the caller applies it before Engine()."""
+    return 7 if total_bytes < SIZE_RULE_BYTES else requested
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    def __init__(self, klist, gap=0, r_bits=27, s_bits=7, device=0, stream=None, ext_sketch=None, ext_f1=None):
+        self._lib = _abi.lib()
+        self.klist = [int(k) for k in klist]
+        self.gap, self.r_bits, self.s_bits, self.device = int(gap), int(r_bits), int(s_bits), int(device)
+        self._karr = (C.c_uint32 * len(self.klist))(*self.klist)
+        cfg = NtcConfig()
+        cfg.n_k = len(self.klist)
+        cfg.k = C.cast(self._karr, C.POINTER(C.c_uint32))
+        cfg.gap, cfg.r_bits, cfg.s_bits, cfg.device = self.gap, self.r_bits, self.s_bits, self.device
+        cfg.stream = C.c_void_p(stream) if stream else None
+        self._keep = (ext_sketch, ext_f1)  # keep torch tensors alive
+        cfg.ext_sketch = C.c_void_p(ext_sketch.data_ptr()) if ext_sketch is not None else None
+        cfg.ext_f1 = C.c_void_p(ext_f1.data_ptr()) if ext_f1 is not None else None
+        cfg.flags = 0
+        h = C.c_void_p()
+        check(self._lib.ntc_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ntc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        check(self._lib.ntc_reset(self._h))
+
+    # -- the seam ----------------------------------------------------------------------------
+    def submit(self, bases, offsets):
+        """bases: uint8 array / bytes of concatenated reads; offsets: uint64[n+1]."""
+        b = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if b.size == 0:
+            b = np.zeros(1, dtype=np.uint8)
+        check(self._lib.ntc_submit(self._h, _np_ptr(b), _np_ptr(o), len(o) - 1))
+
+    def submit_reads(self, reads):
+        offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        if reads:
+            offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        self.submit(b"".join(reads), offs)
+
+    def submit_device(self, d_slots_ptr, n_reads, read_len, stride):
+        check(self._lib.ntc_submit_device(self._h, C.c_void_p(d_slots_ptr), n_reads, read_len, stride))
+
+    def sync(self):
+        check(self._lib.ntc_sync(self._h))
+
+    def finish(self, counters=False, p_hist=True):
+        """-> (t_counter uint16[nk,2,2^r] | None, p_hist uint32[nk,2,65536] | None, f1 uint64[nk])"""
+        nk = len(self.klist)
+        tc = np.zeros((nk, 2, 1 << self.r_bits), dtype=np.uint16) if counters else None
+        ph = np.zeros((nk, 2, 65536), dtype=np.uint32) if p_hist else None
+        f1 = np.zeros(nk, dtype=np.uint64)
+        check(self._lib.ntc_finish(self._h, _np_ptr(tc) if counters else None, _np_ptr(ph) if p_hist else None, _np_ptr(f1)))
+        return tc, ph, f1
+
+    def device_state(self):
+        sk, n, f1 = C.c_void_p(), C.c_uint64(), C.c_void_p()
+        check(self._lib.ntc_device_state(self._h, C.byref(sk), C.byref(n), C.byref(f1)))
+        return sk.value, n.value, f1.value
+
+    def set_profiling(self, on=True):
+        check(self._lib.ntc_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        check(self._lib.ntc_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+# -- stateless entry points ---------------------------------------------------------------------
+def estimate(p_hist_k, r_bits, s_bits, cov_max=1000):
+    """compEst for one k from p[2][65536] -> (F0, f[0..cov_max])"""
+    p = np.ascontiguousarray(p_hist_k, dtype=np.uint32)
+    assert p.shape == (2, 65536)
+    cov_max = min(int(cov_max), 65535)
+    f0 = C.c_double()
+    f = np.zeros(cov_max + 1, dtype=np.float64)
+    check(_abi.lib().ntc_estimate(_np_ptr(p), r_bits, s_bits, cov_max, C.byref(f0), _np_ptr(f)))
+    return f0.value, f
+
+
+def write_hist(path, f1, F0, f, cov_max=1000):
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    check(_abi.lib().ntc_write_hist(str(path).encode(), int(f1), float(F0), _np_ptr(f), min(int(cov_max), 65535)))
+
+
+def gen_reads_device(d_ptr, seed, first, n, read_len, stride, dist, genome_len=100_000_000, device=0, stream=None):
+    check(_abi.lib().ntc_gen_reads_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_ptr), seed, first, n,
+                                          read_len, stride, dist, genome_len))
+
+
+def hash_dump_device(d_slots_ptr, n_reads, read_len, stride, k, gap, max_win, d_hash_ptr, d_count_ptr, device=0, stream=None):
+    check(_abi.lib().ntc_hash_dump_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_slots_ptr), n_reads,
+                                          read_len, stride, k, gap, max_win, C.c_void_p(d_hash_ptr), C.c_void_p(d_count_ptr)))

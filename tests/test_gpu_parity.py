@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs (bit-exact: integer/byte work), against the committed golden fixtures produced by the
+real reference, and — at sizes the oracle cannot reach quickly — through size-independent properties.
+"""
+import gzip
+import json
+import os
+import random
+import threading
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def nt():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device (run on the MI355X box)"
+    import ntcard_amd
+    return ntcard_amd
+
+
+def to_slots(reads, stride=None):
+    L = max((len(r) for r in reads), default=0)
+    stride = stride or max(4, (L + 3) & ~3)
+    buf = np.full(len(reads) * stride + 16, 10, dtype=np.uint8)
+    for i, r in enumerate(reads):
+        buf[i * stride: i * stride + len(r)] = np.frombuffer(r, dtype=np.uint8)
+    return buf, stride
+
+
+def rseq(rng, n, pn=0.02, plow=0.1, bad="NnRYKMSWBDHV-.*Xx\r"):
+    out = []
+    for _ in range(n):
+        r = rng.random()
+        if r < pn:
+            out.append(rng.choice(bad))
+        elif r < pn + plow:
+            out.append(rng.choice("acgtu"))
+        else:
+            out.append(rng.choice("ACGTU"))
+    return "".join(out).encode()
+
+
+def small_reads(golden_dir):
+    with gzip.open(os.path.join(golden_dir, "reads_small.fq.gz"), "rb") as f:
+        lines = f.read().split(b"\n")
+    return [lines[i] for i in range(1, len(lines) - 1, 4)]
+
+
+# ------------------------------------------------------------------------------------------------
+def test_generator_matches_oracle(nt):
+    for dist, glen in ((0, 0), (1, 100_000), (1, 100_000_000)):
+        n, L, stride = 3000, 150, 152
+        d = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+        nt.gen_reads_device(d.data_ptr(), 42, 1_000_000, n, L, stride, dist, genome_len=max(glen, L))
+        torch.cuda.synchronize()
+        ref = orc.gen_reads(42, 1_000_000, n, L, stride, dist, genome_len=max(glen, L))
+        assert np.array_equal(d.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("L", [150, 151, 70, 33, 253])
+def test_hash_dump_matches_oracle(nt, L):
+    """K1d: every canonical hash of every clean window, vs ntHashIterator semantics in the oracle"""
+    rng = random.Random(1000 + L)
+    reads = [rseq(rng, L, pn=rng.choice([0.0, 0.0, 0.01, 0.05, 0.3])) for _ in range(333)]
+    reads[0] = b"N" * L
+    reads[1] = (b"ACGT" * 100)[:L]
+    reads[2] = (b"acgu" * 100)[:L]
+    buf, stride = to_slots(reads)
+    d = torch.from_numpy(buf).cuda()
+    for k in (1, 2, 3, 4, 5, 12, 20, 31, 32, 33, 34, 35, 64, 70, 96, 128, 200):
+        maxw = max(L - k + 1, 1)
+        dh = torch.zeros(len(reads) * maxw, dtype=torch.int64, device="cuda")
+        dc = torch.full((len(reads),), -1, dtype=torch.int32, device="cuda")
+        nt.hash_dump_device(d.data_ptr(), len(reads), L, stride, k, 0, maxw, dh.data_ptr(), dc.data_ptr())
+        torch.cuda.synchronize()
+        hh = dh.cpu().numpy().view(np.uint64).reshape(len(reads), maxw)
+        cc = dc.cpu().numpy()
+        for i, r in enumerate(reads):
+            oh, _ = orc.hash_read(r, k)
+            assert cc[i] == len(oh), (L, k, i, cc[i], len(oh))
+            assert np.array_equal(hh[i, : len(oh)], oh), (L, k, i)
+
+
+def test_known_answer_on_device(nt):
+    # vendor/ntHash/unittest/UnitTests.cpp:39,45 — the reference's own invariant value
+    buf, stride = to_slots([b"ACGTACACTGGACTGAGTCT"])
+    d = torch.from_numpy(buf).cuda()
+    dh = torch.zeros(1, dtype=torch.int64, device="cuda")
+    dc = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nt.hash_dump_device(d.data_ptr(), 1, 20, stride, 20, 0, 1, dh.data_ptr(), dc.data_ptr())
+    torch.cuda.synchronize()
+    assert int(dc[0]) == 1
+    assert int(dh.cpu().numpy().view(np.uint64)[0]) == 10434435546371013747
+
+
+@pytest.mark.parametrize("dist,klist,r_bits,s_bits", [
+    (1, [32], 20, 7), (0, [32], 20, 7), (1, [32], 22, 11), (1, [12], 18, 7), (1, [33], 20, 7),
+    (1, [31], 19, 5), (1, [16, 24, 32, 48], 19, 7), (1, [32, 64, 96, 128], 20, 7), (0, [150], 16, 2),
+])
+def test_sketch_device_batch_matches_oracle(nt, dist, klist, r_bits, s_bits):
+    n, L, stride = 20_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 9, 0, n, L, stride, dist, genome_len=300_000)
+    torch.cuda.synchronize()
+    host = d[: n * stride].cpu().numpy().reshape(n, stride)
+    reads = [host[i, :L].tobytes() for i in range(n)]
+    with nt.Engine(klist, r_bits=r_bits, s_bits=s_bits) as e:
+        e.submit_device(d.data_ptr(), n, L, stride)
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads(reads, klist, 0, r_bits, s_bits)
+    assert np.array_equal(f1, of1)
+    assert np.array_equal(tc, oc)
+    for ki in range(len(klist)):
+        assert np.array_equal(ph[ki], orc.value_hist(oc[ki], r_bits))
+
+
+def test_host_submit_ragged_and_chunked(nt):
+    """ntc_submit: raw host buffers, reads of any length (empty, shorter than k, long sequences that
+    the shim splits into overlapping chunks), dirty bytes everywhere"""
+    rng = random.Random(77)
+    reads = [rseq(rng, rng.choice([0, 1, 5, 31, 32, 33, 100, 150, 151, 250]), pn=rng.choice([0, 0.01, 0.1])) for _ in range(3000)]
+    reads += [rseq(rng, n, pn=0.001) for n in (257, 300, 1000, 5000, 20_000, 70_000)]
+    rng.shuffle(reads)
+    for klist in ([32], [12, 33, 64], [128]):
+        with nt.Engine(klist, r_bits=18, s_bits=4) as e:
+            e.submit_reads(reads)
+            tc, ph, f1 = e.finish(counters=True)
+        oc, of1 = orc.sketch_reads(reads, klist, 0, 18, 4)
+        assert np.array_equal(f1, of1), (klist, f1, of1)
+        assert np.array_equal(tc, oc), klist
+    # short-read-only batch (uniform, non-chunked path) and an all-too-short batch
+    shorts = [rseq(rng, 75, pn=0.01) for _ in range(1000)]
+    with nt.Engine([20], r_bits=16, s_bits=3) as e:
+        e.submit_reads(shorts)
+        e.submit_reads([b"ACGT", b"", b"ACGTACGT"])
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads(shorts, [20], 0, 16, 3)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+
+
+def test_golden_hist_from_reference(nt, golden_dir, tmp_path):
+    """the reference CLI's own .hist outputs (default rBits = 27) reproduced byte for byte"""
+    reads = small_reads(golden_dir)
+    cases = [("ref_k12__out_k12.hist", [12], 27, 7, 1000), ("ref_k32__out_k32.hist", [32], 27, 7, 1000),
+             ("ref_k20_c50__out_k20.hist", [20], 27, 7, 50), ("ref_k24_s11_r22__out_k24.hist", [24], 22, 7, 1000)]
+    for name, klist, rb, sb, cov in cases:
+        with nt.Engine(klist, r_bits=rb, s_bits=sb) as e:
+            e.submit_reads(reads)
+            _, ph, f1 = e.finish()
+        F0, f = nt.estimate(ph[0], rb, sb, cov)
+        out = tmp_path / name
+        nt.write_hist(out, f1[0], F0, f, cov)
+        assert out.read_bytes() == open(os.path.join(golden_dir, name), "rb").read(), name
+    with nt.Engine([16, 24, 32, 48], r_bits=27, s_bits=7) as e:
+        e.submit_reads(reads)
+        _, ph, f1 = e.finish()
+    for ki, k in enumerate([16, 24, 32, 48]):
+        F0, f = nt.estimate(ph[ki], 27, 7, 1000)
+        out = tmp_path / f"m_k{k}.hist"
+        nt.write_hist(out, f1[ki], F0, f, 1000)
+        assert out.read_bytes() == open(os.path.join(golden_dir, f"ref_multi__out_k{k}.hist"), "rb").read(), k
+
+
+def test_golden_sketch_digests(nt, golden_dir):
+    reads = small_reads(golden_dir)
+    with open(os.path.join(golden_dir, "sketch_goldens.json")) as f:
+        gold = json.load(f)
+    for ent in gold:
+        if ent["gap"] != 0 or ent["r_bits"] > 22:
+            continue
+        with nt.Engine(ent["klist"], r_bits=ent["r_bits"], s_bits=ent["s_bits"]) as e:
+            e.submit_reads(reads)
+            tc, ph, f1 = e.finish(counters=True)
+        assert [int(x) for x in f1] == ent["f1"]
+        for ki, pl in enumerate(ent["planes"]):
+            assert "%016x" % orc.fnv1a64(tc[ki]) == pl["fnv1a64"]
+            nz = [[int(s), int(v), int(ph[ki][s, v])] for s in range(2) for v in np.nonzero(ph[ki][s])[0]]
+            assert nz == pl["p_nonzero"]
+
+
+def test_uint16_wraparound(nt):
+    rng = random.Random(3)
+    seq = "".join(rng.choice("ACGT") for _ in range(4000)).encode()
+    h, pos = orc.hash_read(seq, 32)
+    i = next(i for i, x in enumerate(h) if orc.lib().orc_sample_of(int(x), 7) < 2)
+    km = seq[pos[i]: pos[i] + 32]
+    with nt.Engine([32], r_bits=12, s_bits=7) as e:
+        e.submit_reads([km] * 65537)
+        tc, ph, f1 = e.finish(counters=True)
+    assert int(f1[0]) == 65537 and int(tc.sum()) == 1  # 65536 increments wrap to 0, +1
+    assert int(ph[0].sum()) == 2 << 12
+
+
+def test_batching_order_and_reset_invariance(nt):
+    """results do not depend on batch boundaries or submit order (commutative atomics)"""
+    n, L, stride = 50_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 11, 0, n, L, stride, 1, genome_len=1_000_000)
+    with nt.Engine([32], r_bits=22, s_bits=7) as e:
+        e.submit_device(d.data_ptr(), n, L, stride)
+        a_tc, a_ph, a_f1 = e.finish(counters=True)
+        e.reset()
+        cuts = [0, 64 * 3, 64 * 3 + 17 * 64, 30_016, n]  # device batches must start on 16-byte aligned slots
+        order = [2, 0, 3, 1]
+        for j in order:
+            lo, hi = cuts[j], cuts[j + 1]
+            e.submit_device(d.data_ptr() + lo * stride, hi - lo, L, stride)
+        b_tc, b_ph, b_f1 = e.finish(counters=True)
+    assert np.array_equal(a_f1, b_f1) and np.array_equal(a_tc, b_tc) and np.array_equal(a_ph, b_ph)
+
+
+def test_concurrent_submit_is_thread_safe(nt):
+    rng = random.Random(5)
+    parts = [[rseq(rng, 150, pn=0.005) for _ in range(2000)] for _ in range(4)]
+    with nt.Engine([32], r_bits=18, s_bits=5) as e:
+        ts = [threading.Thread(target=e.submit_reads, args=(p,)) for p in parts]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads([r for p in parts for r in p], [32], 0, 18, 5)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+
+
+def test_full_size_properties(nt):
+    """config-2 shape at a size the CPU cannot check quickly: 4 M x 150 bp, k = 32, rBits = 27.
+    F1 closed form (uniform reads have no dirty bytes), increments == sum of counters, and the
+    value histogram accounts for every bucket; sharded == whole (the multi-GPU merge identity)."""
+    n, L, stride, k = 4_000_000, 150, 152, 32
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 1, 0, n, L, stride, 0)
+    with nt.Engine([k], r_bits=27, s_bits=7) as e:
+        e.submit_device(d.data_ptr(), n, L, stride)
+        _, ph, f1 = e.finish()
+        assert int(f1[0]) == n * (L - k + 1)
+        assert int(ph[0].sum()) == 2 << 27
+        hits = int((ph[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
+        assert abs(hits / (n * (L - k + 1)) - 2.0 ** -6) < 2e-4  # two samples of ~2^-7 each
+        sk, ncnt, _ = e.device_state()
+        assert ncnt == 2 << 27
+    half = n // 2
+    with nt.Engine([k], r_bits=27, s_bits=7) as e1, nt.Engine([k], r_bits=27, s_bits=7) as e2:
+        e1.submit_device(d.data_ptr(), half, L, stride)
+        e2.submit_device(d.data_ptr() + half * stride, n - half, L, stride)
+        _, p1, f1a = e1.finish()
+        _, p2, f1b = e2.finish()
+    assert int(f1a[0] + f1b[0]) == n * (L - k + 1)
+    h1 = int((p1[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
+    h2 = int((p2[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
+    assert h1 + h2 == hits
