@@ -58,6 +58,7 @@ typedef struct {
 } ntc_config;
 
 #define NTC_FLAG_NONE 0u
+#define NTC_FLAG_SIMPLE_KERNEL 1u /* run the simple validation kernel instead of the tuned one */
 
 uint32_t ntc_abi_version(void);
 uint32_t ntc_max_k(void);
@@ -76,8 +77,10 @@ int ntc_reset(ntc_engine *e);                    /* re-zero sketch and F1 */
 int ntc_submit(ntc_engine *e, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 
 /* Same for a batch that is already DEVICE-resident in the engine's slot layout: read i occupies
- * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Asynchronous on
- * the engine's stream; the buffer must stay valid until ntc_sync/ntc_finish.                    */
+ * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Padding bytes
+ * (read_len..stride) are never hashed; filling them with a base letter ('A') keeps the kernel on
+ * its fast path (a non-ACGTU byte anywhere in a wave's 64 slots selects the dirty-window path).
+ * Asynchronous on the engine's stream; the buffer must stay valid until ntc_sync/ntc_finish.    */
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
                       uint32_t stride);
 
@@ -96,8 +99,8 @@ int ntc_device_state(ntc_engine *e, void **d_sketch_u32, uint64_t *n_counters, v
 
 /* Validation kernel (K1d): canonical hash of every window of ONE k for a device-resident slot
  * batch.  d_hash_out: DEVICE uint64_t [n_reads][max_win], d_count_out: DEVICE uint32_t [n_reads].
- * Window j of read i is valid iff bit 63.. no: hashes are written compacted in window order and
- * d_count_out[i] gives how many (== that read's F1 share), mirroring ntHashIterator
+ * The hashes of read i are written compacted, in window order, and d_count_out[i] says how many
+ * there are (== that read's F1 share; may exceed max_win, then only max_win are stored), mirroring ntHashIterator
  * (ntHashIterator.hpp:59-86) / stHashIterator when gap != 0.                                     */
 int ntc_hash_dump_device(int32_t device, void *stream, const void *d_slots, uint64_t n_reads,
                          uint32_t read_len, uint32_t stride, uint32_t k, uint32_t gap,

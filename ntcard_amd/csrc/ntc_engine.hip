@@ -55,17 +55,25 @@ int device_info(int dev, DevInfo& di)
 	return 0;
 }
 
-size_t smem_for(uint32_t stride) { return (size_t)ntc::kTableBytes + (size_t)ntc::kWavesPerBlock * 64u * stride; }
+// dynamic LDS per block: the simple kernel keeps its tables in the dynamic region, the fast one statically
+size_t smem_for(uint32_t stride, bool fast)
+{
+	return (fast ? 0 : (size_t)ntc::kTableBytes) + (size_t)ntc::kWavesPerBlock * 64u * stride;
+}
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
-int hash_grid(int dev, uint64_t n_slots, uint32_t stride, unsigned& grid, size_t& smem)
+int hash_grid(int dev, uint64_t n_slots, uint32_t stride, bool fast, unsigned& grid, size_t& smem)
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
-	smem = smem_for(stride);
-	if (smem > 160 * 1024) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, smem);
-	HIP_TRY(ntc::set_hash_smem_limit(smem));
-	unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
+	smem = smem_for(stride, fast);
+	const size_t total = smem + (fast ? (size_t)ntc::kTableBytes : 0);
+	if (total > 160 * 1024) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, total);
+	if (fast)
+		HIP_TRY(ntc::set_sketch_fast_smem_limit(smem));
+	else
+		HIP_TRY(ntc::set_hash_smem_limit(smem));
+	unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / total));
 	uint64_t need = (n_slots + 64 * ntc::kWavesPerBlock - 1) / (64 * ntc::kWavesPerBlock);
 	uint64_t cap = (uint64_t)di.cus * per_cu;
 	grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, cap));
@@ -84,6 +92,9 @@ struct ntc_engine {
 	bool own_sketch = false, own_f1 = false;
 	uint32_t* d_phist = nullptr; // [nk][2][65536]
 	uint16_t* d_out16 = nullptr; // [2][1<<r_bits] scratch for finish
+	void* d_queue = nullptr;     // fast kernel: per-wave hit queues
+	size_t queue_cap = 0;
+	bool simple_kernel = false;  // NTC_FLAG_SIMPLE_KERNEL
 	// host-submit staging (grow-only)
 	unsigned char* h_stage = nullptr;
 	uint32_t* h_meta = nullptr;
@@ -111,8 +122,8 @@ int drain_events(ntc_engine* e)
 		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
 		e->ms_total += ms;
 		e->launches += 1;
-		hipEventDestroy(pr.first);
-		hipEventDestroy(pr.second);
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
 	}
 	e->pending.clear();
 	return 0;
@@ -125,7 +136,22 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	if (n_slots == 0) return 0;
 	unsigned grid = 0;
 	size_t smem = 0;
-	if (int rc = hash_grid(e->device, n_slots, stride, grid, smem)) return rc;
+	const bool fast = !e->simple_kernel;
+	if (int rc = hash_grid(e->device, n_slots, stride, fast, grid, smem)) return rc;
+	// every lane can queue at most one hit per window of its slot: `stride` rows always suffice
+	const uint32_t queue_rows = stride;
+	if (fast) {
+		const size_t need = (size_t)grid * ntc::kWavesPerBlock * queue_rows * 1024u;
+		if (need > e->queue_cap) {
+			HIP_TRY(hipStreamSynchronize(e->stream));
+			if (e->d_queue) (void)hipFree(e->d_queue);
+			e->d_queue = nullptr;
+			e->queue_cap = 0;
+			if (hipMalloc(&e->d_queue, need) != hipSuccess)
+				return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of hit queues on device", need);
+			e->queue_cap = need;
+		}
+	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		ntc::HashArgs a;
 		std::memset(&a, 0, sizeof a);
@@ -146,7 +172,12 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			HIP_TRY(hipEventCreate(&ev1));
 			HIP_TRY(hipEventRecord(ev0, e->stream));
 		}
-		HIP_TRY(ntc::launch_hash(0, a, grid, smem, e->stream));
+		a.queue = e->d_queue;
+		a.queue_rows = queue_rows;
+		if (fast)
+			HIP_TRY(ntc::launch_sketch_fast(a, grid, smem, e->stream));
+		else
+			HIP_TRY(ntc::launch_hash(0, a, grid, smem, e->stream));
 		if (e->profiling) {
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
@@ -193,6 +224,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	e->gap = cfg->gap;
 	e->r_bits = cfg->r_bits;
 	e->s_bits = cfg->s_bits;
+	e->simple_kernel = (cfg->flags & NTC_FLAG_SIMPLE_KERNEL) != 0;
 	const size_t sk_bytes = e->klist.size() * e->plane_elems() * sizeof(uint32_t);
 	if (cfg->ext_sketch) {
 		e->d_sketch = (uint32_t*)cfg->ext_sketch;
@@ -228,20 +260,21 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 void ntc_destroy(ntc_engine* e)
 {
 	if (!e) return;
-	hipSetDevice(e->device);
-	hipStreamSynchronize(e->stream);
+	(void)hipSetDevice(e->device);
+	(void)hipStreamSynchronize(e->stream);
 	for (auto& pr : e->pending) {
-		hipEventDestroy(pr.first);
-		hipEventDestroy(pr.second);
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
 	}
 	if (e->own_sketch && e->d_sketch) hipFree(e->d_sketch);
 	if (e->own_f1 && e->d_f1) hipFree(e->d_f1);
-	if (e->d_phist) hipFree(e->d_phist);
-	if (e->d_out16) hipFree(e->d_out16);
-	if (e->d_stage) hipFree(e->d_stage);
-	if (e->d_meta) hipFree(e->d_meta);
-	if (e->h_stage) hipHostFree(e->h_stage);
-	if (e->h_meta) hipHostFree(e->h_meta);
+	if (e->d_phist) (void)hipFree(e->d_phist);
+	if (e->d_out16) (void)hipFree(e->d_out16);
+	if (e->d_queue) (void)hipFree(e->d_queue);
+	if (e->d_stage) (void)hipFree(e->d_stage);
+	if (e->d_meta) (void)hipFree(e->d_meta);
+	if (e->h_stage) (void)hipHostFree(e->h_stage);
+	if (e->h_meta) (void)hipHostFree(e->h_meta);
 	delete e;
 }
 
@@ -309,7 +342,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	const size_t need = (size_t)n_slots * stride + 16;
 	if (need > e->h_stage_cap) {
-		if (e->h_stage) hipHostFree(e->h_stage);
+		if (e->h_stage) (void)hipHostFree(e->h_stage);
 		e->h_stage = nullptr;
 		size_t cap = std::max(need, e->h_stage_cap * 2);
 		if (hipHostMalloc((void**)&e->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
@@ -319,7 +352,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 		e->h_stage_cap = cap;
 	}
 	if (need > e->d_stage_cap) {
-		if (e->d_stage) hipFree(e->d_stage);
+		if (e->d_stage) (void)hipFree(e->d_stage);
 		e->d_stage = nullptr;
 		size_t cap = std::max(need, e->d_stage_cap * 2);
 		if (hipMalloc((void**)&e->d_stage, cap) != hipSuccess) {
@@ -330,8 +363,8 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 	}
 	const bool need_meta = chunked || !uniform;
 	if (need_meta && n_slots > e->h_meta_cap) {
-		if (e->h_meta) hipHostFree(e->h_meta);
-		if (e->d_meta) hipFree(e->d_meta);
+		if (e->h_meta) (void)hipHostFree(e->h_meta);
+		if (e->d_meta) (void)hipFree(e->d_meta);
 		e->h_meta = nullptr;
 		e->d_meta = nullptr;
 		size_t cap = std::max<size_t>(n_slots, e->h_meta_cap * 2);
@@ -351,7 +384,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 		if (!chunked) {
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src, l);
-			std::memset(dst + l, '\n', stride - l);
+			std::memset(dst + l, 'A', stride - l);
 			if (need_meta) e->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
 			++slot;
 			continue;
@@ -360,7 +393,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 		if (l <= cap_chunk) {
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src, l);
-			std::memset(dst + l, '\n', stride - l);
+			std::memset(dst + l, 'A', stride - l);
 			e->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
 			++slot;
 			continue;
@@ -370,7 +403,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 			const bool last = start + cap_chunk >= l;
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src + start, nbytes);
-			std::memset(dst + nbytes, '\n', stride - nbytes);
+			std::memset(dst + nbytes, 'A', stride - nbytes);
 			e->h_meta[slot] = (uint32_t)nbytes | ((uint32_t)(last ? nbytes : ch) << 16);
 			++slot;
 			if (last) break;
@@ -445,7 +478,7 @@ int ntc_hash_dump_device(int32_t device, void* stream, const void* d_slots, uint
 	HIP_TRY(hipSetDevice(device));
 	unsigned grid = 0;
 	size_t smem = 0;
-	if (int rc = hash_grid(device, n_reads, stride, grid, smem)) return rc;
+	if (int rc = hash_grid(device, n_reads, stride, false, grid, smem)) return rc;
 	ntc::HashArgs a;
 	std::memset(&a, 0, sizeof a);
 	a.slots = (const unsigned char*)d_slots;

@@ -24,11 +24,15 @@ struct HashArgs {
 	unsigned long long* f1;     // MODE 0: F1 of this k
 	uint64_t* dump;             // MODE 1: [n_slots][max_win]
 	uint32_t* dump_count;       // MODE 1: [n_slots]
+	void* queue;                // fast kernel: per-wave hit queues, [grid*4][queue_rows][64] x 16 B
+	uint32_t queue_rows;        // rows (hits per lane) each wave queue can hold
 	HashTables tab;
 };
 
 hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_hash_smem_limit(size_t smem);
+hipError_t launch_sketch_fast(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
+hipError_t set_sketch_fast_smem_limit(size_t smem);
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
                            uint16_t* out16, hipStream_t st);
 hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,

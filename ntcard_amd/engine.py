@@ -13,6 +13,7 @@ import numpy as np
 from . import _abi
 from ._abi import NtcConfig, NtcError, check
 
+FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 
 
@@ -26,7 +27,7 @@ def _np_ptr(a):
 
 
 class Engine:
-    def __init__(self, klist, gap=0, r_bits=27, s_bits=7, device=0, stream=None, ext_sketch=None, ext_f1=None):
+    def __init__(self, klist, gap=0, r_bits=27, s_bits=7, device=0, stream=None, ext_sketch=None, ext_f1=None, flags=0):
         self._lib = _abi.lib()
         self.klist = [int(k) for k in klist]
         self.gap, self.r_bits, self.s_bits, self.device = int(gap), int(r_bits), int(s_bits), int(device)
@@ -39,7 +40,7 @@ class Engine:
         self._keep = (ext_sketch, ext_f1)  # keep torch tensors alive
         cfg.ext_sketch = C.c_void_p(ext_sketch.data_ptr()) if ext_sketch is not None else None
         cfg.ext_f1 = C.c_void_p(ext_f1.data_ptr()) if ext_f1 is not None else None
-        cfg.flags = 0
+        cfg.flags = int(flags)
         h = C.c_void_p()
         check(self._lib.ntc_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -411,7 +411,7 @@ void orc_gen_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_
                 dst[j] = c;
             }
         }
-        for (uint32_t j = read_len; j < stride; ++j) dst[j] = '\n';
+        for (uint32_t j = read_len; j < stride; ++j) dst[j] = 'A'; /* padding: never hashed */
     }
 }
 

@@ -121,6 +121,21 @@ def test_sketch_device_batch_matches_oracle(nt, dist, klist, r_bits, s_bits):
         assert np.array_equal(ph[ki], orc.value_hist(oc[ki], r_bits))
 
 
+def test_simple_and_tuned_kernels_agree(nt):
+    """two independently written kernels (ntc_kernels.hip vs ntc_sketch_fast.hip) on dirty, ragged input"""
+    rng = random.Random(4242)
+    reads = [rseq(rng, rng.choice([40, 100, 149, 150, 150, 150, 151, 200]), pn=rng.choice([0, 0, 0.003, 0.05])) for _ in range(6000)]
+    for klist, sb in (([32], 7), ([25, 61], 3)):
+        res = []
+        for flags in (0, nt.FLAG_SIMPLE_KERNEL):
+            with nt.Engine(klist, r_bits=19, s_bits=sb, flags=flags) as e:
+                e.submit_reads(reads)
+                res.append(e.finish(counters=True))
+        assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][0], res[1][0])
+        oc, of1 = orc.sketch_reads(reads, klist, 0, 19, sb)
+        assert np.array_equal(res[0][2], of1) and np.array_equal(res[0][0], oc)
+
+
 def test_host_submit_ragged_and_chunked(nt):
     """ntc_submit: raw host buffers, reads of any length (empty, shorter than k, long sequences that
     the shim splits into overlapping chunks), dirty bytes everywhere"""
