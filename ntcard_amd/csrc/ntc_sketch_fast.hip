@@ -99,7 +99,7 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 
 } // namespace
 
-__global__ __launch_bounds__(kBlockThreads) void sketch_fast_kernel(const HashArgs a)
+__global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const HashArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[]; // per-wave slot data
 	__shared__ __align__(16) uint32_t tabw[kSlots * 8];     // static: offsets fold into ds_read immediates
@@ -142,31 +142,66 @@ __global__ __launch_bounds__(kBlockThreads) void sketch_fast_kernel(const HashAr
 	const uint32_t gA = (k - 1) >> 2;   // group that contains step k-1
 	const uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
 
-	for (uint64_t wb = gwave; wb < n_wb; wb += (uint64_t)gridDim.x * kWavesPerBlock) {
+	// ---- global -> LDS staging.  A full wave batch (64 slots) is 64*stride contiguous bytes =
+	// `nchunk` coalesced 16-byte loads per lane.  Up to kPref of them are kept in flight in
+	// registers: the loads of batch i+1 are issued before batch i is hashed, so HBM latency is
+	// paid under the hash loop instead of in front of it.
+	constexpr int kPref = 10; // 10 KiB per wave: slots of up to 160 bytes
+	const uint32_t full_bytes = 64u * stride;
+	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
+	const bool can_prefetch = nchunk <= (uint32_t)kPref;
+	const uint64_t wb_step = (uint64_t)gridDim.x * kWavesPerBlock;
+	uint4 pref[kPref];
+	auto load_round = [&](uint64_t wb_, uint32_t c0) {
+		const unsigned char* src = a.slots + wb_ * full_bytes;
+#pragma unroll
+		for (int c = 0; c < kPref; ++c) {
+			const uint32_t off = lane * 16u + (c0 + c) * 1024u;
+			if (off + 16u <= full_bytes) pref[c] = *reinterpret_cast<const uint4*>(src + off);
+		}
+	};
+	auto store_round = [&](uint32_t c0, uint32_t& badacc) {
+#pragma unroll
+		for (int c = 0; c < kPref; ++c) {
+			const uint32_t off = lane * 16u + (c0 + c) * 1024u;
+			if (off + 16u <= full_bytes) {
+				uint4 v = pref[c];
+				v.x = decode4(v.x, badacc);
+				v.y = decode4(v.y, badacc);
+				v.z = decode4(v.z, badacc);
+				v.w = decode4(v.w, badacc);
+				*reinterpret_cast<uint4*>(wdata + off) = v;
+			}
+		}
+	};
+	auto is_full = [&](uint64_t wb_) { return wb_ * 64 + 64 <= a.n_slots; };
+	if (can_prefetch && gwave < n_wb && is_full(gwave)) load_round(gwave, 0);
+
+	for (uint64_t wb = gwave; wb < n_wb; wb += wb_step) {
 		const uint64_t slot0 = wb * 64;
 		const uint32_t nvalid = (uint32_t)((a.n_slots - slot0) < 64 ? (a.n_slots - slot0) : 64);
 		// ---- stage + decode: coalesced 16 B global loads -> code bytes in LDS ----
 		uint32_t badacc = 0;
-		{
+		__builtin_amdgcn_wave_barrier();
+		if (nvalid == 64 && can_prefetch) {
+			store_round(0, badacc);
+			if (wb + wb_step < n_wb && is_full(wb + wb_step)) load_round(wb + wb_step, 0);
+		} else if (nvalid == 64) {
+			for (uint32_t c0 = 0; c0 < nchunk; c0 += kPref) {
+				load_round(wb, c0);
+				store_round(c0, badacc);
+			}
+		} else {
+			// last, partial batch of the launch
 			const unsigned char* src = a.slots + slot0 * stride;
 			const uint32_t bytes = nvalid * stride; // multiple of 4
-			__builtin_amdgcn_wave_barrier();
 			for (uint32_t off = lane * 16u; off < bytes; off += 1024u) {
-				if (off + 16u <= bytes) {
-					uint4 v = *reinterpret_cast<const uint4*>(src + off);
-					v.x = decode4(v.x, badacc);
-					v.y = decode4(v.y, badacc);
-					v.z = decode4(v.z, badacc);
-					v.w = decode4(v.w, badacc);
-					*reinterpret_cast<uint4*>(wdata + off) = v;
-				} else {
-					for (uint32_t o = off; o < bytes; o += 4)
-						*reinterpret_cast<uint32_t*>(wdata + o) =
-						    decode4(*reinterpret_cast<const uint32_t*>(src + o), badacc);
-				}
+				for (uint32_t o = off; o < bytes && o < off + 16u; o += 4)
+					*reinterpret_cast<uint32_t*>(wdata + o) =
+					    decode4(*reinterpret_cast<const uint32_t*>(src + o), badacc);
 			}
-			__builtin_amdgcn_wave_barrier();
 		}
+		__builtin_amdgcn_wave_barrier();
 		const bool wave_dirty = __any(badacc != 0u);
 
 		// ---- per-lane read geometry ----
@@ -312,9 +347,8 @@ __global__ __launch_bounds__(kBlockThreads) void sketch_fast_kernel(const HashAr
 		// ---- drain: resolve my queued hits (canonical strand, sample plane, bucket) ----
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		const uint32_t nrec = qoff >> 10;
-		for (uint32_t j = 0; __any(j < nrec); ++j) {
-			if (j < nrec) {
-				const v4u rec = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane * 16u + j * 1024u, 0, 1 /*glc: bypass L1*/);
+		auto resolve = [&](const v4u rec) {
+			{
 				const uint32_t flo = rec.x, rlo = rec.y, fHd = rec.z, rHd = rec.w;
 				bool rev = rHd < fHd;
 				if (rHd == fHd && rlo != flo) {
@@ -339,6 +373,17 @@ __global__ __launch_bounds__(kBlockThreads) void sketch_fast_kernel(const HashAr
 				const uint32_t idx = (lo & rmask) + ((int32_t)m >= lo1 ? rbuck : 0u);
 				atomicAdd(a.sketch + idx, 1u);
 			}
+		};
+		// four queue rows per round: the loads go out together, so their L2 latency is paid once
+		for (uint32_t j0 = 0; __any(j0 < nrec); j0 += 4) {
+			v4u rec[4];
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u)
+				if (j0 + u < nrec)
+					rec[u] = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, lane * 16u + (j0 + u) * 1024u, 0, 1 /*glc: bypass L1*/);
+#pragma unroll
+			for (uint32_t u = 0; u < 4; ++u)
+				if (j0 + u < nrec) resolve(rec[u]);
 		}
 	}
 	if (lane == 0 && f1_wave) atomicAdd(a.f1, (unsigned long long)f1_wave);
