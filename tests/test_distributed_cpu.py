@@ -1,0 +1,63 @@
+"""world_size-2 gloo test of the multi-GPU merge path (CPU tensors): per-rank private sketches,
+read-index sharding, one SUM reduce, uint16 wrap afterwards == the single-process sketch."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import orc
+from ntcard_amd import parallel
+
+K, RB, SB, N, L = 25, 14, 3, 3000, 100
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, n = parallel.split_reads(N, world)[rank]
+    slots = orc.gen_reads(3, first, n, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(n)]
+    # every rank pre-loads one counter so that the merged value wraps past 65535 (uint16 semantics)
+    counters, f1 = orc.sketch_reads(reads, [K], 0, RB, SB)
+    sk = torch.from_numpy(counters.astype(np.int64).reshape(-1)).to(torch.int32)
+    sk[7] += 40000
+    f1t = torch.from_numpy(f1.astype(np.int64))
+    parallel.reduce_sketch(sk, f1t, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sk.npy"), parallel.to_uint16_counters(sk).numpy())
+        np.save(os.path.join(out_dir, "f1.npy"), f1t.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sk = np.load(tmp_path / "sk.npy")
+    f1 = np.load(tmp_path / "f1.npy")
+    slots = orc.gen_reads(3, 0, N, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(N)]
+    oc, of1 = orc.sketch_reads(reads, [K], 0, RB, SB)
+    expect = oc.astype(np.int64).reshape(-1)
+    expect[7] = (expect[7] + 80000) & 0xFFFF
+    assert int(f1[0]) == int(of1[0])
+    assert np.array_equal(sk.astype(np.int64), expect)
+
+
+def test_split_reads_covers_everything():
+    for n, w in ((10, 3), (100_000_000, 8), (7, 8)):
+        parts = parallel.split_reads(n, w)
+        assert sum(c for _, c in parts) == n
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+    assert parallel.read_range(3, 8, 1000) == (3000, 1000)
