@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libntcard_hip.so")
+LIB_PATH = os.environ.get("NTCARD_HIP_LIB") or os.path.join(HERE, "lib", "libntcard_hip.so")  # env override: A/B builds
 
 # every symbol include/ntcard_hip.h declares
 ABI_SYMBOLS = [

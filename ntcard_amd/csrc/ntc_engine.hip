@@ -58,7 +58,7 @@ int device_info(int dev, DevInfo& di)
 // dynamic LDS per block: the simple kernel keeps its tables in the dynamic region, the fast one statically
 size_t smem_for(uint32_t stride, bool fast)
 {
-	return (fast ? 0 : (size_t)ntc::kTableBytes) + (size_t)ntc::kWavesPerBlock * 64u * stride;
+	return (fast ? 16 : (size_t)ntc::kTableBytes) + (size_t)ntc::kWavesPerBlock * 64u * stride;
 }
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
@@ -166,6 +166,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		a.sketch = e->d_sketch + ki * e->plane_elems();
 		a.f1 = e->d_f1 + ki;
 		ntc::build_tables(a.k, a.tab);
+		ntc::poly_a_state(a.k, a.init);
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
 		if (e->profiling) {
 			HIP_TRY(hipEventCreate(&ev0));

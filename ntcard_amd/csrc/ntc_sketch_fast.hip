@@ -19,7 +19,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ntc_kernels.hpp"
+
+#ifndef NTC_PIPE
+#define NTC_PIPE 0 // 1: table entries of group g+1 are fetched while group g is hashed
+#endif
+#ifndef NTC_PREF
+#define NTC_PREF 1 // 1: global loads of batch i+1 stay in flight (registers) while batch i is hashed
+#endif
 
 namespace ntc {
 
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 
 	const uint32_t stride = a.stride;
 	const uint32_t k = a.k;
-	unsigned char* const wdata = smem + (size_t)wave * 64u * stride;
+	unsigned char* const wdata = smem + 16 + (size_t)wave * 64u * stride; // 16 B pad: out-base loads reach 4 B below a slot
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
 
 	// sample windows on the top bits (ntcard.cpp:135-138).  Kept in VGPRs on purpose: a VALU op with an
@@ -146,10 +155,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 	// `nchunk` coalesced 16-byte loads per lane.  Up to kPref of them are kept in flight in
 	// registers: the loads of batch i+1 are issued before batch i is hashed, so HBM latency is
 	// paid under the hash loop instead of in front of it.
-	constexpr int kPref = 10; // 10 KiB per wave: slots of up to 160 bytes
+	constexpr int kPref = NTC_PREF ? 10 : 4; // 10 KiB per wave: slots of up to 160 bytes
 	const uint32_t full_bytes = 64u * stride;
 	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
-	const bool can_prefetch = nchunk <= (uint32_t)kPref;
+	const bool can_prefetch = NTC_PREF && nchunk <= (uint32_t)kPref;
 	const uint64_t wb_step = (uint64_t)gridDim.x * kWavesPerBlock;
 	uint4 pref[kPref];
 	auto load_round = [&](uint64_t wb_, uint32_t c0) {
@@ -225,7 +234,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 		// a "uniform" wave: every lane walks the same number of steps and no lane saw a dirty byte
 		const bool uniform = (minq == maxq) && !wave_dirty;
 
-		Strands s = { 0, 0, 0, 0, 0, 0 };
+		// The walk starts from the hash of a virtual window of k 'A's and feeds 'A' (code 0) as the
+		// outgoing base of the first k steps: the rolling identity then removes the virtual bases
+		// again, so ONE step body serves window filling and steady state (no special table slots).
+		Strands s = { a.init[0], a.init[1], a.init[2], a.init[3], a.init[4], a.init[5] };
 		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff; // emission allowed from this step on
 		uint32_t qoff = lane * 16u;                              // byte offset of my next queue record
 
@@ -242,105 +254,143 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 			__builtin_amdgcn_raw_buffer_store_b128(rec, qrsrc, qoff, 0, 0);
 			qoff += 1024u;
 		};
-
-		// generic single step: any mix of window filling, dirty bytes, read ends
-		auto generic_step = [&](int32_t q) {
-			const uint32_t ain = mine[q];
-			if (ain & 1u) nextok = nextok == 0x7fffffff ? nextok : q + (int32_t)k;
-			if (q >= endq) nextok = 0x7fffffff;
-			uint32_t off;
-			if (q >= (int32_t)k)
-				off = (ain & 0xc0u) | ((mine[q - (int32_t)k] >> 2) & 0x30u);
-			else
-				off = kMainSlots * 16 + ((ain >> 2) & 0x30u);
-			uint4 t;
-			uint32_t tbb;
-			lookup(off, t, tbb);
-			roll(s, t, tbb);
-			const bool live = nextok <= q;
-			f1_wave += __popcll(__ballot(live));
-			if (live && sampled()) enqueue();
+		// table offsets (one byte per base) of the 4 steps of group q0
+		auto group_idx = [&](int32_t q0, uint32_t& ain) -> uint32_t {
+			ain = *reinterpret_cast<const uint32_t*>(mine + q0);
+			uint32_t aout = 0;
+			if (q0 + 3 >= (int32_t)k) { // at least one step of the group has a real outgoing base
+				const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + ((q0 - (int32_t)k) & ~3));
+				aout = shb ? alignbyte(p[1], p[0], shb) : p[0];
+				if (q0 < (int32_t)k) aout &= 0xffffffffu << (8 * ((int32_t)k - q0)); // steps q < k: virtual 'A'
+			}
+			return (ain & 0xc0c0c0c0u) | ((aout >> 2) & 0x30303030u);
 		};
-
-		const uint32_t n_groups = (uint32_t)(maxq + 3) >> 2;
-		const uint32_t full_groups = (uint32_t)minq >> 2; // groups every lane walks completely
-
-		// 4 window-filling steps (q < k-1: no emission, "no outgoing base" table slots)
-		auto fill_group = [&](uint32_t ain) {
-			const uint32_t pin = (ain >> 2) & 0x30303030u;
+		struct Tab4 {
 			uint4 t[4];
 			uint32_t tb[4];
+		};
+		auto issue = [&](uint32_t idx4, Tab4& T) {
 #pragma unroll
 			for (int b = 0; b < 4; ++b)
-				lookup(kMainSlots * 16 + ((pin >> (8 * b)) & 0xffu), t[b], tb[b]);
-#pragma unroll
-			for (int b = 0; b < 4; ++b)
-				roll(s, t[b], tb[b]);
-		};
-		auto generic_group = [&](uint32_t g) {
-#pragma unroll 1
-			for (int b = 0; b < 4; ++b) {
-				const int32_t q = (int32_t)(g << 2) + b;
-				if (q >= maxq) break;
-				generic_step(q);
-			}
-		};
-		auto out_word = [&](int32_t q0) -> uint32_t {
-			const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + ((q0 - (int32_t)k) & ~3));
-			return shb ? alignbyte(p[1], p[0], shb) : p[0];
+				lookup((idx4 >> (8 * b)) & 0xffu, T.t[b], T.tb[b]);
 		};
 
+		// group kinds by position: FILL (all 4 steps before k-1: no window yet), MIXED (the group that
+		// contains step k-1, or a partial last group), MAIN (every step emits)
+		constexpr int FILL = 0, MIXED = 1, MAIN = 2;
+		const int32_t full_groups = maxq >> 2;                       // groups with 4 steps for the longest lane
+		const int32_t first_main = ((int32_t)k - 1 + 3) >> 2;        // first group with q0 >= k-1
+		const int32_t fill_end = ((int32_t)k - 1) >> 2;              // groups [0, fill_end) are pure FILL
+		auto kind_of = [&](int32_t g) { return g < fill_end ? FILL : (g >= first_main ? MAIN : MIXED); };
+
 		if (uniform) {
-			// every lane walks the same steps, no dirty byte anywhere: no per-lane bookkeeping at all
+			// ---- clean wave: every lane walks the same steps, no per-lane bookkeeping at all ----
 			const uint32_t nact = __popcll(__ballot(true));
-			uint32_t g = 0;
-			for (; g < gA && g < full_groups; ++g)
-				fill_group(*reinterpret_cast<const uint32_t*>(mine + (g << 2)));
-			for (; g <= gA && g < n_groups; ++g)
-				generic_group(g);
-			for (; g < full_groups; ++g) {
-				const int32_t q0 = (int32_t)(g << 2);
-				const uint32_t ain = *reinterpret_cast<const uint32_t*>(mine + q0);
-				const uint32_t idx4 = (ain & 0xc0c0c0c0u) | ((out_word(q0) >> 2) & 0x30303030u);
-				uint4 t[4];
-				uint32_t tb[4];
-#pragma unroll
-				for (int b = 0; b < 4; ++b)
-					lookup((idx4 >> (8 * b)) & 0xffu, t[b], tb[b]);
+			auto compute = [&](auto kind, int32_t q0, const Tab4& T) {
 #pragma unroll
 				for (int b = 0; b < 4; ++b) {
-					roll(s, t[b], tb[b]);
-					if (sampled()) enqueue();
-				}
-				f1_wave += 4u * nact;
-			}
-			for (; g < n_groups; ++g)
-				generic_group(g);
-		} else {
-			for (uint32_t g = 0; g < n_groups; ++g) {
-				const int32_t q0 = (int32_t)(g << 2);
-				const uint32_t ain = *reinterpret_cast<const uint32_t*>(mine + q0);
-				// lanes that are shut off (outside the batch / finished) never force the per-base path
-				const bool special = __any((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff));
-				if (special || g == gA) {
-					generic_group(g);
-				} else if (g < gA) {
-					fill_group(ain);
-				} else {
-					const uint32_t idx4 = (ain & 0xc0c0c0c0u) | ((out_word(q0) >> 2) & 0x30303030u);
-					uint4 t[4];
-					uint32_t tb[4];
-#pragma unroll
-					for (int b = 0; b < 4; ++b)
-						lookup((idx4 >> (8 * b)) & 0xffu, t[b], tb[b]);
-#pragma unroll
-					for (int b = 0; b < 4; ++b) {
-						roll(s, t[b], tb[b]);
-						const bool live = nextok <= q0 + b;
-						f1_wave += __popcll(__ballot(live));
-						if (live && sampled()) enqueue();
+					roll(s, T.t[b], T.tb[b]);
+					if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) {
+						if (sampled()) enqueue();
 					}
 				}
+			};
+			auto run = [&](auto kind, int32_t g0, int32_t g1) {
+				uint32_t ain;
+#if NTC_PIPE
+				Tab4 A, B;
+				if (g0 < g1) issue(group_idx(g0 << 2, ain), A);
+				for (int32_t g = g0; g < g1; g += 2) {
+					if (g + 1 < g1) issue(group_idx((g + 1) << 2, ain), B);
+					compute(kind, g << 2, A);
+					if (g + 1 < g1) {
+						if (g + 2 < g1) issue(group_idx((g + 2) << 2, ain), A);
+						compute(kind, (g + 1) << 2, B);
+					}
+				}
+#else
+				for (int32_t g = g0; g < g1; ++g) {
+					Tab4 A;
+					issue(group_idx(g << 2, ain), A);
+					compute(kind, g << 2, A);
+				}
+#endif
+			};
+			const int32_t e0 = fill_end < full_groups ? fill_end : full_groups;
+			const int32_t e1 = first_main < full_groups ? first_main : full_groups;
+			run(std::integral_constant<int, FILL>{}, 0, e0);
+			run(std::integral_constant<int, MIXED>{}, e0, e1 > e0 ? e1 : e0);
+			run(std::integral_constant<int, MAIN>{}, e1 > e0 ? e1 : e0, full_groups);
+			// partial last group: one step at a time
+			for (int32_t q = full_groups << 2; q < maxq; ++q) {
+				const uint32_t ain = mine[q];
+				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
+				uint4 t;
+				uint32_t tbb;
+				lookup(off, t, tbb);
+				roll(s, t, tbb);
+				if (q >= (int32_t)k - 1 && sampled()) enqueue();
+			}
+			if (maxq >= (int32_t)k) f1_wave += (uint64_t)nact * (uint32_t)(maxq - (int32_t)k + 1);
+		} else {
+			// ---- dirty / ragged wave: per-lane `nextok` (first step whose window is clean again) ----
+			auto step_tail = [&](int32_t q, uint32_t mark) {
+				if (mark && nextok != 0x7fffffff) nextok = q + (int32_t)k;
+				if (q >= endq) nextok = 0x7fffffff;
+			};
+			auto emit = [&](int32_t q) {
+				const bool live = nextok <= q;
+				f1_wave += __popcll(__ballot(live));
+				if (live && sampled()) enqueue();
+			};
+			auto compute = [&](auto kind, int32_t q0, uint32_t ain, const Tab4& T) {
+				// lanes that are shut off (outside the batch / finished) never trigger the extra work
+				const bool alive = nextok != 0x7fffffff;
+				const bool fix = __any((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & alive);
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const int32_t q = q0 + b;
+					if (fix) step_tail(q, (ain >> (8 * b)) & 1u);
+					roll(s, T.t[b], T.tb[b]);
+					if (kind.value == MAIN || (kind.value == MIXED && q >= (int32_t)k - 1)) emit(q);
+				}
+			};
+			auto run = [&](auto kind, int32_t g0, int32_t g1) {
+#if NTC_PIPE
+				Tab4 A, B;
+				uint32_t ainA = 0, ainB = 0;
+				if (g0 < g1) issue(group_idx(g0 << 2, ainA), A);
+				for (int32_t g = g0; g < g1; g += 2) {
+					if (g + 1 < g1) issue(group_idx((g + 1) << 2, ainB), B);
+					compute(kind, g << 2, ainA, A);
+					if (g + 1 < g1) {
+						if (g + 2 < g1) issue(group_idx((g + 2) << 2, ainA), A);
+						compute(kind, (g + 1) << 2, ainB, B);
+					}
+				}
+#else
+				for (int32_t g = g0; g < g1; ++g) {
+					Tab4 A;
+					uint32_t ainA;
+					issue(group_idx(g << 2, ainA), A);
+					compute(kind, g << 2, ainA, A);
+				}
+#endif
+			};
+			const int32_t e0 = fill_end < full_groups ? fill_end : full_groups;
+			const int32_t e1 = first_main < full_groups ? first_main : full_groups;
+			run(std::integral_constant<int, FILL>{}, 0, e0);
+			run(std::integral_constant<int, MIXED>{}, e0, e1 > e0 ? e1 : e0);
+			run(std::integral_constant<int, MAIN>{}, e1 > e0 ? e1 : e0, full_groups);
+			for (int32_t q = full_groups << 2; q < maxq; ++q) {
+				const uint32_t ain = mine[q];
+				step_tail(q, ain & 1u);
+				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
+				uint4 t;
+				uint32_t tbb;
+				lookup(off, t, tbb);
+				roll(s, t, tbb);
+				if (q >= (int32_t)k - 1) emit(q);
 			}
 		}
 
@@ -353,11 +403,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 				bool rev = rHd < fHd;
 				if (rHd == fHd && rlo != flo) {
 					// top 31 bits tie (p = 2^-31): bit 32 decides first; re-walk the read to recover it
-					Strands w = { 0, 0, 0, 0, 0, 0 };
+					Strands w = { a.init[0], a.init[1], a.init[2], a.init[3], a.init[4], a.init[5] };
 					for (int32_t q = 0; q < endq; ++q) {
 						const uint32_t ain = mine[q];
-						const uint32_t off = q >= (int32_t)k ? ((ain & 0xc0u) | ((mine[q - (int32_t)k] >> 2) & 0x30u))
-						                                     : (kMainSlots * 16 + ((ain >> 2) & 0x30u));
+						const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
 						uint4 t;
 						uint32_t tbb;
 						lookup(off, t, tbb);

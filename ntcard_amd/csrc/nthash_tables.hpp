@@ -73,4 +73,21 @@ inline void build_tables(unsigned k, HashTables& t)
 	}
 }
 
+// Strand registers (device layout) of the hash of k consecutive 'A' bases — the state the tuned
+// kernel starts every read from (see ntc_sketch_fast.hip): {flo, fB, fHd, rlo, rB, rHd}.
+inline void poly_a_state(unsigned k, uint32_t out[6])
+{
+	uint64_t fh = 0, rh = 0;
+	for (unsigned i = 0; i < k; ++i) {
+		fh ^= srol(seed_of(0), i);
+		rh ^= srol(comp_of(0), i);
+	}
+	out[0] = lo_of(fh);
+	out[1] = b32_of(fh) << 31;
+	out[2] = hd_of(fh);
+	out[3] = lo_of(rh);
+	out[4] = b32_of(rh);
+	out[5] = hd_of(rh);
+}
+
 } // namespace ntc
