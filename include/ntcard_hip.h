@@ -59,6 +59,7 @@ typedef struct {
 
 #define NTC_FLAG_NONE 0u
 #define NTC_FLAG_SIMPLE_KERNEL 1u /* run the simple validation kernel instead of the tuned one */
+#define NTC_FLAG_FAST_KERNEL 2u   /* run the first tuned kernel (full hash in the loop) instead of the H-filter one */
 
 uint32_t ntc_abi_version(void);
 uint32_t ntc_max_k(void);

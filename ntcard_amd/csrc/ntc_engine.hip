@@ -56,20 +56,28 @@ int device_info(int dev, DevInfo& di)
 }
 
 // dynamic LDS per block: the simple kernel keeps its tables in the dynamic region, the fast one statically
-size_t smem_for(uint32_t stride, bool fast)
+// kernel kinds: the simple validation kernel, the first tuned kernel, the H-filter kernel (default)
+enum { KIND_SIMPLE = 0, KIND_FAST = 1, KIND_HF = 2 };
+
+size_t smem_for(uint32_t stride, int kind, uint32_t k)
 {
-	return (fast ? 16 : (size_t)ntc::kTableBytes) + (size_t)ntc::kWavesPerBlock * 64u * stride;
+	const size_t data = (size_t)ntc::kWavesPerBlock * 64u * stride;
+	if (kind == KIND_SIMPLE) return (size_t)ntc::kTableBytes + data;
+	if (kind == KIND_FAST) return 16 + data;
+	return 16 + data + (size_t)k * 64u + (size_t)ntc::kWavesPerBlock * 128u * 4u;
 }
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
-int hash_grid(int dev, uint64_t n_slots, uint32_t stride, bool fast, unsigned& grid, size_t& smem)
+int hash_grid(int dev, uint64_t n_slots, uint32_t stride, int kind, uint32_t k, unsigned& grid, size_t& smem)
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
-	smem = smem_for(stride, fast);
-	const size_t total = smem + (fast ? (size_t)ntc::kTableBytes : 0);
+	smem = smem_for(stride, kind, k);
+	const size_t total = smem + (kind == KIND_FAST ? (size_t)ntc::kTableBytes : (kind == KIND_HF ? 256 : 0));
 	if (total > 160 * 1024) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, total);
-	if (fast)
+	if (kind == KIND_HF)
+		HIP_TRY(ntc::set_sketch_hf_smem_limit(smem));
+	else if (kind == KIND_FAST)
 		HIP_TRY(ntc::set_sketch_fast_smem_limit(smem));
 	else
 		HIP_TRY(ntc::set_hash_smem_limit(smem));
@@ -94,7 +102,8 @@ struct ntc_engine {
 	uint16_t* d_out16 = nullptr; // [2][1<<r_bits] scratch for finish
 	void* d_queue = nullptr;     // fast kernel: per-wave hit queues
 	size_t queue_cap = 0;
-	bool simple_kernel = false;  // NTC_FLAG_SIMPLE_KERNEL
+	int kernel_kind = 2;         // KIND_HF unless NTC_FLAG_SIMPLE_KERNEL / NTC_FLAG_FAST_KERNEL
+	std::vector<void*> d_t1;     // per k: closed-form table of the H-filter kernel's resolve stage
 	// host-submit staging (grow-only)
 	unsigned char* h_stage = nullptr;
 	uint32_t* h_meta = nullptr;
@@ -136,12 +145,13 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	if (n_slots == 0) return 0;
 	unsigned grid = 0;
 	size_t smem = 0;
-	const bool fast = !e->simple_kernel;
-	if (int rc = hash_grid(e->device, n_slots, stride, fast, grid, smem)) return rc;
+	const int kind = e->kernel_kind;
+	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
+	if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem)) return rc;
 	// every lane can queue at most one hit per window of its slot: `stride` rows always suffice
 	const uint32_t queue_rows = stride;
-	if (fast) {
-		const size_t need = (size_t)grid * ntc::kWavesPerBlock * queue_rows * 1024u;
+	if (kind != KIND_SIMPLE) {
+		const size_t need = (size_t)grid * ntc::kWavesPerBlock * queue_rows * (kind == KIND_FAST ? 1024u : 256u);
 		if (need > e->queue_cap) {
 			HIP_TRY(hipStreamSynchronize(e->stream));
 			if (e->d_queue) (void)hipFree(e->d_queue);
@@ -175,10 +185,14 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		}
 		a.queue = e->d_queue;
 		a.queue_rows = queue_rows;
-		if (fast)
-			HIP_TRY(ntc::launch_sketch_fast(a, grid, smem, e->stream));
+		a.t1 = e->d_t1[ki];
+		const size_t smem_k = smem_for(stride, kind, a.k);
+		if (kind == KIND_HF)
+			HIP_TRY(ntc::launch_sketch_hf(a, grid, smem_k, e->stream));
+		else if (kind == KIND_FAST)
+			HIP_TRY(ntc::launch_sketch_fast(a, grid, smem_k, e->stream));
 		else
-			HIP_TRY(ntc::launch_hash(0, a, grid, smem, e->stream));
+			HIP_TRY(ntc::launch_hash(0, a, grid, smem_k, e->stream));
 		if (e->profiling) {
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
@@ -225,7 +239,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	e->gap = cfg->gap;
 	e->r_bits = cfg->r_bits;
 	e->s_bits = cfg->s_bits;
-	e->simple_kernel = (cfg->flags & NTC_FLAG_SIMPLE_KERNEL) != 0;
+	e->kernel_kind = (cfg->flags & NTC_FLAG_SIMPLE_KERNEL) ? KIND_SIMPLE : ((cfg->flags & NTC_FLAG_FAST_KERNEL) ? KIND_FAST : KIND_HF);
 	const size_t sk_bytes = e->klist.size() * e->plane_elems() * sizeof(uint32_t);
 	if (cfg->ext_sketch) {
 		e->d_sketch = (uint32_t*)cfg->ext_sketch;
@@ -248,6 +262,16 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	if (hipMalloc((void**)&e->d_phist, e->klist.size() * 2 * 65536 * 4) != hipSuccess) {
 		ntc_destroy(e);
 		return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate histogram on device");
+	}
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		std::vector<uint32_t> t1((size_t)e->klist[ki] * 16);
+		ntc::build_t1(e->klist[ki], t1.data());
+		void* d = nullptr;
+		if (hipMalloc(&d, t1.size() * 4) != hipSuccess || hipMemcpy(d, t1.data(), t1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+			ntc_destroy(e);
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form seed table on device");
+		}
+		e->d_t1.push_back(d);
 	}
 	int rc = ntc_reset(e);
 	if (rc) {
@@ -272,6 +296,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_queue) (void)hipFree(e->d_queue);
+	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_stage) (void)hipFree(e->d_stage);
 	if (e->d_meta) (void)hipFree(e->d_meta);
 	if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -479,7 +504,7 @@ int ntc_hash_dump_device(int32_t device, void* stream, const void* d_slots, uint
 	HIP_TRY(hipSetDevice(device));
 	unsigned grid = 0;
 	size_t smem = 0;
-	if (int rc = hash_grid(device, n_reads, stride, false, grid, smem)) return rc;
+	if (int rc = hash_grid(device, n_reads, stride, KIND_SIMPLE, k, grid, smem)) return rc;
 	ntc::HashArgs a;
 	std::memset(&a, 0, sizeof a);
 	a.slots = (const unsigned char*)d_slots;

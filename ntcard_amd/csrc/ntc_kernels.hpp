@@ -26,6 +26,7 @@ struct HashArgs {
 	uint32_t* dump_count;       // MODE 1: [n_slots]
 	void* queue;                // fast kernel: per-wave hit queues, [grid*4][queue_rows][64] x 16 B
 	uint32_t queue_rows;        // rows (hits per lane) each wave queue can hold
+	const void* t1;             // H-filter kernel: [k][4] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seeds (device)
 	uint32_t init[6];           // fast kernel: strand registers of the k x 'A' window {flo,fB,fHd,rlo,rB,rHd}
 	HashTables tab;
 };
@@ -34,6 +35,8 @@ hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, 
 hipError_t set_hash_smem_limit(size_t smem);
 hipError_t launch_sketch_fast(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_sketch_fast_smem_limit(size_t smem);
+hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
+hipError_t set_sketch_hf_smem_limit(size_t smem);
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
                            uint16_t* out16, hipStream_t st);
 hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,

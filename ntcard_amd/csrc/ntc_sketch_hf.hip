@@ -1,0 +1,389 @@
+// ntc_sketch_hf.hip — K1 "H-filter": the production ntHash -> sample -> count kernel for gfx950.
+//
+// Profiling of the straightforward lane-per-read kernel (ntc_sketch_fast.hip, profiles/r01_*) showed
+// it to be bound by the number of wave instructions issued, not by HBM, LDS or latency.  This
+// variant therefore does the minimum per k-mer and moves everything that is only needed for the
+// ~2^(1-sBits) sampled k-mers out of the per-base loop:
+//
+//   * the sampling decision of ntComp (ntcard.cpp:135-138) only looks at the top sBits+1 bits of
+//     min(fh, rh); those bits live in the 31-bit rotating half H of the hash (nthash.hpp:186-217), and
+//     H rolls independently of the 33-bit half.  The per-base loop therefore rolls ONLY the two H
+//     halves (3 VALU ops each, one ds_read_b64 of seed terms) and tests min(fHd, rHd);
+//   * a lane that sees a sampled window just stores the step number in its queue row;
+//   * after the read, the wave compacts the (lane, step) pairs and 64 lanes at a time recompute the
+//     full 64-bit forward and reverse hashes of those windows from the closed form
+//     fh = XOR_i srol^(k-1-i)(seed(c_i)), rh = XOR_i srol^i(comp(c_i))      (nthash.hpp:220-239)
+//     with a k x 4 table of pre-rotated seeds in LDS, take the canonical min (nthash.hpp:275-279),
+//     and update the sketch.  Full 64-bit compare: exact, no tie special case.
+//
+// Semantics reproduced: ntRead (ntcard.cpp:147-158), ntHashIterator (ntHashIterator.hpp:59-86),
+// NTMC64 (nthash.hpp:381-390,467-492), ntComp (ntcard.cpp:132-145).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "ntc_kernels.hpp"
+
+namespace ntc {
+
+namespace {
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+	return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+__device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+	return __builtin_amdgcn_perm(s0, s1, sel);
+}
+
+// v_perm tables indexed by (byte & 7): 1:A 3:C 7:G 4:T 5:U, 0/2/6: not a base (nthash.hpp:16,32 trick)
+constexpr uint32_t kExpS0 = 0x47ff5554u; // 'G', ff, 'U', 'T'
+constexpr uint32_t kExpS1 = 0x43ff41ffu; // 'C', ff, 'A', ff
+constexpr uint32_t kIn6S0 = 0x8000c0c0u; // code<<6 : G=2, -, U=3, T=3
+constexpr uint32_t kIn6S1 = 0x40000000u; //           C=1, -, A=0, -
+
+// x << 1 as a full-rate v_add_u32 (hipcc canonicalises x + x back into the half-rate v_lshlrev_b32)
+__device__ __forceinline__ uint32_t dbl(uint32_t x)
+{
+	uint32_t r;
+	asm("v_add_u32_e32 %0, %1, %1" : "=v"(r) : "v"(x));
+	return r;
+}
+
+// decode one dword of raw bytes -> code<<6 per byte, bit 0 set on bytes that are not ACGTU/acgtu
+__device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
+{
+	const uint32_t sel = w & 0x07070707u;
+	const uint32_t bad = (perm(kExpS0, kExpS1, sel) ^ w) & 0xdfdfdfdfu;
+	uint32_t code = perm(kIn6S0, kIn6S1, sel);
+	badacc |= bad;
+	if (bad != 0u) {
+		const uint32_t nz = (((bad & 0x7f7f7f7fu) + 0x7f7f7f7fu) | bad) & 0x80808080u;
+		code = (code & ~(nz >> 1) & ~nz) | (nz >> 7); // dirty byte: code 0, mark bit 0
+	}
+	return code;
+}
+
+constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a dense resolve round
+
+} // namespace
+
+__global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashArgs a)
+{
+	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][k x 4 x 16 B closed-form table][waves x ring]
+	extern __shared__ __align__(16) unsigned char smem[];
+	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
+	__shared__ __align__(16) uint32_t tabH[kMainSlots * 4];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	const uint32_t stride = a.stride;
+	const uint32_t k = a.k;
+	unsigned char* const wdata = smem + 16 + (size_t)wave * 64u * stride;
+	const unsigned char* const mine = wdata + (size_t)lane * stride;
+	unsigned char* const t1 = smem + 16 + (size_t)kWavesPerBlock * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
+	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + (size_t)k * 64u) + wave * kRing;
+	{
+		for (int i = tid; i < kMainSlots * 4; i += kBlockThreads) {
+			const int slot = i >> 2, w = i & 3;
+			tabH[i] = w == 0 ? a.tab.A[slot][1] : (w == 1 ? a.tab.A[slot][3] : 0u);
+		}
+		const uint4* src = reinterpret_cast<const uint4*>(a.t1);
+		for (uint32_t i = tid; i < k * 4u; i += kBlockThreads)
+			reinterpret_cast<uint4*>(t1)[i] = src[i];
+	}
+	__syncthreads();
+	const unsigned char* const tabHb = reinterpret_cast<const unsigned char*>(tabH);
+
+	// sample windows on the top bits (ntcard.cpp:135-138); VGPR-resident on purpose (SGPR sources halve the VALU rate)
+	uint32_t lo0 = 1u << (31 - a.s_bits);
+	int32_t lo1 = (int32_t)(((1u << (a.s_bits - 1)) - 1u) << (32 - a.s_bits));
+	asm volatile("" : "+v"(lo0), "+v"(lo1));
+	const uint32_t s_bits = a.s_bits;
+	const uint32_t rmask = (1u << a.r_bits) - 1u;
+	const uint32_t rbuck = 1u << a.r_bits;
+
+	// per-wave hit queue in global memory (L2-resident): row j = the j-th sampled step of every lane
+	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave);
+	const uint64_t qbytes = (uint64_t)a.queue_rows * 256u;
+	__amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    reinterpret_cast<unsigned char*>(a.queue) + (uint64_t)gwave * qbytes, 0, (int)qbytes, 0x00020000);
+
+	const uint64_t n_wb = (a.n_slots + 63) / 64;
+	uint64_t f1_wave = 0;
+	const uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
+
+	// ---- global -> LDS staging with register prefetch of the next batch (see ntc_sketch_fast.hip) ----
+	constexpr int kPref = 10;
+	const uint32_t full_bytes = 64u * stride;
+	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
+	const bool can_prefetch = nchunk <= (uint32_t)kPref;
+	const uint64_t wb_step = (uint64_t)gridDim.x * kWavesPerBlock;
+	uint4 pref[kPref];
+	auto load_round = [&](uint64_t wb_, uint32_t c0) {
+		const unsigned char* src = a.slots + wb_ * full_bytes;
+#pragma unroll
+		for (int c = 0; c < kPref; ++c) {
+			const uint32_t off = lane * 16u + (c0 + c) * 1024u;
+			if (off + 16u <= full_bytes) pref[c] = *reinterpret_cast<const uint4*>(src + off);
+		}
+	};
+	auto store_round = [&](uint32_t c0, uint32_t& badacc) {
+#pragma unroll
+		for (int c = 0; c < kPref; ++c) {
+			const uint32_t off = lane * 16u + (c0 + c) * 1024u;
+			if (off + 16u <= full_bytes) {
+				uint4 v = pref[c];
+				v.x = decode4(v.x, badacc);
+				v.y = decode4(v.y, badacc);
+				v.z = decode4(v.z, badacc);
+				v.w = decode4(v.w, badacc);
+				*reinterpret_cast<uint4*>(wdata + off) = v;
+			}
+		}
+	};
+	auto is_full = [&](uint64_t wb_) { return wb_ * 64 + 64 <= a.n_slots; };
+	if (can_prefetch && gwave < n_wb && is_full(gwave)) load_round(gwave, 0);
+
+	for (uint64_t wb = gwave; wb < n_wb; wb += wb_step) {
+		const uint64_t slot0 = wb * 64;
+		const uint32_t nvalid = (uint32_t)((a.n_slots - slot0) < 64 ? (a.n_slots - slot0) : 64);
+		uint32_t badacc = 0;
+		__builtin_amdgcn_wave_barrier();
+		if (nvalid == 64 && can_prefetch) {
+			store_round(0, badacc);
+			if (wb + wb_step < n_wb && is_full(wb + wb_step)) load_round(wb + wb_step, 0);
+		} else if (nvalid == 64) {
+			for (uint32_t c0 = 0; c0 < nchunk; c0 += kPref) {
+				load_round(wb, c0);
+				store_round(c0, badacc);
+			}
+		} else {
+			const unsigned char* src = a.slots + slot0 * stride;
+			const uint32_t bytes = nvalid * stride;
+			for (uint32_t off = lane * 16u; off < bytes; off += 1024u)
+				for (uint32_t o = off; o < bytes && o < off + 16u; o += 4)
+					*reinterpret_cast<uint32_t*>(wdata + o) = decode4(*reinterpret_cast<const uint32_t*>(src + o), badacc);
+		}
+		__builtin_amdgcn_wave_barrier();
+		const bool wave_dirty = __any(badacc != 0u);
+
+		// ---- per-lane read geometry ----
+		uint32_t len = a.read_len, wlim = a.read_len;
+		const bool in_batch = (uint32_t)lane < nvalid;
+		if (a.meta != nullptr && in_batch) {
+			const uint32_t m = a.meta[slot0 + lane];
+			len = m & 0xffffu;
+			wlim = m >> 16;
+		}
+		int32_t endq = (int32_t)(len < wlim + k - 1 ? len : wlim + k - 1); // steps q in [0,endq)
+		if (!in_batch || len < k) endq = 0;
+		int32_t maxq = endq, minq = endq;
+		for (int o = 32; o > 0; o >>= 1) {
+			const int32_t omax = __shfl_xor(maxq, o), omin = __shfl_xor(minq, o);
+			maxq = omax > maxq ? omax : maxq;
+			minq = omin < minq ? omin : minq;
+		}
+		maxq = __builtin_amdgcn_readfirstlane(maxq);
+		minq = __builtin_amdgcn_readfirstlane(minq);
+		const bool uniform = (minq == maxq) && !wave_dirty;
+
+		// The walk starts from the H halves of the hash of k virtual 'A's and feeds 'A' as the outgoing
+		// base of the first k steps, so ONE step body serves window filling and steady state.
+		uint32_t fHd = a.init[2], rHd = a.init[5];
+		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff; // emission allowed from this step on
+		uint32_t qoff = lane * 4u;                               // byte offset of my next queue entry
+
+		auto roll = [&](const uint2 t) {
+			fHd = alignbit(fHd, dbl(fHd), 31) ^ t.x;          // rotl31 in the (H<<1)|H[30] layout, then ^ Tf
+			const uint32_t xh = rHd ^ t.y;                    // reverse strand: ^ Tr, then rotr31
+			rHd = alignbit(xh >> 1, xh, 1);
+		};
+		auto sampled = [&]() -> bool {
+			const uint32_t m = fHd < rHd ? fHd : rHd; // top bits of min(fh,rh)
+			return ((m ^ lo0) < lo0) | ((int32_t)m >= lo1);
+		};
+		auto enqueue = [&](uint32_t qv, int b) {
+			__builtin_amdgcn_raw_buffer_store_b32(qv + b, qrsrc, qoff, 0, 0);
+			qoff += 256u;
+		};
+		auto group_idx = [&](int32_t q0, uint32_t& ain) -> uint32_t {
+			ain = *reinterpret_cast<const uint32_t*>(mine + q0);
+			uint32_t aout = 0;
+			if (q0 + 3 >= (int32_t)k) { // at least one step of the group has a real outgoing base
+				const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + ((q0 - (int32_t)k) & ~3));
+				aout = shb ? alignbyte(p[1], p[0], shb) : p[0];
+				if (q0 < (int32_t)k) aout &= 0xffffffffu << (8 * ((int32_t)k - q0)); // steps q < k: virtual 'A'
+			}
+			// bits 7:6 of every byte from ain (incoming code), the rest from aout >> 2 (outgoing code in 5:4)
+			return (ain & 0xc0c0c0c0u) | ((aout >> 2) & 0x3f3f3f3fu);
+		};
+		struct Tab4 {
+			uint2 t[4];
+		};
+		auto issue = [&](uint32_t idx4, Tab4& T) {
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+				T.t[b] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> (8 * b)) & 0xf0u));
+		};
+
+		constexpr int FILL = 0, MIXED = 1, MAIN = 2;
+		const int32_t full_groups = maxq >> 2;
+		const int32_t first_main = ((int32_t)k - 1 + 3) >> 2; // first group with q0 >= k-1
+		const int32_t fill_end = ((int32_t)k - 1) >> 2;        // groups [0, fill_end) never emit
+		const int32_t e0 = fill_end < full_groups ? fill_end : full_groups;
+		const int32_t e1m = first_main < full_groups ? first_main : full_groups;
+		const int32_t e1 = e1m > e0 ? e1m : e0;
+
+		if (uniform) {
+			// ---- clean wave: every lane walks the same steps, no per-lane bookkeeping ----
+			const uint32_t nact = __popcll(__ballot(true));
+			auto run = [&](auto kind, int32_t g0, int32_t g1) {
+				for (int32_t g = g0; g < g1; ++g) {
+					const int32_t q0 = g << 2;
+					uint32_t ain;
+					Tab4 T;
+					issue(group_idx(q0, ain), T);
+					uint32_t qv = (uint32_t)q0;
+					asm volatile("" : "+v"(qv));
+#pragma unroll
+					for (int b = 0; b < 4; ++b) {
+						roll(T.t[b]);
+						if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) {
+							if (sampled()) enqueue(qv, b);
+						}
+					}
+				}
+			};
+			run(std::integral_constant<int, FILL>{}, 0, e0);
+			run(std::integral_constant<int, MIXED>{}, e0, e1);
+			run(std::integral_constant<int, MAIN>{}, e1, full_groups);
+			for (int32_t q = full_groups << 2; q < maxq; ++q) { // partial last group
+				const uint32_t ain = mine[q];
+				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
+				roll(*reinterpret_cast<const uint2*>(tabHb + off));
+				if (q >= (int32_t)k - 1 && sampled()) enqueue((uint32_t)q, 0);
+			}
+			if (maxq >= (int32_t)k) f1_wave += (uint64_t)nact * (uint32_t)(maxq - (int32_t)k + 1);
+		} else {
+			// ---- dirty / ragged wave: per-lane `nextok` (first step whose window is clean again) ----
+			auto step_fix = [&](int32_t q, uint32_t mark) {
+				if (mark && nextok != 0x7fffffff) nextok = q + (int32_t)k;
+				if (q >= endq) nextok = 0x7fffffff;
+			};
+			auto emit = [&](int32_t q, uint32_t qv, int b) {
+				const bool live = nextok <= q;
+				f1_wave += __popcll(__ballot(live));
+				if (live && sampled()) enqueue(qv, b);
+			};
+			auto run = [&](auto kind, int32_t g0, int32_t g1) {
+				for (int32_t g = g0; g < g1; ++g) {
+					const int32_t q0 = g << 2;
+					uint32_t ain;
+					Tab4 T;
+					issue(group_idx(q0, ain), T);
+					uint32_t qv = (uint32_t)q0;
+					asm volatile("" : "+v"(qv));
+					// lanes that are shut off (outside the batch / finished) never trigger the extra work
+					const bool fix = __any((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff));
+#pragma unroll
+					for (int b = 0; b < 4; ++b) {
+						if (fix) step_fix(q0 + b, (ain >> (8 * b)) & 1u);
+						roll(T.t[b]);
+						if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) emit(q0 + b, qv, b);
+					}
+				}
+			};
+			run(std::integral_constant<int, FILL>{}, 0, e0);
+			run(std::integral_constant<int, MIXED>{}, e0, e1);
+			run(std::integral_constant<int, MAIN>{}, e1, full_groups);
+			for (int32_t q = full_groups << 2; q < maxq; ++q) {
+				const uint32_t ain = mine[q];
+				step_fix(q, ain & 1u);
+				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
+				roll(*reinterpret_cast<const uint2*>(tabHb + off));
+				if (q >= (int32_t)k - 1) emit(q, (uint32_t)q, 0);
+			}
+		}
+
+		// ---- resolve: compact (lane, step) pairs, 64 at a time recompute the full hashes ----
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const uint32_t nrec = qoff >> 8;
+		auto resolve_round = [&](uint32_t first, uint32_t count) {
+			// entry -> window start in LDS (any lane's slot), then the closed form over k bases
+			const bool act = (uint32_t)lane < count;
+			const uint32_t e = act ? ring[(first + lane) & (kRing - 1)] : 0u;
+			const uint32_t src_lane = e >> 16, q = e & 0xffffu;
+			const uint32_t base = act ? src_lane * stride + q + 1u - k : 0u; // byte offset of the window in wdata
+			const uint32_t sh = base & 3u;
+			const uint32_t* dp = reinterpret_cast<const uint32_t*>(wdata + (base & ~3u));
+			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+			uint32_t cur = dp[0];
+			const unsigned char* tp = t1;
+			for (uint32_t i = 0; i < k; i += 4) {
+				const uint32_t nxt = dp[(i >> 2) + 1];
+				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes of window positions i..i+3
+				cur = nxt;
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					if (i + b < k) {
+						const uint32_t off = ((w >> (8 * b + 2)) & 0x30u); // code * 16
+						const uint4 t = *reinterpret_cast<const uint4*>(tp + (i + b) * 64u + off);
+						flo ^= t.x;
+						fhi ^= t.y;
+						rlo ^= t.z;
+						rhi ^= t.w;
+					}
+				}
+			}
+			if (act) {
+				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
+				const uint32_t hi = rev ? rhi : fhi;
+				const uint32_t lo = rev ? rlo : flo;
+				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+				const bool c0 = (hi >> (31 - s_bits)) == 1u;
+				if (c0 | c1) atomicAdd(a.sketch + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
+			}
+		};
+		uint32_t head = 0, tail = 0; // ring indices (wave-uniform)
+		for (uint32_t j = 0; __any(j < nrec); ++j) {
+			const bool has = j < nrec;
+			uint32_t qv = 0;
+			if (has) qv = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, lane * 4u + j * 256u, 0, 1 /*glc*/);
+			const uint64_t m = __ballot(has);
+			if (has) {
+				const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				ring[(tail + pos) & (kRing - 1)] = ((uint32_t)lane << 16) | (qv & 0xffffu);
+			}
+			tail += (uint32_t)__popcll(m);
+			__builtin_amdgcn_wave_barrier();
+			if (tail - head >= 64u) {
+				resolve_round(head, 64u);
+				head += 64u;
+			}
+		}
+		if (tail != head) resolve_round(head, tail - head);
+	}
+	if (lane == 0 && f1_wave) atomicAdd(a.f1, (unsigned long long)f1_wave);
+}
+
+hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st)
+{
+	hipLaunchKernelGGL(sketch_hf_kernel, dim3(grid), dim3(kBlockThreads), smem, st, a);
+	return hipGetLastError();
+}
+
+hipError_t set_sketch_hf_smem_limit(size_t smem)
+{
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_hf_kernel),
+	                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+} // namespace ntc

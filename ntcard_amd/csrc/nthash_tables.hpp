@@ -90,4 +90,19 @@ inline void poly_a_state(unsigned k, uint32_t out[6])
 	out[5] = hd_of(rh);
 }
 
+// Closed-form table of the resolve stage: entry (i, code) = { srol^(k-1-i)(seed(code)), srol^i(comp(code)) }
+// as {fwd.lo, fwd.hi, rev.lo, rev.hi} (nthash.hpp:220-239: fh = XOR_i srol^(k-1-i) seed(c_i), rh = XOR_i srol^i comp(c_i))
+inline void build_t1(unsigned k, uint32_t* out /* k*4*4 dwords */)
+{
+	for (unsigned i = 0; i < k; ++i)
+		for (unsigned c = 0; c < 4; ++c) {
+			const uint64_t f = srol(seed_of(c), k - 1 - i), r = srol(comp_of(c), i);
+			uint32_t* e = out + (i * 4 + c) * 4;
+			e[0] = (uint32_t)f;
+			e[1] = (uint32_t)(f >> 32);
+			e[2] = (uint32_t)r;
+			e[3] = (uint32_t)(r >> 32);
+		}
+}
+
 } // namespace ntc

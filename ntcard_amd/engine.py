@@ -14,6 +14,7 @@ from . import _abi
 from ._abi import NtcConfig, NtcError, check
 
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
+FLAG_FAST_KERNEL = 2  # NTC_FLAG_FAST_KERNEL: first tuned kernel (full hash in the loop)
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 
 

@@ -127,11 +127,12 @@ def test_simple_and_tuned_kernels_agree(nt):
     reads = [rseq(rng, rng.choice([40, 100, 149, 150, 150, 150, 151, 200]), pn=rng.choice([0, 0, 0.003, 0.05])) for _ in range(6000)]
     for klist, sb in (([32], 7), ([25, 61], 3)):
         res = []
-        for flags in (0, nt.FLAG_SIMPLE_KERNEL):
+        for flags in (0, nt.FLAG_SIMPLE_KERNEL, nt.FLAG_FAST_KERNEL):
             with nt.Engine(klist, r_bits=19, s_bits=sb, flags=flags) as e:
                 e.submit_reads(reads)
                 res.append(e.finish(counters=True))
-        assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][0], res[1][0])
+        for other in res[1:]:
+            assert np.array_equal(res[0][2], other[2]) and np.array_equal(res[0][0], other[0])
         oc, of1 = orc.sketch_reads(reads, klist, 0, 19, sb)
         assert np.array_equal(res[0][2], of1) and np.array_equal(res[0][0], oc)
 
