@@ -64,7 +64,8 @@ size_t smem_for(uint32_t stride, int kind, uint32_t k)
 	const size_t data = (size_t)ntc::kWavesPerBlock * 64u * stride;
 	if (kind == KIND_SIMPLE) return (size_t)ntc::kTableBytes + data;
 	if (kind == KIND_FAST) return 16 + data;
-	return 16 + data + (size_t)k * 64u + (size_t)ntc::kWavesPerBlock * 128u * 4u;
+	return 16 + data + (size_t)k * 64u + (size_t)ntc::kWavesPerBlock * 128u * 4u +
+	       (size_t)ntc::kWavesPerBlock * ((stride + 31u) / 32u) * 64u * 4u; // + closed-form table, rings, hit masks
 }
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
@@ -150,8 +151,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem)) return rc;
 	// every lane can queue at most one hit per window of its slot: `stride` rows always suffice
 	const uint32_t queue_rows = stride;
-	if (kind != KIND_SIMPLE) {
-		const size_t need = (size_t)grid * ntc::kWavesPerBlock * queue_rows * (kind == KIND_FAST ? 1024u : 256u);
+	if (kind == KIND_FAST) {
+		const size_t need = (size_t)grid * ntc::kWavesPerBlock * queue_rows * 1024u;
 		if (need > e->queue_cap) {
 			HIP_TRY(hipStreamSynchronize(e->stream));
 			if (e->d_queue) (void)hipFree(e->d_queue);

@@ -9,7 +9,8 @@
 //     min(fh, rh); those bits live in the 31-bit rotating half H of the hash (nthash.hpp:186-217), and
 //     H rolls independently of the 33-bit half.  The per-base loop therefore rolls ONLY the two H
 //     halves (3 VALU ops each, one ds_read_b64 of seed terms) and tests min(fHd, rHd);
-//   * a lane that sees a sampled window just stores the step number in its queue row;
+//   * a lane that sees a sampled window just sets bit (step & 31) of a mask register (flushed to LDS
+//     every 32 steps): one VALU op, no memory traffic;
 //   * after the read, the wave compacts the (lane, step) pairs and 64 lanes at a time recompute the
 //     full 64-bit forward and reverse hashes of those windows from the closed form
 //     fh = XOR_i srol^(k-1-i)(seed(c_i)), rh = XOR_i srol^i(comp(c_i))      (nthash.hpp:220-239)
@@ -70,6 +71,12 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 	return code;
 }
 
+#ifndef NTC_EXP_NO_ATOMIC
+#define NTC_EXP_NO_ATOMIC 0
+#endif
+#ifndef NTC_EXP_NO_QUEUE
+#define NTC_EXP_NO_QUEUE 0
+#endif
 constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a dense resolve round
 
 } // namespace
@@ -77,6 +84,7 @@ constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a 
 __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashArgs a)
 {
 	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][k x 4 x 16 B closed-form table][waves x ring]
+	//              [waves x ceil(stride/32) x 64 hit-mask words]
 	extern __shared__ __align__(16) unsigned char smem[];
 	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
 	__shared__ __align__(16) uint32_t tabH[kMainSlots * 4];
@@ -89,6 +97,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
 	unsigned char* const t1 = smem + 16 + (size_t)kWavesPerBlock * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
 	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + (size_t)k * 64u) + wave * kRing;
+	const uint32_t hm_words = (stride + 31u) >> 5; // 32-step blocks per slot
+	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + (size_t)k * 64u) + kWavesPerBlock * kRing + wave * hm_words * 64u + lane;
 	{
 		for (int i = tid; i < kMainSlots * 4; i += kBlockThreads) {
 			const int slot = i >> 2, w = i & 3;
@@ -109,12 +119,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	const uint32_t rmask = (1u << a.r_bits) - 1u;
 	const uint32_t rbuck = 1u << a.r_bits;
 
-	// per-wave hit queue in global memory (L2-resident): row j = the j-th sampled step of every lane
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave);
-	const uint64_t qbytes = (uint64_t)a.queue_rows * 256u;
-	__amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
-	    reinterpret_cast<unsigned char*>(a.queue) + (uint64_t)gwave * qbytes, 0, (int)qbytes, 0x00020000);
-
 	const uint64_t n_wb = (a.n_slots + 63) / 64;
 	uint64_t f1_wave = 0;
 	const uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 					*reinterpret_cast<uint32_t*>(wdata + o) = decode4(*reinterpret_cast<const uint32_t*>(src + o), badacc);
 		}
 		__builtin_amdgcn_wave_barrier();
-		const bool wave_dirty = __any(badacc != 0u);
+		const bool wave_dirty = __builtin_amdgcn_readfirstlane(__ballot(badacc != 0u) != 0 ? 1 : 0) != 0;
 
 		// ---- per-lane read geometry ----
 		uint32_t len = a.read_len, wlim = a.read_len;
@@ -192,13 +197,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 		}
 		maxq = __builtin_amdgcn_readfirstlane(maxq);
 		minq = __builtin_amdgcn_readfirstlane(minq);
-		const bool uniform = (minq == maxq) && !wave_dirty;
+		// wave classes: CLEAN (equal lengths, no dirty byte), DIRTY (equal lengths, some non-ACGTU byte),
+		// RAGGED (lanes end at different steps, e.g. the last partial batch or a ragged host batch)
+		constexpr int CLEAN = 0, DIRTY = 1, RAGGED = 2;
+		const int wclass = minq != maxq ? RAGGED : (wave_dirty ? DIRTY : CLEAN);
 
 		// The walk starts from the H halves of the hash of k virtual 'A's and feeds 'A' as the outgoing
 		// base of the first k steps, so ONE step body serves window filling and steady state.
 		uint32_t fHd = a.init[2], rHd = a.init[5];
 		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff; // emission allowed from this step on
-		uint32_t qoff = lane * 4u;                               // byte offset of my next queue entry
+		uint32_t hmask = 0;                                      // sampled steps of the current 32-step block
 
 		auto roll = [&](const uint2 t) {
 			fHd = alignbit(fHd, dbl(fHd), 31) ^ t.x;          // rotl31 in the (H<<1)|H[30] layout, then ^ Tf
@@ -209,56 +217,80 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			const uint32_t m = fHd < rHd ? fHd : rHd; // top bits of min(fh,rh)
 			return ((m ^ lo0) < lo0) | ((int32_t)m >= lo1);
 		};
-		auto enqueue = [&](uint32_t qv, int b) {
-			__builtin_amdgcn_raw_buffer_store_b32(qv + b, qrsrc, qoff, 0, 0);
-			qoff += 256u;
+		auto flush = [&](int32_t blk) { // end of a 32-step block: park the mask in LDS
+			hm[blk * 64] = hmask;
+			hmask = 0;
 		};
-		auto group_idx = [&](int32_t q0, uint32_t& ain) -> uint32_t {
+		// Table offsets (one byte per base: in<<6 | out<<4) of the 4 steps of group q0.
+		//   FILL : every step has q < k     -> outgoing base is the virtual 'A' (code 0)
+		//   MIXED: the group straddles k    -> mask the steps with q < k
+		//   MAIN : every step has q >= k
+		constexpr int FILL = 0, MIXED = 1, MAIN = 2;
+		auto group_idx = [&](auto kind, int32_t q0, uint32_t& ain) -> uint32_t {
 			ain = *reinterpret_cast<const uint32_t*>(mine + q0);
+			if (kind.value == FILL) return ain & 0xc0c0c0c0u;
 			uint32_t aout = 0;
-			if (q0 + 3 >= (int32_t)k) { // at least one step of the group has a real outgoing base
+			if (kind.value == MAIN || q0 + 3 >= (int32_t)k) {
 				const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + ((q0 - (int32_t)k) & ~3));
 				aout = shb ? alignbyte(p[1], p[0], shb) : p[0];
-				if (q0 < (int32_t)k) aout &= 0xffffffffu << (8 * ((int32_t)k - q0)); // steps q < k: virtual 'A'
+				if (kind.value == MIXED && q0 < (int32_t)k) aout &= 0xffffffffu << (8 * ((int32_t)k - q0));
 			}
-			// bits 7:6 of every byte from ain (incoming code), the rest from aout >> 2 (outgoing code in 5:4)
+			// bits 7:6 of every byte from ain (incoming code), bits 5:4 from aout >> 2 (outgoing code); v_bfi_b32
 			return (ain & 0xc0c0c0c0u) | ((aout >> 2) & 0x3f3f3f3fu);
 		};
 		struct Tab4 {
 			uint2 t[4];
 		};
 		auto issue = [&](uint32_t idx4, Tab4& T) {
-#pragma unroll
-			for (int b = 0; b < 4; ++b)
-				T.t[b] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> (8 * b)) & 0xf0u));
+			T.t[0] = *reinterpret_cast<const uint2*>(tabHb + (idx4 & 0xffu));
+			T.t[1] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> 8) & 0xffu));
+			T.t[2] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> 16) & 0xffu));
+			T.t[3] = *reinterpret_cast<const uint2*>(tabHb + (idx4 >> 24));
 		};
 
-		constexpr int FILL = 0, MIXED = 1, MAIN = 2;
+		// group ranges: [0,e0) never emit and never see a real outgoing base; [e0,e1) are the (at most
+		// two) groups around steps k-1 and k; [e1, full_groups) are steady state
 		const int32_t full_groups = maxq >> 2;
-		const int32_t first_main = ((int32_t)k - 1 + 3) >> 2; // first group with q0 >= k-1
-		const int32_t fill_end = ((int32_t)k - 1) >> 2;        // groups [0, fill_end) never emit
-		const int32_t e0 = fill_end < full_groups ? fill_end : full_groups;
-		const int32_t e1m = first_main < full_groups ? first_main : full_groups;
-		const int32_t e1 = e1m > e0 ? e1m : e0;
+		const int32_t gk = ((int32_t)k - 1) >> 2; // group of step k-1
+		const int32_t gm = ((int32_t)k + 3) >> 2; // first group with q0 >= k
+		const int32_t e0 = gk < full_groups ? gk : full_groups;
+		const int32_t e1 = gm < full_groups ? gm : full_groups;
 
-		if (uniform) {
-			// ---- clean wave: every lane walks the same steps, no per-lane bookkeeping ----
-			const uint32_t nact = __popcll(__ballot(true));
+		auto walk = [&](auto wc) {
+			// per-lane bookkeeping of the DIRTY / RAGGED classes
+			auto step_fix = [&](int32_t q, uint32_t mark) {
+				if (mark && (wc.value == DIRTY || nextok != 0x7fffffff)) nextok = q + (int32_t)k;
+				if (wc.value == RAGGED && q >= endq) nextok = 0x7fffffff;
+			};
+			auto emit = [&](int32_t q) {
+				const uint32_t bit = 1u << (q & 31);
+				if (wc.value == CLEAN) {
+					if (sampled()) hmask |= bit;
+				} else {
+					const bool live = nextok <= q;
+					f1_wave += __popcll(__ballot(live));
+					if (live && sampled()) hmask |= bit;
+				}
+			};
 			auto run = [&](auto kind, int32_t g0, int32_t g1) {
 				for (int32_t g = g0; g < g1; ++g) {
 					const int32_t q0 = g << 2;
 					uint32_t ain;
 					Tab4 T;
-					issue(group_idx(q0, ain), T);
-					uint32_t qv = (uint32_t)q0;
-					asm volatile("" : "+v"(qv));
+					issue(group_idx(kind, q0, ain), T);
+					int fix = 0;
+					if (wc.value == DIRTY)
+						fix = __builtin_amdgcn_readfirstlane(__ballot((ain & 0x01010101u) != 0u) != 0 ? 1 : 0);
+					if (wc.value == RAGGED) // lanes that are shut off never trigger the extra work
+						fix = __builtin_amdgcn_readfirstlane(
+						    __ballot((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff)) != 0 ? 1 : 0);
 #pragma unroll
 					for (int b = 0; b < 4; ++b) {
+						if (wc.value != CLEAN && fix) step_fix(q0 + b, (ain >> (8 * b)) & 1u);
 						roll(T.t[b]);
-						if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) {
-							if (sampled()) enqueue(qv, b);
-						}
+						if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) emit(q0 + b);
 					}
+					if ((g & 7) == 7) flush(g >> 3);
 				}
 			};
 			run(std::integral_constant<int, FILL>{}, 0, e0);
@@ -266,55 +298,24 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			run(std::integral_constant<int, MAIN>{}, e1, full_groups);
 			for (int32_t q = full_groups << 2; q < maxq; ++q) { // partial last group
 				const uint32_t ain = mine[q];
+				if (wc.value != CLEAN) step_fix(q, ain & 1u);
 				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
 				roll(*reinterpret_cast<const uint2*>(tabHb + off));
-				if (q >= (int32_t)k - 1 && sampled()) enqueue((uint32_t)q, 0);
+				if (q >= (int32_t)k - 1) emit(q);
 			}
-			if (maxq >= (int32_t)k) f1_wave += (uint64_t)nact * (uint32_t)(maxq - (int32_t)k + 1);
-		} else {
-			// ---- dirty / ragged wave: per-lane `nextok` (first step whose window is clean again) ----
-			auto step_fix = [&](int32_t q, uint32_t mark) {
-				if (mark && nextok != 0x7fffffff) nextok = q + (int32_t)k;
-				if (q >= endq) nextok = 0x7fffffff;
-			};
-			auto emit = [&](int32_t q, uint32_t qv, int b) {
-				const bool live = nextok <= q;
-				f1_wave += __popcll(__ballot(live));
-				if (live && sampled()) enqueue(qv, b);
-			};
-			auto run = [&](auto kind, int32_t g0, int32_t g1) {
-				for (int32_t g = g0; g < g1; ++g) {
-					const int32_t q0 = g << 2;
-					uint32_t ain;
-					Tab4 T;
-					issue(group_idx(q0, ain), T);
-					uint32_t qv = (uint32_t)q0;
-					asm volatile("" : "+v"(qv));
-					// lanes that are shut off (outside the batch / finished) never trigger the extra work
-					const bool fix = __any((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff));
-#pragma unroll
-					for (int b = 0; b < 4; ++b) {
-						if (fix) step_fix(q0 + b, (ain >> (8 * b)) & 1u);
-						roll(T.t[b]);
-						if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) emit(q0 + b, qv, b);
-					}
-				}
-			};
-			run(std::integral_constant<int, FILL>{}, 0, e0);
-			run(std::integral_constant<int, MIXED>{}, e0, e1);
-			run(std::integral_constant<int, MAIN>{}, e1, full_groups);
-			for (int32_t q = full_groups << 2; q < maxq; ++q) {
-				const uint32_t ain = mine[q];
-				step_fix(q, ain & 1u);
-				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
-				roll(*reinterpret_cast<const uint2*>(tabHb + off));
-				if (q >= (int32_t)k - 1) emit(q, (uint32_t)q, 0);
-			}
-		}
+			if ((maxq & 31) != 0) flush(maxq >> 5);
+			if (wc.value == CLEAN && maxq >= (int32_t)k)
+				f1_wave += (uint64_t)__popcll(__ballot(true)) * (uint32_t)(maxq - (int32_t)k + 1);
+		};
+		if (wclass == CLEAN)
+			walk(std::integral_constant<int, CLEAN>{});
+		else if (wclass == DIRTY)
+			walk(std::integral_constant<int, DIRTY>{});
+		else
+			walk(std::integral_constant<int, RAGGED>{});
 
 		// ---- resolve: compact (lane, step) pairs, 64 at a time recompute the full hashes ----
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const uint32_t nrec = qoff >> 8;
+		__builtin_amdgcn_wave_barrier();
 		auto resolve_round = [&](uint32_t first, uint32_t count) {
 			// entry -> window start in LDS (any lane's slot), then the closed form over k bases
 			const bool act = (uint32_t)lane < count;
@@ -349,24 +350,36 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
 				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
 				const bool c0 = (hi >> (31 - s_bits)) == 1u;
+#if NTC_EXP_NO_ATOMIC
+				if ((c0 | c1) && lo == 0x12345678u && hi == 0x9abcdef0u) atomicAdd(a.sketch, 1u); // A/B experiment
+#else
 				if (c0 | c1) atomicAdd(a.sketch + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
+#endif
 			}
 		};
 		uint32_t head = 0, tail = 0; // ring indices (wave-uniform)
-		for (uint32_t j = 0; __any(j < nrec); ++j) {
-			const bool has = j < nrec;
-			uint32_t qv = 0;
-			if (has) qv = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, lane * 4u + j * 256u, 0, 1 /*glc*/);
-			const uint64_t m = __ballot(has);
-			if (has) {
-				const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-				ring[(tail + pos) & (kRing - 1)] = ((uint32_t)lane << 16) | (qv & 0xffffu);
-			}
-			tail += (uint32_t)__popcll(m);
-			__builtin_amdgcn_wave_barrier();
-			if (tail - head >= 64u) {
-				resolve_round(head, 64u);
-				head += 64u;
+		const int32_t nblk = (maxq + 31) >> 5;
+		for (int32_t blk = 0; blk < nblk; ++blk) {
+			uint32_t cur = hm[blk * 64];
+#if NTC_EXP_NO_QUEUE
+			cur = 0;
+#endif
+			for (;;) {
+				const uint64_t m = __ballot(cur != 0u);
+				if (m == 0) break;
+				if (cur != 0u) {
+					const uint32_t bit = __builtin_ctz(cur);
+					cur &= cur - 1u;
+					const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+					ring[(tail + pos) & (kRing - 1)] = ((uint32_t)lane << 16) | ((uint32_t)blk * 32u + bit);
+				}
+				tail += (uint32_t)__popcll(m);
+				__builtin_amdgcn_wave_barrier();
+				if (tail - head >= 64u) {
+					resolve_round(head, 64u);
+					head += 64u;
+					__builtin_amdgcn_wave_barrier();
+				}
 			}
 		}
 		if (tail != head) resolve_round(head, tail - head);
