@@ -74,9 +74,18 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 #ifndef NTC_EXP_NO_ATOMIC
 #define NTC_EXP_NO_ATOMIC 0
 #endif
+#ifndef NTC_EXP_ABL
+#define NTC_EXP_ABL 0 // ablations of the walk: 1 no record, 2 no table lookup, 3 no data reads
+#endif
+#ifndef NTC_EXP_STAGE_ONLY
+#define NTC_EXP_STAGE_ONLY 0
+#endif
 #ifndef NTC_EXP_NO_QUEUE
 #define NTC_EXP_NO_QUEUE 0
 #endif
+// wave ballot of a bool without the int round trip hipcc's ballot() goes through (saves 2 VALU ops per use)
+__device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a dense resolve round
 
 } // namespace
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 					*reinterpret_cast<uint32_t*>(wdata + o) = decode4(*reinterpret_cast<const uint32_t*>(src + o), badacc);
 		}
 		__builtin_amdgcn_wave_barrier();
-		const bool wave_dirty = __builtin_amdgcn_readfirstlane(__ballot(badacc != 0u) != 0 ? 1 : 0) != 0;
+		const bool wave_dirty = __builtin_amdgcn_readfirstlane(ballot(badacc != 0u) != 0 ? 1 : 0) != 0;
 
 		// ---- per-lane read geometry ----
 		uint32_t len = a.read_len, wlim = a.read_len;
@@ -213,10 +222,6 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			const uint32_t xh = rHd ^ t.y;                    // reverse strand: ^ Tr, then rotr31
 			rHd = alignbit(xh >> 1, xh, 1);
 		};
-		auto sampled = [&]() -> bool {
-			const uint32_t m = fHd < rHd ? fHd : rHd; // top bits of min(fh,rh)
-			return ((m ^ lo0) < lo0) | ((int32_t)m >= lo1);
-		};
 		auto flush = [&](int32_t blk) { // end of a 32-step block: park the mask in LDS
 			hm[blk * 64] = hmask;
 			hmask = 0;
@@ -227,21 +232,32 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 		//   MAIN : every step has q >= k
 		constexpr int FILL = 0, MIXED = 1, MAIN = 2;
 		auto group_idx = [&](auto kind, int32_t q0, uint32_t& ain) -> uint32_t {
+#if NTC_EXP_ABL == 3
+			ain = 0x40c08000u;
+			return (uint32_t)q0 * 0x10101010u & 0xf0f0f0f0u;
+#endif
 			ain = *reinterpret_cast<const uint32_t*>(mine + q0);
 			if (kind.value == FILL) return ain & 0xc0c0c0c0u;
 			uint32_t aout = 0;
 			if (kind.value == MAIN || q0 + 3 >= (int32_t)k) {
 				const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + ((q0 - (int32_t)k) & ~3));
-				aout = shb ? alignbyte(p[1], p[0], shb) : p[0];
+				aout = alignbyte(p[1], p[0], shb); // shb == 0 returns p[0]; unconditional: no per-group branch
 				if (kind.value == MIXED && q0 < (int32_t)k) aout &= 0xffffffffu << (8 * ((int32_t)k - q0));
 			}
-			// bits 7:6 of every byte from ain (incoming code), bits 5:4 from aout >> 2 (outgoing code); v_bfi_b32
-			return (ain & 0xc0c0c0c0u) | ((aout >> 2) & 0x3f3f3f3fu);
+			// bits 7:6 of every byte from ain (incoming code), bits 5:4 from aout >> 2 (outgoing code): one v_bfi_b32
+			constexpr uint32_t M = 0xc0c0c0c0u;
+			uint32_t idx4 = (ain & M) | ((aout >> 2) & ~M);
+			asm volatile("" : "+v"(idx4)); // keep it ONE v_bfi_b32: stops hipcc from re-deriving byte 0 with three more ops
+			return idx4;
 		};
 		struct Tab4 {
 			uint2 t[4];
 		};
 		auto issue = [&](uint32_t idx4, Tab4& T) {
+#if NTC_EXP_ABL == 2
+			T.t[0] = T.t[1] = T.t[2] = T.t[3] = make_uint2(idx4, idx4 * 3u);
+			return;
+#endif
 			T.t[0] = *reinterpret_cast<const uint2*>(tabHb + (idx4 & 0xffu));
 			T.t[1] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> 8) & 0xffu));
 			T.t[2] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> 16) & 0xffu));
@@ -256,21 +272,39 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 		const int32_t e0 = gk < full_groups ? gk : full_groups;
 		const int32_t e1 = gm < full_groups ? gm : full_groups;
 
+		// Sampled steps are recorded without a branch: every step from the first non-FILL group on shifts
+		// the lane's mask left and shifts the wave's "sampled" condition in as carry (one v_addc_co_u32);
+		// after 32 steps the mask is parked in LDS.  Step q of block b sits at bit (steps_in_block-1-(q-q_b)).
+		auto push = [&](uint64_t m) { asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(hmask), "+s"(m)); };
+		const int32_t qs = e0 << 2; // first step that is recorded
+		uint32_t f1_lane = 0;       // DIRTY / RAGGED: clean windows of this lane (accumulated on the rare path)
+
 		auto walk = [&](auto wc) {
-			// per-lane bookkeeping of the DIRTY / RAGGED classes
-			auto step_fix = [&](int32_t q, uint32_t mark) {
-				if (mark && (wc.value == DIRTY || nextok != 0x7fffffff)) nextok = q + (int32_t)k;
-				if (wc.value == RAGGED && q >= endq) nextok = 0x7fffffff;
-			};
-			auto emit = [&](int32_t q) {
-				const uint32_t bit = 1u << (q & 31);
-				if (wc.value == CLEAN) {
-					if (sampled()) hmask |= bit;
-				} else {
-					const bool live = nextok <= q;
-					f1_wave += __popcll(__ballot(live));
-					if (live && sampled()) hmask |= bit;
+			// a dirty byte at step q closes the current run of clean windows [nextok, q) and reopens at q+k
+			auto on_mark = [&](int32_t q) {
+				if (nextok != 0x7fffffff) {
+					if (q > nextok) f1_lane += (uint32_t)(q - nextok);
+					nextok = q + (int32_t)k;
 				}
+			};
+			auto on_end = [&](int32_t q) { // RAGGED: the lane's last step was q-1
+				if (q >= endq && nextok != 0x7fffffff) {
+					if (endq > nextok) f1_lane += (uint32_t)(endq - nextok);
+					nextok = 0x7fffffff;
+				}
+			};
+			auto record = [&](int32_t q, bool emitting) {
+#if NTC_EXP_ABL == 1
+				hmask ^= fHd & rHd;
+				return;
+#endif
+				uint64_t m = 0;
+				if (emitting) {
+					const uint32_t mn = fHd < rHd ? fHd : rHd; // top bits of min(fh,rh)
+					m = ballot((mn ^ lo0) < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64
+					if (wc.value != CLEAN) m &= ballot(nextok <= q);
+				}
+				push(m);
 			};
 			auto run = [&](auto kind, int32_t g0, int32_t g1) {
 				for (int32_t g = g0; g < g1; ++g) {
@@ -278,19 +312,30 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 					uint32_t ain;
 					Tab4 T;
 					issue(group_idx(kind, q0, ain), T);
-					int fix = 0;
-					if (wc.value == DIRTY)
-						fix = __builtin_amdgcn_readfirstlane(__ballot((ain & 0x01010101u) != 0u) != 0 ? 1 : 0);
+					uint64_t fixm = 0;
+					if (wc.value == DIRTY) fixm = ballot((ain & 0x01010101u) != 0u);
 					if (wc.value == RAGGED) // lanes that are shut off never trigger the extra work
-						fix = __builtin_amdgcn_readfirstlane(
-						    __ballot((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff)) != 0 ? 1 : 0);
+						fixm = ballot((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff));
+					uint32_t fix = (uint32_t)(fixm | (fixm >> 32));
+					asm volatile("" : "+s"(fix)); // opaque SGPR: the test below must stay a scalar branch
+					// two copies of the group body behind ONE scalar branch: the common (no dirty byte, no read
+					// end in this group) copy carries no per-lane bookkeeping at all
+					if (wc.value != CLEAN && fix) {
 #pragma unroll
-					for (int b = 0; b < 4; ++b) {
-						if (wc.value != CLEAN && fix) step_fix(q0 + b, (ain >> (8 * b)) & 1u);
-						roll(T.t[b]);
-						if (kind.value == MAIN || (kind.value == MIXED && q0 + b >= (int32_t)k - 1)) emit(q0 + b);
+						for (int b = 0; b < 4; ++b) {
+							if (wc.value == RAGGED) on_end(q0 + b);
+							if ((ain >> (8 * b)) & 1u) on_mark(q0 + b);
+							roll(T.t[b]);
+							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
+						}
+					} else {
+#pragma unroll
+						for (int b = 0; b < 4; ++b) {
+							roll(T.t[b]);
+							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
+						}
 					}
-					if ((g & 7) == 7) flush(g >> 3);
+					if (kind.value != FILL && ((g - e0) & 7) == 7) flush((g - e0) >> 3);
 				}
 			};
 			run(std::integral_constant<int, FILL>{}, 0, e0);
@@ -298,15 +343,28 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			run(std::integral_constant<int, MAIN>{}, e1, full_groups);
 			for (int32_t q = full_groups << 2; q < maxq; ++q) { // partial last group
 				const uint32_t ain = mine[q];
-				if (wc.value != CLEAN) step_fix(q, ain & 1u);
+				if (wc.value != CLEAN) {
+					if (wc.value == RAGGED) on_end(q);
+					if (ain & 1u) on_mark(q);
+				}
 				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
 				roll(*reinterpret_cast<const uint2*>(tabHb + off));
-				if (q >= (int32_t)k - 1) emit(q);
+				record(q, q >= (int32_t)k - 1);
 			}
-			if ((maxq & 31) != 0) flush(maxq >> 5);
-			if (wc.value == CLEAN && maxq >= (int32_t)k)
-				f1_wave += (uint64_t)__popcll(__ballot(true)) * (uint32_t)(maxq - (int32_t)k + 1);
+			if (maxq > qs && ((maxq - qs) & 31) != 0) flush((maxq - qs) >> 5);
+			if (wc.value == CLEAN) {
+				if (maxq >= (int32_t)k) f1_wave += (uint64_t)__popcll(ballot(true)) * (uint32_t)(maxq - (int32_t)k + 1);
+			} else {
+				if (nextok != 0x7fffffff && endq > nextok) f1_lane += (uint32_t)(endq - nextok);
+				uint32_t v = f1_lane;
+				for (int o = 32; o > 0; o >>= 1)
+					v += __shfl_xor(v, o);
+				f1_wave += __builtin_amdgcn_readfirstlane(v);
+			}
 		};
+#if NTC_EXP_STAGE_ONLY
+		if (mine[lane] == 0x7f && a.k == 9999) // A/B experiment: staging only (never true)
+#endif
 		if (wclass == CLEAN)
 			walk(std::integral_constant<int, CLEAN>{});
 		else if (wclass == DIRTY)
@@ -358,20 +416,24 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			}
 		};
 		uint32_t head = 0, tail = 0; // ring indices (wave-uniform)
-		const int32_t nblk = (maxq + 31) >> 5;
+		const int32_t nrec_steps = maxq > qs ? maxq - qs : 0;
+		const int32_t nblk = (nrec_steps + 31) >> 5;
 		for (int32_t blk = 0; blk < nblk; ++blk) {
+			// the block's first step sits at its highest recorded bit
+			const int32_t in_blk = nrec_steps - blk * 32 < 32 ? nrec_steps - blk * 32 : 32;
+			const uint32_t top = (uint32_t)(qs + blk * 32 + in_blk - 1);
 			uint32_t cur = hm[blk * 64];
 #if NTC_EXP_NO_QUEUE
 			cur = 0;
 #endif
 			for (;;) {
-				const uint64_t m = __ballot(cur != 0u);
+				const uint64_t m = ballot(cur != 0u);
 				if (m == 0) break;
 				if (cur != 0u) {
 					const uint32_t bit = __builtin_ctz(cur);
 					cur &= cur - 1u;
 					const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-					ring[(tail + pos) & (kRing - 1)] = ((uint32_t)lane << 16) | ((uint32_t)blk * 32u + bit);
+					ring[(tail + pos) & (kRing - 1)] = ((uint32_t)lane << 16) | (top - bit);
 				}
 				tail += (uint32_t)__popcll(m);
 				__builtin_amdgcn_wave_barrier();
