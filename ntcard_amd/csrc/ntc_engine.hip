@@ -64,7 +64,7 @@ size_t smem_for(uint32_t stride, int kind, uint32_t k)
 	const size_t data = (size_t)ntc::kWavesPerBlock * 64u * stride;
 	if (kind == KIND_SIMPLE) return (size_t)ntc::kTableBytes + data;
 	if (kind == KIND_FAST) return 16 + data;
-	return 16 + data + (size_t)k * 64u + (size_t)ntc::kWavesPerBlock * 128u * 4u +
+	return 16 + data + (size_t)ntc::t2_pairs(k) * 256u + (size_t)ntc::kWavesPerBlock * 128u * 4u +
 	       (size_t)ntc::kWavesPerBlock * ((stride + 31u) / 32u) * 64u * 4u; // + closed-form table, rings, hit masks
 }
 
@@ -265,8 +265,8 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate histogram on device");
 	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
-		std::vector<uint32_t> t1((size_t)e->klist[ki] * 16);
-		ntc::build_t1(e->klist[ki], t1.data());
+		std::vector<uint32_t> t1((size_t)ntc::t2_pairs(e->klist[ki]) * 64);
+		ntc::build_t2(e->klist[ki], t1.data());
 		void* d = nullptr;
 		if (hipMalloc(&d, t1.size() * 4) != hipSuccess || hipMemcpy(d, t1.data(), t1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
 			ntc_destroy(e);

@@ -26,7 +26,7 @@ struct HashArgs {
 	uint32_t* dump_count;       // MODE 1: [n_slots]
 	void* queue;                // fast kernel: per-wave hit queues, [grid*4][queue_rows][64] x 16 B
 	uint32_t queue_rows;        // rows (hits per lane) each wave queue can hold
-	const void* t1;             // H-filter kernel: [k][4] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seeds (device)
+	const void* t1;             // H-filter kernel: [ceil(k/2)][16] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seed pairs (device)
 	uint32_t init[6];           // fast kernel: strand registers of the k x 'A' window {flo,fB,fHd,rlo,rB,rHd}
 	HashTables tab;
 };

@@ -14,7 +14,7 @@
 //   * after the read, the wave compacts the (lane, step) pairs and 64 lanes at a time recompute the
 //     full 64-bit forward and reverse hashes of those windows from the closed form
 //     fh = XOR_i srol^(k-1-i)(seed(c_i)), rh = XOR_i srol^i(comp(c_i))      (nthash.hpp:220-239)
-//     with a k x 4 table of pre-rotated seeds in LDS, take the canonical min (nthash.hpp:275-279),
+//     with a ceil(k/2) x 16 table of pre-rotated seed PAIRS in LDS (two bases per lookup), take the canonical min (nthash.hpp:275-279),
 //     and update the sketch.  Full 64-bit compare: exact, no tie special case.
 //
 // Semantics reproduced: ntRead (ntcard.cpp:147-158), ntHashIterator (ntHashIterator.hpp:59-86),
@@ -92,7 +92,7 @@ constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a 
 
 __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashArgs a)
 {
-	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][k x 4 x 16 B closed-form table][waves x ring]
+	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][ceil(k/2) x 256 B closed-form table][waves x ring]
 	//              [waves x ceil(stride/32) x 64 hit-mask words]
 	extern __shared__ __align__(16) unsigned char smem[];
 	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
@@ -105,16 +105,17 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	unsigned char* const wdata = smem + 16 + (size_t)wave * 64u * stride;
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
 	unsigned char* const t1 = smem + 16 + (size_t)kWavesPerBlock * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
-	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + (size_t)k * 64u) + wave * kRing;
+	const uint32_t t1_bytes = ((k + 1u) >> 1) * 256u;
+	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + wave * kRing;
 	const uint32_t hm_words = (stride + 31u) >> 5; // 32-step blocks per slot
-	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + (size_t)k * 64u) + kWavesPerBlock * kRing + wave * hm_words * 64u + lane;
+	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + kWavesPerBlock * kRing + wave * hm_words * 64u + lane;
 	{
 		for (int i = tid; i < kMainSlots * 4; i += kBlockThreads) {
 			const int slot = i >> 2, w = i & 3;
 			tabH[i] = w == 0 ? a.tab.A[slot][1] : (w == 1 ? a.tab.A[slot][3] : 0u);
 		}
 		const uint4* src = reinterpret_cast<const uint4*>(a.t1);
-		for (uint32_t i = tid; i < k * 4u; i += kBlockThreads)
+		for (uint32_t i = tid; i < t1_bytes / 16u; i += kBlockThreads)
 			reinterpret_cast<uint4*>(t1)[i] = src[i];
 	}
 	__syncthreads();
@@ -387,19 +388,26 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			const unsigned char* tp = t1;
 			for (uint32_t i = 0; i < k; i += 4) {
 				const uint32_t nxt = dp[(i >> 2) + 1];
-				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes of window positions i..i+3
+				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes (code<<6) of window positions i..i+3
 				cur = nxt;
-#pragma unroll
-				for (int b = 0; b < 4; ++b) {
-					if (i + b < k) {
-						const uint32_t off = ((w >> (8 * b + 2)) & 0x30u); // code * 16
-						const uint4 t = *reinterpret_cast<const uint4*>(tp + (i + b) * 64u + off);
-						flo ^= t.x;
-						fhi ^= t.y;
-						rlo ^= t.z;
-						rhi ^= t.w;
-					}
+				// pair offsets (a<<6 | b<<4): bytes 0,1 and bytes 2,3; a base beyond k contributes nothing
+				// because the odd-k table drops the b term and positions >= k are never looked up
+				const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
+				const uint4 t0 = *reinterpret_cast<const uint4*>(tp + o0);
+				flo ^= t0.x;
+				fhi ^= t0.y;
+				rlo ^= t0.z;
+				rhi ^= t0.w;
+				if (i + 2 < k) {
+					const uint32_t w2 = w >> 16;
+					const uint32_t o1 = (w2 & 0xc0u) | ((w2 >> 10) & 0x30u);
+					const uint4 t1v = *reinterpret_cast<const uint4*>(tp + 256 + o1);
+					flo ^= t1v.x;
+					fhi ^= t1v.y;
+					rlo ^= t1v.z;
+					rhi ^= t1v.w;
 				}
+				tp += 512;
 			}
 			if (act) {
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279

@@ -90,19 +90,28 @@ inline void poly_a_state(unsigned k, uint32_t out[6])
 	out[5] = hd_of(rh);
 }
 
-// Closed-form table of the resolve stage: entry (i, code) = { srol^(k-1-i)(seed(code)), srol^i(comp(code)) }
-// as {fwd.lo, fwd.hi, rev.lo, rev.hi} (nthash.hpp:220-239: fh = XOR_i srol^(k-1-i) seed(c_i), rh = XOR_i srol^i comp(c_i))
-inline void build_t1(unsigned k, uint32_t* out /* k*4*4 dwords */)
+// Closed-form table of the resolve stage, two bases per entry: entry (j, a, b) covers window positions 2j, 2j+1
+//   fwd = srol^(k-1-2j)(seed(a)) ^ srol^(k-2-2j)(seed(b)),  rev = srol^(2j)(comp(a)) ^ srol^(2j+1)(comp(b))
+// as {fwd.lo, fwd.hi, rev.lo, rev.hi} (nthash.hpp:220-239: fh = XOR_i srol^(k-1-i) seed(c_i), rh = XOR_i srol^i comp(c_i)).
+// For odd k the last pair has no second base (its b term is dropped).  Entry offset: j*256 + (a*4+b)*16 bytes.
+inline unsigned t2_pairs(unsigned k) { return (k + 1) / 2; }
+inline void build_t2(unsigned k, uint32_t* out /* t2_pairs(k)*16*4 dwords */)
 {
-	for (unsigned i = 0; i < k; ++i)
-		for (unsigned c = 0; c < 4; ++c) {
-			const uint64_t f = srol(seed_of(c), k - 1 - i), r = srol(comp_of(c), i);
-			uint32_t* e = out + (i * 4 + c) * 4;
-			e[0] = (uint32_t)f;
-			e[1] = (uint32_t)(f >> 32);
-			e[2] = (uint32_t)r;
-			e[3] = (uint32_t)(r >> 32);
-		}
+	for (unsigned j = 0; j < t2_pairs(k); ++j)
+		for (unsigned a = 0; a < 4; ++a)
+			for (unsigned b = 0; b < 4; ++b) {
+				const unsigned i0 = 2 * j, i1 = 2 * j + 1;
+				uint64_t f = srol(seed_of(a), k - 1 - i0), r = srol(comp_of(a), i0);
+				if (i1 < k) {
+					f ^= srol(seed_of(b), k - 1 - i1);
+					r ^= srol(comp_of(b), i1);
+				}
+				uint32_t* e = out + ((j * 16) + a * 4 + b) * 4;
+				e[0] = (uint32_t)f;
+				e[1] = (uint32_t)(f >> 32);
+				e[2] = (uint32_t)r;
+				e[3] = (uint32_t)(r >> 32);
+			}
 }
 
 } // namespace ntc
