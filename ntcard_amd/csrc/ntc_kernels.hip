@@ -251,7 +251,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
                                                        uint64_t n_per_sample, uint32_t* __restrict__ p_hist,
                                                        uint16_t* __restrict__ out16)
 {
-	// grid.y = sample
+	// grid.y = sample.  Counter values are tiny for almost every bucket, so each block histograms the
+	// values below kLocal in LDS and only the rare large ones go to global atomics directly.
+	constexpr uint32_t kLocal = 2048;
+	__shared__ uint32_t lh[kLocal];
+	for (uint32_t i = threadIdx.x; i < kLocal; i += blockDim.x)
+		lh[i] = 0;
+	__syncthreads();
 	const unsigned s = blockIdx.y;
 	const uint32_t* src = sketch + (uint64_t)s * n_per_sample;
 	uint16_t* dst = out16 ? out16 + (uint64_t)s * n_per_sample : nullptr;
@@ -266,6 +272,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
 		for (int j = 0; j < 4; ++j) {
 			if (c[j] == 0)
 				++zeros;
+			else if (c[j] < kLocal)
+				atomicAdd(&lh[c[j]], 1u);
 			else
 				atomicAdd(p + c[j], 1u);
 		}
@@ -279,6 +287,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
 	for (int o = 32; o > 0; o >>= 1)
 		zeros += __shfl_xor(zeros, o);
 	if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(p, zeros);
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < kLocal; i += blockDim.x) {
+		const uint32_t n = lh[i];
+		if (n) atomicAdd(p + i, n);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
