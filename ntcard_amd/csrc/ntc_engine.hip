@@ -59,21 +59,22 @@ int device_info(int dev, DevInfo& di)
 // kernel kinds: the simple validation kernel, the first tuned kernel, the H-filter kernel (default)
 enum { KIND_SIMPLE = 0, KIND_FAST = 1, KIND_HF = 2 };
 
-size_t smem_for(uint32_t stride, int kind, uint32_t k)
+size_t smem_for(uint32_t stride, int kind, uint32_t k, uint32_t gap = 0)
 {
 	const size_t data = (size_t)ntc::kWavesPerBlock * 64u * stride;
 	if (kind == KIND_SIMPLE) return (size_t)ntc::kTableBytes + data;
 	if (kind == KIND_FAST) return 16 + data;
 	return 16 + data + (size_t)ntc::t2_pairs(k) * 256u + (size_t)ntc::kWavesPerBlock * 128u * 4u +
-	       (size_t)ntc::kWavesPerBlock * ((stride + 31u) / 32u) * 64u * 4u; // + closed-form table, rings, hit masks
+	       (size_t)ntc::kWavesPerBlock * ((stride + 31u) / 32u) * 64u * 4u + // + closed-form table, rings, hit masks
+	       (size_t)((gap + 1u) / 2u) * 256u;                                   // + spaced-seed table
 }
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
-int hash_grid(int dev, uint64_t n_slots, uint32_t stride, int kind, uint32_t k, unsigned& grid, size_t& smem)
+int hash_grid(int dev, uint64_t n_slots, uint32_t stride, int kind, uint32_t k, unsigned& grid, size_t& smem, uint32_t gap = 0)
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
-	smem = smem_for(stride, kind, k);
+	smem = smem_for(stride, kind, k, gap);
 	const size_t total = smem + (kind == KIND_FAST ? (size_t)ntc::kTableBytes : (kind == KIND_HF ? 256 : 0));
 	if (total > 160 * 1024) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, total);
 	if (kind == KIND_HF)
@@ -104,6 +105,7 @@ struct ntc_engine {
 	void* d_queue = nullptr;     // fast kernel: per-wave hit queues
 	size_t queue_cap = 0;
 	int kernel_kind = 2;         // KIND_HF unless NTC_FLAG_SIMPLE_KERNEL / NTC_FLAG_FAST_KERNEL
+	void* d_gapt = nullptr;      // spaced seed: filter table of the don't-care positions
 	std::vector<void*> d_t1;     // per k: closed-form table of the H-filter kernel's resolve stage
 	// host-submit staging (grow-only)
 	unsigned char* h_stage = nullptr;
@@ -148,7 +150,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	size_t smem = 0;
 	const int kind = e->kernel_kind;
 	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
-	if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem)) return rc;
+	if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem, e->gap)) return rc;
 	// every lane can queue at most one hit per window of its slot: `stride` rows always suffice
 	const uint32_t queue_rows = stride;
 	if (kind == KIND_FAST) {
@@ -187,7 +189,10 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		a.queue = e->d_queue;
 		a.queue_rows = queue_rows;
 		a.t1 = e->d_t1[ki];
-		const size_t smem_k = smem_for(stride, kind, a.k);
+		a.gapt = e->d_gapt;
+		a.gap = e->gap;
+		a.gap_first = (a.k - e->gap) / 2;
+		const size_t smem_k = smem_for(stride, kind, a.k, e->gap);
 		if (kind == KIND_HF)
 			HIP_TRY(ntc::launch_sketch_hf(a, grid, smem_k, e->stream));
 		else if (kind == KIND_FAST)
@@ -223,7 +228,8 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		if (cfg->n_k != 1) return fail(NTC_ERR_ARG, "ntc_create: gap seed does not support multiple k");
 		if (cfg->gap % 2 != cfg->k[0] % 2 || cfg->gap >= cfg->k[0])
 			return fail(NTC_ERR_ARG, "ntc_create: gap size and kmer must have the same modulus");
-		return fail(NTC_ERR_ARG, "ntc_create: gap seeds are not implemented in this build");
+		if (cfg->flags & (NTC_FLAG_SIMPLE_KERNEL | NTC_FLAG_FAST_KERNEL))
+			return fail(NTC_ERR_ARG, "ntc_create: spaced seeds need the default (H-filter) kernel");
 	}
 	if (cfg->r_bits < 8 || cfg->r_bits > 30) return fail(NTC_ERR_ARG, "ntc_create: r_bits %u outside 8..30", cfg->r_bits);
 	if (cfg->s_bits < 2 || cfg->s_bits > 24) return fail(NTC_ERR_ARG, "ntc_create: s_bits %u outside 2..24", cfg->s_bits);
@@ -266,13 +272,22 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		std::vector<uint32_t> t1((size_t)ntc::t2_pairs(e->klist[ki]) * 64);
-		ntc::build_t2(e->klist[ki], t1.data());
+		const uint32_t gap_first = (e->klist[ki] - e->gap) / 2; // "1"x(k-g)/2 "0"xg "1"x(k-g)/2, ntcard.cpp:407-413
+		ntc::build_t2(e->klist[ki], t1.data(), gap_first, e->gap);
 		void* d = nullptr;
 		if (hipMalloc(&d, t1.size() * 4) != hipSuccess || hipMemcpy(d, t1.data(), t1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
 			ntc_destroy(e);
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form seed table on device");
 		}
 		e->d_t1.push_back(d);
+	}
+	if (e->gap) {
+		std::vector<uint32_t> gt((size_t)((e->gap + 1) / 2) * 64);
+		ntc::build_gap_table(e->klist[0], (e->klist[0] - e->gap) / 2, e->gap, gt.data());
+		if (hipMalloc(&e->d_gapt, gt.size() * 4) != hipSuccess || hipMemcpy(e->d_gapt, gt.data(), gt.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+			ntc_destroy(e);
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the spaced-seed table on device");
+		}
 	}
 	int rc = ntc_reset(e);
 	if (rc) {
@@ -298,6 +313,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_queue) (void)hipFree(e->d_queue);
 	for (void* d : e->d_t1) (void)hipFree(d);
+	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_stage) (void)hipFree(e->d_stage);
 	if (e->d_meta) (void)hipFree(e->d_meta);
 	if (e->h_stage) (void)hipHostFree(e->h_stage);

@@ -27,6 +27,8 @@ struct HashArgs {
 	void* queue;                // fast kernel: per-wave hit queues, [grid*4][queue_rows][64] x 16 B
 	uint32_t queue_rows;        // rows (hits per lane) each wave queue can hold
 	const void* t1;             // H-filter kernel: [ceil(k/2)][16] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seed pairs (device)
+	const void* gapt;           // H-filter kernel, spaced seed: [ceil(gap/2)][16] x {f.Hd, r.Hd, 0, 0} terms to XOR out
+	uint32_t gap, gap_first;    // number of don't-care positions and index of the first one (ntcard.cpp:407-413)
 	uint32_t init[6];           // fast kernel: strand registers of the k x 'A' window {flo,fB,fHd,rlo,rB,rHd}
 	HashTables tab;
 };

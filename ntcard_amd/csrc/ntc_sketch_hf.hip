@@ -109,6 +109,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + wave * kRing;
 	const uint32_t hm_words = (stride + 31u) >> 5; // 32-step blocks per slot
 	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + kWavesPerBlock * kRing + wave * hm_words * 64u + lane;
+	// spaced seed (stRead, ntcard.cpp:160-171): per pair of don't-care positions, the H halves of the terms to XOR out
+	const uint32_t ngp = (a.gap + 1u) >> 1;
+	unsigned char* const gapT = t1 + t1_bytes + (size_t)kWavesPerBlock * (kRing + hm_words * 64u) * 4u;
 	{
 		for (int i = tid; i < kMainSlots * 4; i += kBlockThreads) {
 			const int slot = i >> 2, w = i & 3;
@@ -117,6 +120,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 		const uint4* src = reinterpret_cast<const uint4*>(a.t1);
 		for (uint32_t i = tid; i < t1_bytes / 16u; i += kBlockThreads)
 			reinterpret_cast<uint4*>(t1)[i] = src[i];
+		const uint4* gsrc = reinterpret_cast<const uint4*>(a.gapt);
+		for (uint32_t i = tid; i < ngp * 16u; i += kBlockThreads)
+			reinterpret_cast<uint4*>(gapT)[i] = gsrc[i];
 	}
 	__syncthreads();
 	const unsigned char* const tabHb = reinterpret_cast<const unsigned char*>(tabH);
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 		const int32_t qs = e0 << 2; // first step that is recorded
 		uint32_t f1_lane = 0;       // DIRTY / RAGGED: clean windows of this lane (accumulated on the rare path)
 
-		auto walk = [&](auto wc) {
+		auto walk = [&](auto wc, auto gapped) {
 			// a dirty byte at step q closes the current run of clean windows [nextok, q) and reopens at q+k
 			auto on_mark = [&](int32_t q) {
 				if (nextok != 0x7fffffff) {
@@ -301,7 +307,18 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 #endif
 				uint64_t m = 0;
 				if (emitting) {
-					const uint32_t mn = fHd < rHd ? fHd : rHd; // top bits of min(fh,rh)
+					uint32_t fs = fHd, rs = rHd;
+					if (gapped.value) {
+						// NTMSM64 (nthash.hpp:641-646,665-670): XOR the don't-care bases' rotated seeds back out
+						const unsigned char* gp = mine + (q - (int32_t)k + 1 + (int32_t)a.gap_first);
+						for (uint32_t p = 0; p < ngp; ++p) {
+							const uint32_t off = (gp[2 * p] & 0xc0u) | ((gp[2 * p + 1] >> 2) & 0x30u);
+							const uint2 g = *reinterpret_cast<const uint2*>(gapT + p * 256u + off);
+							fs ^= g.x;
+							rs ^= g.y;
+						}
+					}
+					const uint32_t mn = fs < rs ? fs : rs; // top bits of min(fh,rh) (of the spaced-seed values when gapped)
 					m = ballot((mn ^ lo0) < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64
 					if (wc.value != CLEAN) m &= ballot(nextok <= q);
 				}
@@ -366,12 +383,14 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 #if NTC_EXP_STAGE_ONLY
 		if (mine[lane] == 0x7f && a.k == 9999) // A/B experiment: staging only (never true)
 #endif
-		if (wclass == CLEAN)
-			walk(std::integral_constant<int, CLEAN>{});
+		if (a.gap != 0)
+			walk(std::integral_constant<int, RAGGED>{}, std::true_type{}); // one (general) class keeps the gapped code small
+		else if (wclass == CLEAN)
+			walk(std::integral_constant<int, CLEAN>{}, std::false_type{});
 		else if (wclass == DIRTY)
-			walk(std::integral_constant<int, DIRTY>{});
+			walk(std::integral_constant<int, DIRTY>{}, std::false_type{});
 		else
-			walk(std::integral_constant<int, RAGGED>{});
+			walk(std::integral_constant<int, RAGGED>{}, std::false_type{});
 
 		// ---- resolve: compact (lane, step) pairs, 64 at a time recompute the full hashes ----
 		__builtin_amdgcn_wave_barrier();

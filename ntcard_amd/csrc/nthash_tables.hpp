@@ -95,14 +95,16 @@ inline void poly_a_state(unsigned k, uint32_t out[6])
 // as {fwd.lo, fwd.hi, rev.lo, rev.hi} (nthash.hpp:220-239: fh = XOR_i srol^(k-1-i) seed(c_i), rh = XOR_i srol^i comp(c_i)).
 // For odd k the last pair has no second base (its b term is dropped).  Entry offset: j*256 + (a*4+b)*16 bytes.
 inline unsigned t2_pairs(unsigned k) { return (k + 1) / 2; }
-inline void build_t2(unsigned k, uint32_t* out /* t2_pairs(k)*16*4 dwords */)
+inline void build_t2(unsigned k, uint32_t* out /* t2_pairs(k)*16*4 dwords */, unsigned gap_first = 0, unsigned gap = 0)
 {
+	auto dc = [&](unsigned i) { return i >= gap_first && i < gap_first + gap; }; // don't-care position of a spaced seed
 	for (unsigned j = 0; j < t2_pairs(k); ++j)
 		for (unsigned a = 0; a < 4; ++a)
 			for (unsigned b = 0; b < 4; ++b) {
 				const unsigned i0 = 2 * j, i1 = 2 * j + 1;
 				uint64_t f = srol(seed_of(a), k - 1 - i0), r = srol(comp_of(a), i0);
-				if (i1 < k) {
+				if (dc(i0)) f = r = 0; // spaced seed: this base does not enter the hash (nthash.hpp:641-646)
+				if (i1 < k && !dc(i1)) {
 					f ^= srol(seed_of(b), k - 1 - i1);
 					r ^= srol(comp_of(b), i1);
 				}
@@ -111,6 +113,27 @@ inline void build_t2(unsigned k, uint32_t* out /* t2_pairs(k)*16*4 dwords */)
 				e[1] = (uint32_t)(f >> 32);
 				e[2] = (uint32_t)r;
 				e[3] = (uint32_t)(r >> 32);
+			}
+}
+
+// Spaced-seed filter table: for the p-th PAIR of don't-care positions (i, i+1), entry (a, b) holds the H halves
+// (Hd layout) of  srol^(k-1-i)(seed(a)) ^ srol^(k-2-i)(seed(b))  and  srol^i(comp(a)) ^ srol^(i+1)(comp(b)),
+// i.e. what NTMSM64 XORs out of fh / rh (nthash.hpp:641-646).  16-byte stride: {f.Hd, r.Hd, 0, 0}.
+inline void build_gap_table(unsigned k, unsigned gap_first, unsigned gap, uint32_t* out /* ceil(gap/2)*16*4 dwords */)
+{
+	for (unsigned p = 0; p < (gap + 1) / 2; ++p)
+		for (unsigned a = 0; a < 4; ++a)
+			for (unsigned b = 0; b < 4; ++b) {
+				const unsigned i0 = gap_first + 2 * p, i1 = i0 + 1;
+				uint64_t f = srol(seed_of(a), k - 1 - i0), r = srol(comp_of(a), i0);
+				if (i1 < gap_first + gap) {
+					f ^= srol(seed_of(b), k - 1 - i1);
+					r ^= srol(comp_of(b), i1);
+				}
+				uint32_t* e = out + ((p * 16) + a * 4 + b) * 4;
+				e[0] = hd_of(f);
+				e[1] = hd_of(r);
+				e[2] = e[3] = 0;
 			}
 }
 

@@ -189,9 +189,9 @@ def test_golden_sketch_digests(nt, golden_dir):
     with open(os.path.join(golden_dir, "sketch_goldens.json")) as f:
         gold = json.load(f)
     for ent in gold:
-        if ent["gap"] != 0 or ent["r_bits"] > 22:
+        if ent["r_bits"] > 22:
             continue
-        with nt.Engine(ent["klist"], r_bits=ent["r_bits"], s_bits=ent["s_bits"]) as e:
+        with nt.Engine(ent["klist"], gap=ent["gap"], r_bits=ent["r_bits"], s_bits=ent["s_bits"]) as e:
             e.submit_reads(reads)
             tc, ph, f1 = e.finish(counters=True)
         assert [int(x) for x in f1] == ent["f1"]
@@ -199,6 +199,32 @@ def test_golden_sketch_digests(nt, golden_dir):
             assert "%016x" % orc.fnv1a64(tc[ki]) == pl["fnv1a64"]
             nz = [[int(s), int(v), int(ph[ki][s, v])] for s in range(2) for v in np.nonzero(ph[ki][s])[0]]
             assert nz == pl["p_nonzero"]
+
+
+@pytest.mark.parametrize("k,gap", [(12, 2), (12, 4), (13, 3), (20, 8), (32, 8), (33, 1), (64, 10), (31, 29)])
+def test_gap_seeds_match_oracle(nt, k, gap):
+    """stRead / stHashIterator path (ntcard.cpp:160-171): spaced seed 1^((k-g)/2) 0^g 1^((k-g)/2)"""
+    rng = random.Random(k * 100 + gap)
+    reads = [rseq(rng, rng.choice([k - 1, k, k + 1, 70, 150, 151]), pn=rng.choice([0, 0, 0.01, 0.05])) for _ in range(4000)]
+    reads += [rseq(rng, n, pn=0.002) for n in (300, 2000)]
+    with nt.Engine([k], gap=gap, r_bits=18, s_bits=5) as e:
+        e.submit_reads(reads)
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads(reads, [k], gap, 18, 5)
+    assert np.array_equal(f1, of1)
+    assert np.array_equal(tc, oc)
+
+
+def test_golden_gap_hist_from_reference(nt, golden_dir, tmp_path):
+    """the reference CLI's `-k 12 -g 2` output (the shape of its own check-dna-gap target, Makefile.am:53-54,71-72)"""
+    reads = small_reads(golden_dir)
+    with nt.Engine([12], gap=2, r_bits=27, s_bits=7) as e:
+        e.submit_reads(reads)
+        _, ph, f1 = e.finish()
+    F0, f = nt.estimate(ph[0], 27, 7, 1000)
+    out = tmp_path / "gap_k12.hist"
+    nt.write_hist(out, f1[0], F0, f, 1000)
+    assert out.read_bytes() == open(os.path.join(golden_dir, "ref_k12_g2__out_k12.hist"), "rb").read()
 
 
 def test_uint16_wraparound(nt):
