@@ -1,0 +1,448 @@
+// ntcard_cli.cpp — drop-in `ntcard` command line front end over the MI355X engine (C ABI).
+//
+// Mirrors the reference's process boundary B1: options and their validation
+// (ntcard.cpp:69-87,325-405), `@list` expansion (:415-425), the input-size rule (:427-431), one worker
+// per input FILE (:445-446), record splitting for FASTQ / FASTA / SAM incl. its quirks (:105-130,
+// 173-235), decompression by file extension through the same external tools the reference pipes
+// through (Common/Uncompress.cpp:32-53), and the two output formats (:277-315) plus the
+// "Runtime(sec)" line (:476).  Everything between "a sequence was parsed" and "the counters are
+// final" runs on the GPU through include/ntcard_hip.h; there is no CPU hashing path in this binary.
+#include <getopt.h>
+#include <sys/stat.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ntcard_hip.h"
+
+namespace {
+
+const char PROGRAM[] = "ntCard";
+
+void usage(std::ostream& os)
+{
+	os << "Usage: " << PROGRAM << " [OPTION]... FILE(S)...\n"
+	   << "Estimates the k-mer coverage histogram of FILE(S) on an AMD MI355X.\n\n"
+	   << "Input: fastq, fasta, sam (bam through samtools), plain or .gz/.bz2/.xz/.zip compressed.\n"
+	   << "A file of file names (one per line) can be given with an @ prefix.\n\n"
+	   << " Options:\n\n"
+	   << "  -t, --threads=N\tparser threads, one per input file at a time [1]\n"
+	   << "  -k, --kmer=N\tk-mer length, or a comma separated list of lengths\n"
+	   << "  -g, --gap=N\tlength of the gap in a gapped seed [0]; g mod 2 must equal k mod 2; single k only\n"
+	   << "  -c, --cov=N\tlargest coverage reported [1000]\n"
+	   << "  -p, --pref=STRING\tprefix of the per-k output files <STRING>_k<k>.hist\n"
+	   << "  -o, --output=STRING\tsingle tab separated output file (k, f, n)\n"
+	   << "      --help\tdisplay this help and exit\n"
+	   << "      --version\toutput version information and exit\n";
+}
+
+struct Options {
+	unsigned threads = 1;
+	unsigned gap = 0;
+	unsigned r_bits = 27; // ntcard.cpp:58
+	unsigned s_bits = 11; // ntcard.cpp:59
+	unsigned cov_max = 1000;
+	std::string prefix, output;
+	std::vector<unsigned> klist;
+};
+
+[[noreturn]] void die_engine()
+{
+	std::cerr << PROGRAM << ": " << ntc_last_error() << "\n";
+	std::exit(EXIT_FAILURE);
+}
+
+// ---- input: plain file or a pipe from the decompressor the reference would have used ----------
+bool ends_with(const std::string& s, const char* suf)
+{
+	const size_t n = std::strlen(suf);
+	return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+const char* unpack_command(const std::string& path) // Common/Uncompress.cpp:32-53 (same tools, same order)
+{
+	if (ends_with(path, ".ar")) return "ar -p";
+	if (ends_with(path, ".tar")) return "tar -xOf";
+	if (ends_with(path, ".tar.Z") || ends_with(path, ".tar.gz")) return "tar -zxOf";
+	if (ends_with(path, ".tar.bz2")) return "tar -jxOf";
+	if (ends_with(path, ".tar.xz")) return "tar --use-compress-program=xzdec -xOf";
+	if (ends_with(path, ".Z") || ends_with(path, ".gz")) return "gunzip -c";
+	if (ends_with(path, ".bz2")) return "bunzip2 -c";
+	if (ends_with(path, ".xz")) return "xzdec -c";
+	if (ends_with(path, ".zip")) return "unzip -p";
+	if (ends_with(path, ".bam")) return "samtools view -h";
+	return nullptr;
+}
+
+std::string shell_quote(const std::string& s)
+{
+	std::string q = "'";
+	for (char c : s) {
+		if (c == '\'')
+			q += "'\\''";
+		else
+			q += c;
+	}
+	return q + "'";
+}
+
+class LineReader { // std::getline semantics on a FILE*: false only when nothing could be extracted
+public:
+	explicit LineReader(const std::string& path)
+	{
+		struct stat st;
+		if (stat(path.c_str(), &st) != 0) return;
+		if (const char* cmd = unpack_command(path)) {
+			fp_ = popen((std::string(cmd) + " " + shell_quote(path)).c_str(), "r");
+			piped_ = true;
+		} else {
+			fp_ = std::fopen(path.c_str(), "rb");
+		}
+		if (fp_) buf_.resize(1 << 20);
+	}
+	~LineReader()
+	{
+		if (!fp_) return;
+		if (piped_) {
+			if (pclose(fp_) != 0) { // Common/SignalHandler.cpp:32-52: a failed decompressor is fatal
+				std::cerr << PROGRAM << ": the decompressor of an input file failed\n";
+				std::exit(EXIT_FAILURE);
+			}
+		} else {
+			std::fclose(fp_);
+		}
+	}
+	bool ok() const { return fp_ != nullptr; }
+	bool getline(std::string& out)
+	{
+		out.clear();
+		if (!fp_) return false;
+		bool any = false;
+		for (;;) {
+			if (pos_ == len_) {
+				len_ = std::fread(&buf_[0], 1, buf_.size(), fp_);
+				pos_ = 0;
+				if (len_ == 0) return any;
+			}
+			const char* b = &buf_[pos_];
+			const char* nl = static_cast<const char*>(std::memchr(b, '\n', len_ - pos_));
+			any = true;
+			if (nl) {
+				out.append(b, nl - b);
+				pos_ += (nl - b) + 1;
+				return true;
+			}
+			out.append(b, len_ - pos_);
+			pos_ = len_;
+		}
+	}
+
+private:
+	FILE* fp_ = nullptr;
+	bool piped_ = false;
+	std::string buf_;
+	size_t pos_ = 0, len_ = 0;
+};
+
+// ---- the seam: what replaces ntRead / stRead (ntcard.cpp:147-171) ---------------------------------
+class Batcher {
+public:
+	explicit Batcher(ntc_engine* e) : eng_(e) { offsets_.push_back(0); }
+	void add(const std::string& seq)
+	{
+		bases_ += seq;
+		offsets_.push_back(bases_.size());
+		if (bases_.size() >= (48u << 20)) flush();
+	}
+	void flush()
+	{
+		if (offsets_.size() > 1 && ntc_submit(eng_, bases_.data(), offsets_.data(), offsets_.size() - 1) != 0) die_engine();
+		bases_.clear();
+		offsets_.assign(1, 0);
+	}
+
+private:
+	ntc_engine* eng_;
+	std::string bases_;
+	std::vector<uint64_t> offsets_;
+};
+
+bool is_number(const std::string& s) // ntcard.cpp:96-103
+{
+	if (s.empty()) return false;
+	for (char c : s)
+		if (c < '0' || c > '9') return false;
+	return true;
+}
+
+// ntcard.cpp:105-130: classify by the first line; 0 fastq, 1 fasta, 2 sam, 3 unknown
+unsigned sniff(const std::string& first, bool& sam_has_header)
+{
+	const char c0 = first.empty() ? '\0' : first[0];
+	const char c1 = first.size() > 1 ? first[1] : '\0', c2 = first.size() > 2 ? first[2] : '\0';
+	if (c0 == '>') return 1;
+	if (c0 == '@') {
+		const bool tag = (c1 == 'H' && c2 == 'D') || (c1 == 'S' && c2 == 'Q') || (c1 == 'R' && c2 == 'G') ||
+		                 (c1 == 'P' && c2 == 'G') || (c1 == 'C' && c2 == 'O');
+		return tag ? 2 : 0;
+	}
+	std::istringstream fields(first);
+	std::string f[11];
+	for (auto& x : f)
+		fields >> x;
+	if (is_number(f[1]) && is_number(f[4])) {
+		sam_has_header = false;
+		return 2;
+	}
+	return 3;
+}
+
+void parse_fastq(LineReader& in, Batcher& out) // ntcard.cpp:173-189 (4-line records, header already consumed)
+{
+	std::string seq, skip;
+	for (bool good = true; good;) {
+		in.getline(seq);
+		in.getline(skip);
+		good = in.getline(skip);
+		if (good) out.add(seq);
+		good = in.getline(skip);
+	}
+}
+
+void parse_fasta(LineReader& in, Batcher& out) // ntcard.cpp:191-208 (multi-line records are concatenated)
+{
+	std::string line, seq;
+	for (bool good = true; good;) {
+		seq.clear();
+		good = in.getline(line);
+		while (good && (line.empty() || line[0] != '>')) {
+			seq += line;
+			good = in.getline(line);
+		}
+		out.add(seq);
+	}
+}
+
+void parse_sam(LineReader& in, Batcher& out, const std::string& first, bool has_header) // ntcard.cpp:210-235
+{
+	std::string line, seq, f;
+	if (has_header) {
+		while (in.getline(line))
+			if (line.empty() || line[0] != '@') break;
+	} else {
+		line = first;
+	}
+	do {
+		std::istringstream fields(line);
+		for (int i = 0; i < 9; ++i)
+			fields >> f;
+		fields >> seq >> f; // a short line leaves `seq` at its previous value, exactly like the reference
+		out.add(seq);
+	} while (in.getline(line));
+}
+
+void process_file(const std::string& path, ntc_engine* eng)
+{
+	LineReader in(path);
+	std::string first;
+	in.getline(first);
+	bool sam_has_header = true;
+	const unsigned type = sniff(first, sam_has_header);
+	Batcher batch(eng);
+	if (type == 0)
+		parse_fastq(in, batch);
+	else if (type == 1)
+		parse_fasta(in, batch);
+	else if (type == 2)
+		parse_sam(in, batch, first, sam_has_header);
+	else {
+		std::cerr << "Error in reading file: " << path << std::endl; // ntcard.cpp:459-462
+		std::exit(EXIT_FAILURE);
+	}
+	batch.flush();
+}
+
+template <typename T>
+bool parse_value(const char* text, T& out) // `arg >> value` followed by the reference's `!arg.eof()` check
+{
+	std::istringstream arg(text ? text : "");
+	arg >> out;
+	return arg.eof();
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+	const auto t_start = std::chrono::steady_clock::now();
+	static const char shortopts[] = "t:s:r:k:c:l:p:f:o:g:";
+	enum { OPT_HELP = 1, OPT_VERSION };
+	static const struct option longopts[] = { { "threads", required_argument, nullptr, 't' },
+		                                      { "kmer", required_argument, nullptr, 'k' },
+		                                      { "gap", required_argument, nullptr, 'g' },
+		                                      { "cov", required_argument, nullptr, 'c' },
+		                                      { "rbit", required_argument, nullptr, 'r' },
+		                                      { "sbit", required_argument, nullptr, 's' },
+		                                      { "output", required_argument, nullptr, 'o' },
+		                                      { "pref", required_argument, nullptr, 'p' },
+		                                      { "help", no_argument, nullptr, OPT_HELP },
+		                                      { "version", no_argument, nullptr, OPT_VERSION },
+		                                      { nullptr, 0, nullptr, 0 } };
+	Options opt;
+	bool die = false;
+	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, nullptr)) != -1;) {
+		bool clean = true;
+		switch (c) {
+		case '?': die = true; break;
+		case 't': clean = parse_value(optarg, opt.threads); break;
+		case 's': clean = parse_value(optarg, opt.s_bits); break;
+		case 'r': clean = parse_value(optarg, opt.r_bits); break;
+		case 'c':
+			clean = parse_value(optarg, opt.cov_max);
+			if (opt.cov_max > 65535) opt.cov_max = 65535;
+			break;
+		case 'p': clean = parse_value(optarg, opt.prefix); break;
+		case 'o': clean = parse_value(optarg, opt.output); break;
+		case 'g': clean = parse_value(optarg, opt.gap); break;
+		case 'k': {
+			std::istringstream arg(optarg ? optarg : "");
+			std::string token;
+			while (std::getline(arg, token, ',')) {
+				unsigned k = 0;
+				std::stringstream ss(token);
+				ss >> k;
+				opt.klist.push_back(k);
+			}
+			break;
+		}
+		case OPT_HELP: usage(std::cerr); return EXIT_SUCCESS;
+		case OPT_VERSION:
+			std::cerr << PROGRAM << " 1.2.2 \nMI355X (gfx950) engine, C ABI version " << ntc_abi_version()
+			          << "; command line compatible with bcgsc/ntCard 1.2.2\n";
+			return EXIT_SUCCESS;
+		default: clean = false; break; // -l / -f: accepted by getopt, never handled (ntcard.cpp:69,372-375)
+		}
+		if (optarg != nullptr && !clean) {
+			std::cerr << PROGRAM << ": invalid option: `-" << (char)c << optarg << "'\n";
+			return EXIT_FAILURE;
+		}
+	}
+	if (argc - optind < 1) {
+		std::cerr << PROGRAM << ": missing arguments\n";
+		die = true;
+	}
+	if (opt.gap != 0 && !opt.klist.empty() && opt.gap % 2 != opt.klist[0] % 2) {
+		std::cerr << PROGRAM << "Gap size and kmer must have the same modulus\n";
+		die = true;
+	}
+	if (opt.klist.empty()) {
+		std::cerr << PROGRAM << ": missing argument -k ... \n";
+		die = true;
+	}
+	if (opt.prefix.empty() && opt.output.empty()) {
+		std::cerr << PROGRAM << ": missing argument -p/-o ... \n";
+		die = true;
+	}
+	if (opt.gap != 0 && opt.klist.size() != 1) {
+		std::cerr << PROGRAM << ": -g does not support multiple k currently.\n";
+		die = true;
+	}
+	if (die) {
+		std::cerr << "Try `" << PROGRAM << " --help' for more information.\n";
+		return EXIT_FAILURE;
+	}
+
+	std::vector<std::string> files;
+	for (int i = optind; i < argc; ++i) {
+		std::string f(argv[i]);
+		if (!f.empty() && f[0] == '@') {
+			LineReader list(f.substr(1));
+			std::string name;
+			while (list.getline(name))
+				files.push_back(name);
+		} else {
+			files.push_back(f);
+		}
+	}
+
+	// ntcard.cpp:427-431: on-disk size of all inputs decides the sampling rate
+	uint64_t total = 0;
+	for (const auto& f : files) {
+		struct stat st;
+		total += stat(f.c_str(), &st) == 0 ? (uint64_t)st.st_size : (uint64_t)-1; // tellg() == -1 on a missing file
+	}
+	if (total < 50000000000ULL) opt.s_bits = 7;
+
+	ntc_config cfg;
+	std::memset(&cfg, 0, sizeof cfg);
+	cfg.n_k = (uint32_t)opt.klist.size();
+	cfg.k = opt.klist.data();
+	cfg.gap = opt.gap;
+	cfg.r_bits = opt.r_bits;
+	cfg.s_bits = opt.s_bits;
+	cfg.device = 0;
+	if (const char* dev = std::getenv("NTCARD_DEVICE")) cfg.device = std::atoi(dev);
+	ntc_engine* eng = nullptr;
+	if (ntc_create(&cfg, &eng) != 0) die_engine();
+
+	// ntcard.cpp:445-446: `#pragma omp parallel for schedule(dynamic)` over the files
+	std::atomic<size_t> next(0);
+	auto worker = [&]() {
+		for (size_t i; (i = next.fetch_add(1)) < files.size();)
+			process_file(files[i], eng);
+	};
+	std::vector<std::thread> pool;
+	const unsigned n_threads = opt.threads == 0 ? 1 : opt.threads;
+	for (unsigned t = 1; t < n_threads && t < files.size(); ++t)
+		pool.emplace_back(worker);
+	worker();
+	for (auto& th : pool)
+		th.join();
+
+	const size_t nk = opt.klist.size();
+	std::vector<uint32_t> p(nk * 2 * 65536);
+	std::vector<uint64_t> f1(nk);
+	if (ntc_finish(eng, nullptr, p.data(), f1.data()) != 0) die_engine();
+	std::vector<double> f(opt.cov_max + 1);
+	if (opt.output.empty()) { // outDefault, ntcard.cpp:277-298
+		for (size_t ki = 0; ki < nk; ++ki) {
+			double F0 = 0;
+			if (ntc_estimate(&p[ki * 2 * 65536], opt.r_bits, opt.s_bits, opt.cov_max, &F0, f.data()) != 0) die_engine();
+			std::ostringstream name;
+			name << opt.prefix << "_k" << opt.klist[ki] << ".hist";
+			if (ntc_write_hist(name.str().c_str(), f1[ki], F0, f.data(), opt.cov_max) != 0) {
+				std::cerr << PROGRAM << ": cannot write " << name.str() << "\n";
+				return EXIT_FAILURE;
+			}
+		}
+	} else { // outCompact, ntcard.cpp:300-315
+		FILE* out = std::fopen(opt.output.c_str(), "w");
+		if (!out) {
+			std::cerr << PROGRAM << ": cannot write " << opt.output << "\n";
+			return EXIT_FAILURE;
+		}
+		std::fprintf(out, "k\tf\tn\n");
+		for (size_t ki = 0; ki < nk; ++ki) {
+			double F0 = 0;
+			if (ntc_estimate(&p[ki * 2 * 65536], opt.r_bits, opt.s_bits, opt.cov_max, &F0, f.data()) != 0) die_engine();
+			std::cerr << "k=" << opt.klist[ki] << "\tF1\t" << f1[ki] << "\n";
+			std::cerr << "k=" << opt.klist[ki] << "\tF0\t" << (uint64_t)F0 << "\n";
+			for (unsigned i = 1; i <= opt.cov_max; ++i)
+				std::fprintf(out, "%u\t%u\t%llu\n", opt.klist[ki], i, (unsigned long long)(uint64_t)f[i]);
+		}
+		std::fclose(out);
+	}
+	ntc_destroy(eng);
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+	std::cerr << "Runtime(sec): " << std::setprecision(4) << std::fixed << secs << "\n";
+	return 0;
+}

@@ -1,0 +1,106 @@
+"""The drop-in `ntcard` front end (ntcard_amd/bin/ntcard): option handling on CPU, and — on the
+GPU box — byte-for-byte reproduction of the reference CLI's own outputs (tests/golden/ref_*), for
+every input rendering the reference's `make check` exercises (Makefile.am:47-83: DNA FASTQ .gz,
+RNA, FASTA, each with and without -g 2) plus SAM, multi-k, -c, -o, -r and @list/-t."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "ntcard_amd", "bin", "ntcard")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run(args, cwd=None):
+    return subprocess.run([BIN] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+
+
+def test_help_and_version_exit_zero():
+    for flag, word in (("--help", b"Usage: ntCard"), ("--version", b"ntCard 1.2.2")):
+        r = run([flag])
+        assert r.returncode == 0 and word in r.stderr  # the reference prints both on stderr (ntcard.cpp:365-370)
+
+
+def test_argument_errors_match_reference():
+    r = run(["-k", "12"])
+    assert r.returncode == 1
+    assert b"ntCard: missing arguments\n" in r.stderr and b"ntCard: missing argument -p/-o ... \n" in r.stderr
+    assert r.stderr.endswith(b"Try `ntCard --help' for more information.\n")
+    r = run(["-p", "x", "reads.fq"])
+    assert r.returncode == 1 and b"ntCard: missing argument -k ... \n" in r.stderr
+    r = run(["-k", "12", "-g", "3", "-p", "x", "reads.fq"])
+    assert r.returncode == 1 and b"Gap size and kmer must have the same modulus" in r.stderr
+    r = run(["-k", "12,14", "-g", "2", "-p", "x", "reads.fq"])
+    assert r.returncode == 1 and b"-g does not support multiple k currently." in r.stderr
+    r = run(["-k", "12", "-c", "10x", "-p", "x", "reads.fq"])
+    assert r.returncode == 1 and b"ntCard: invalid option: `-c10x'" in r.stderr
+    r = run(["-k", "12", "-l", "5", "-p", "x", "reads.fq"])  # -l/-f: in the option string, never handled
+    assert r.returncode == 1 and b"invalid option: `-l5'" in r.stderr
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    gz = os.path.join(GOLD, "reads_small.fq.gz")
+    with gzip.open(gz, "rb") as f:
+        fq = f.read()
+    lines = fq.split(b"\n")
+    names = [lines[i][1:] for i in range(0, len(lines) - 1, 4)]
+    seqs = [lines[i] for i in range(1, len(lines) - 1, 4)]
+    (d / "reads.fq.gz").write_bytes(open(gz, "rb").read())
+    (d / "reads.fq").write_bytes(fq)
+    (d / "rna.fq").write_bytes(b"".join(b"@%s\n%s\n+\n%s\n" % (n, s.replace(b"T", b"U"), b"I" * len(s)) for n, s in zip(names, seqs)))
+    # multi-line FASTA: sequences wrapped at 40 columns (k-mers span the line breaks, ntcard.cpp:198-201)
+    (d / "reads.fa").write_bytes(b"".join(b">%s\n%s\n%s\n" % (n, s[:40], s[40:]) for n, s in zip(names, seqs)))
+    (d / "reads.sam").write_bytes(b"@HD\tVN:1.0\n@SQ\tSN:chr1\tLN:40000\n" + b"".join(
+        b"%s\t0\tchr1\t1\t60\t70M\t*\t0\t0\t%s\t%s\n" % (n, s, b"I" * len(s)) for n, s in zip(names, seqs)))
+    (d / "nohdr.sam").write_bytes(b"".join(
+        b"%s\t0\tchr1\t1\t60\t70M\t*\t0\t0\t%s\t%s\n" % (n, s, b"I" * len(s)) for n, s in zip(names, seqs)))
+    half = len(seqs) // 2
+    for tag, sl in (("a", slice(0, half)), ("b", slice(half, None))):
+        (d / f"part_{tag}.fq").write_bytes(b"".join(b"@%s\n%s\n+\n%s\n" % (n, s, b"I" * len(s)) for n, s in zip(names[sl], seqs[sl])))
+    (d / "parts.txt").write_text("part_a.fq\npart_b.fq\n")
+    return d
+
+
+def gold(name):
+    return open(os.path.join(GOLD, name), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src", ["reads.fq.gz", "reads.fq", "rna.fq", "reads.fa", "reads.sam", "nohdr.sam"])
+def test_every_input_rendering_gives_the_reference_hist(inputs, src):
+    r = run(["-k", "12", "-p", "out_" + src.replace(".", "_"), src], cwd=inputs)
+    assert r.returncode == 0, r.stderr
+    assert b"Runtime(sec): " in r.stderr
+    assert (inputs / ("out_" + src.replace(".", "_") + "_k12.hist")).read_bytes() == gold("ref_k12__out_k12.hist")
+    r = run(["-k", "12", "-g", "2", "-p", "gap_" + src.replace(".", "_"), src], cwd=inputs)
+    assert r.returncode == 0, r.stderr
+    assert (inputs / ("gap_" + src.replace(".", "_") + "_k12.hist")).read_bytes() == gold("ref_k12_g2__out_k12.hist")
+
+
+@pytest.mark.gpu
+def test_multi_k_cov_rbits_compact_and_lists(inputs):
+    r = run(["-k", "16,24,32,48", "-p", "m", "reads.fq"], cwd=inputs)
+    assert r.returncode == 0, r.stderr
+    for k in (16, 24, 32, 48):
+        assert (inputs / f"m_k{k}.hist").read_bytes() == gold(f"ref_multi__out_k{k}.hist")
+    r = run(["-k", "20", "-c", "50", "-p", "c", "reads.fq"], cwd=inputs)
+    assert r.returncode == 0 and (inputs / "c_k20.hist").read_bytes() == gold("ref_k20_c50__out_k20.hist")
+    r = run(["-k", "24", "-r", "22", "-p", "r", "reads.fq"], cwd=inputs)
+    assert r.returncode == 0 and (inputs / "r_k24.hist").read_bytes() == gold("ref_k24_s11_r22__out_k24.hist")
+    r = run(["-k", "12,20", "-c", "20", "-o", "compact.tsv", "reads.fq"], cwd=inputs)
+    assert r.returncode == 0 and (inputs / "compact.tsv").read_bytes() == gold("ref_compact__k12_20_c20.tsv")
+    assert b"k=12\tF1\t" in r.stderr and b"k=20\tF0\t" in r.stderr
+    # @list + two parser threads feeding one engine (ntcard.cpp:415-425,445-446)
+    r = run(["-t", "2", "-k", "32", "-p", "l", "@parts.txt"], cwd=inputs)
+    assert r.returncode == 0, r.stderr
+    assert (inputs / "l_k32.hist").read_bytes() == gold("ref_k32__out_k32.hist")
+
+
+@pytest.mark.gpu
+def test_unreadable_input_fails_like_the_reference(inputs):
+    r = run(["-k", "12", "-p", "x", "does_not_exist.fq"], cwd=inputs)
+    assert r.returncode == 1 and b"Error in reading file: does_not_exist.fq" in r.stderr
