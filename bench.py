@@ -174,7 +174,7 @@ def main():
                        "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sketch_fast_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                         "kernel": "sketch_hf_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_launch_kmers},
             "f1_total": total_kmers,

@@ -402,13 +402,14 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 			const uint32_t base = act ? src_lane * stride + q + 1u - k : 0u; // byte offset of the window in wdata
 			const uint32_t sh = base & 3u;
 			const uint32_t* dp = reinterpret_cast<const uint32_t*>(wdata + (base & ~3u));
-			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0, dirty = 0;
 			uint32_t cur = dp[0];
 			const unsigned char* tp = t1;
 			for (uint32_t i = 0; i < k; i += 4) {
 				const uint32_t nxt = dp[(i >> 2) + 1];
 				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes (code<<6) of window positions i..i+3
 				cur = nxt;
+				dirty |= i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k)))); // bit 0 of a byte: not ACGTU
 				// pair offsets (a<<6 | b<<4): bytes 0,1 and bytes 2,3; a base beyond k contributes nothing
 				// because the odd-k table drops the b term and positions >= k are never looked up
 				const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 				}
 				tp += 512;
 			}
-			if (act) {
+			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
 				const uint32_t hi = rev ? rhi : fhi;
 				const uint32_t lo = rev ? rlo : flo;
