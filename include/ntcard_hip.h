@@ -122,6 +122,17 @@ int ntc_estimate(const uint32_t *p_hist /* [2][65536] */, uint32_t r_bits, uint3
  * given verbatim.  Returns 0 or NTC_ERR_ARG if the file cannot be written.                      */
 int ntc_write_hist(const char *path, uint64_t f1, double F0, const double *f, uint32_t cov_max);
 
+/* ---- nthll: HyperLogLog-style F0 of the same canonical ntHash stream --------------
+ * Replaces nthll.cpp's per-thread `uint8_t mVec[nBuck]`, its ntRead/ntComp (nthll.cpp:92-105: bucket = low
+ * n_bits of the hash, value = leading zeros of the remaining bits, keep the max), the max-merge under
+ * `omp critical` (nthll.cpp:238-243) and the estimate (nthll.cpp:247-254).  Reads are fed with
+ * ntc_submit / ntc_submit_device exactly as for an ntcard engine.                                          */
+int ntc_hll_create(uint32_t k, uint32_t n_bits /* nthll -b, default 16 */, int32_t device, void *stream,
+                   ntc_engine **out);
+/* regs_out: HOST uint8_t [1<<n_bits] (== tVec of nthll.cpp:212-243); f1_out: number of k-mers hashed, or NULL */
+int ntc_hll_finish(ntc_engine *e, uint8_t *regs_out, uint64_t *f1_out);
+int ntc_hll_estimate(const uint8_t *regs, uint32_t n_bits, double *est_out);
+
 /* Timing of the hot kernel as measured with HIP events on the engine's stream (for bench.py's
  * roofline leg): accumulated milliseconds and launch count since create/reset.                  */
 int ntc_kernel_time(ntc_engine *e, double *ms_total, uint64_t *launches);

@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
     "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
-    "ntc_kernel_time", "ntc_set_profiling",
+    "ntc_kernel_time", "ntc_set_profiling", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
 ]
 
 
@@ -70,6 +70,9 @@ def lib():
     L.ntc_write_hist.argtypes = [C.c_char_p, u64, C.c_double, p, u32]
     L.ntc_kernel_time.argtypes = [p, C.POINTER(C.c_double), C.POINTER(u64)]
     L.ntc_set_profiling.argtypes = [p, C.c_int]
+    L.ntc_hll_create.argtypes = [u32, u32, i32, p, C.POINTER(p)]
+    L.ntc_hll_finish.argtypes = [p, p, p]
+    L.ntc_hll_estimate.argtypes = [p, u32, C.POINTER(C.c_double)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_destroy"):

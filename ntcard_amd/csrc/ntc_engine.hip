@@ -105,6 +105,9 @@ struct ntc_engine {
 	void* d_queue = nullptr;     // fast kernel: per-wave hit queues
 	size_t queue_cap = 0;
 	int kernel_kind = 2;         // KIND_HF unless NTC_FLAG_SIMPLE_KERNEL / NTC_FLAG_FAST_KERNEL
+	uint32_t hll_bits = 0;       // != 0: nthll engine (d_sketch holds uint32 M[1<<hll_bits])
+	uint32_t* d_hll_thr = nullptr;
+	uint64_t hll_reads_seen = 0;
 	void* d_gapt = nullptr;      // spaced seed: filter table of the don't-care positions
 	std::vector<void*> d_t1;     // per k: closed-form table of the H-filter kernel's resolve stage
 	// host-submit staging (grow-only)
@@ -164,6 +167,40 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of hit queues on device", need);
 			e->queue_cap = need;
 		}
+	}
+	if (e->hll_bits) {
+		// nthll: refresh the "can still matter" threshold between sub-batches that double in size, so the
+		// expensive resolve stage only sees a vanishing fraction of the k-mers once the registers warm up
+		uint64_t done = 0;
+		while (done < n_slots) {
+			uint64_t n = std::max<uint64_t>(16384, e->hll_reads_seen);
+			n = std::min<uint64_t>((n + 1) & ~1ull, n_slots - done); // even: keeps 16-byte alignment of uniform slots
+			HIP_TRY(ntc::launch_hll_threshold(e->d_sketch, 1u << e->hll_bits, e->d_hll_thr, e->stream));
+			ntc::HashArgs a;
+			std::memset(&a, 0, sizeof a);
+			a.slots = d_slots + done * stride;
+			a.meta = d_meta ? d_meta + done : nullptr;
+			a.n_slots = n;
+			a.stride = stride;
+			a.read_len = read_len;
+			a.k = e->klist[0];
+			a.r_bits = 27;
+			a.s_bits = 7;
+			a.sketch = e->d_sketch;
+			a.f1 = e->d_f1;
+			a.t1 = e->d_t1[0];
+			a.hll_bits = e->hll_bits;
+			a.hll_thr = e->d_hll_thr;
+			ntc::build_tables(a.k, a.tab);
+			ntc::poly_a_state(a.k, a.init);
+			unsigned g2 = 0;
+			size_t sm2 = 0;
+			if (int rc = hash_grid(e->device, n, stride, KIND_HF, a.k, g2, sm2)) return rc;
+			HIP_TRY(ntc::launch_sketch_hf(a, g2, sm2, e->stream));
+			done += n;
+			e->hll_reads_seen += n;
+		}
+		return 0;
 	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		ntc::HashArgs a;
@@ -314,6 +351,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_queue) (void)hipFree(e->d_queue);
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
+	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);
 	if (e->d_stage) (void)hipFree(e->d_stage);
 	if (e->d_meta) (void)hipFree(e->d_meta);
 	if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -326,7 +364,8 @@ int ntc_reset(ntc_engine* e)
 	if (!e) return fail(NTC_ERR_ARG, "ntc_reset: null engine");
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
+	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->hll_bits ? (sizeof(uint32_t) << e->hll_bits) : e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
+	e->hll_reads_seen = 0;
 	HIP_TRY(hipMemsetAsync(e->d_f1, 0, e->klist.size() * 8, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (int rc = drain_events(e)) return rc;
@@ -474,6 +513,7 @@ int ntc_sync(ntc_engine* e)
 int ntc_finish(ntc_engine* e, uint16_t* t_counter_out, uint32_t* p_hist_out, uint64_t* f1_out)
 {
 	if (!e) return fail(NTC_ERR_ARG, "ntc_finish: null engine");
+	if (e->hll_bits) return fail(NTC_ERR_STATE, "ntc_finish: this is an nthll engine, use ntc_hll_finish");
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
 	const size_t nk = e->klist.size();
@@ -550,6 +590,62 @@ int ntc_gen_reads_device(int32_t device, void* stream, void* d_slots, uint64_t s
 	HIP_TRY(ntc::launch_gen((unsigned char*)d_slots, seed, first_read, n_reads, read_len, stride, dist, genome_len,
 	                        (hipStream_t)stream));
 	return 0;
+}
+
+int ntc_hll_create(uint32_t k, uint32_t n_bits, int32_t device, void* stream, ntc_engine** out)
+{
+	if (!out) return fail(NTC_ERR_ARG, "ntc_hll_create: null argument");
+	*out = nullptr;
+	if (k < 1 || k > kMaxK) return fail(NTC_ERR_ARG, "ntc_hll_create: k=%u outside 1..%u", k, kMaxK);
+	if (n_bits < 4 || n_bits > 24) return fail(NTC_ERR_ARG, "ntc_hll_create: n_bits %u outside 4..24", n_bits);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+		return fail(NTC_ERR_DEVICE, "ntc_hll_create: no HIP device available (this library has no CPU fallback)");
+	if (device < 0 || device >= ndev) return fail(NTC_ERR_ARG, "ntc_hll_create: device %d of %d", device, ndev);
+	HIP_TRY(hipSetDevice(device));
+	ntc_engine* e = new (std::nothrow) ntc_engine();
+	if (!e) return fail(NTC_ERR_MEMORY, "ntc_hll_create: out of host memory");
+	e->device = device;
+	e->stream = (hipStream_t)stream;
+	e->klist.assign(1, k);
+	e->r_bits = 27;
+	e->s_bits = 7;
+	e->hll_bits = n_bits;
+	e->kernel_kind = KIND_HF;
+	std::vector<uint32_t> t1((size_t)ntc::t2_pairs(k) * 64);
+	ntc::build_t2(k, t1.data());
+	void* d = nullptr;
+	if (hipMalloc((void**)&e->d_sketch, sizeof(uint32_t) << n_bits) != hipSuccess ||
+	    hipMalloc((void**)&e->d_f1, 8) != hipSuccess || hipMalloc((void**)&e->d_hll_thr, 4) != hipSuccess ||
+	    hipMalloc(&d, t1.size() * 4) != hipSuccess ||
+	    hipMemcpy(d, t1.data(), t1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+		ntc_destroy(e);
+		return fail(NTC_ERR_MEMORY, "ntc_hll_create: device allocation failed");
+	}
+	e->own_sketch = e->own_f1 = true;
+	e->d_t1.push_back(d);
+	int rc = ntc_reset(e);
+	if (rc) {
+		ntc_destroy(e);
+		return rc;
+	}
+	*out = e;
+	return 0;
+}
+
+int ntc_hll_finish(ntc_engine* e, uint8_t* regs_out, uint64_t* f1_out)
+{
+	if (!e || !e->hll_bits) return fail(NTC_ERR_STATE, "ntc_hll_finish: not an nthll engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	std::vector<uint32_t> regs((size_t)1 << e->hll_bits);
+	HIP_TRY(hipMemcpyAsync(regs.data(), e->d_sketch, regs.size() * 4, hipMemcpyDeviceToHost, e->stream));
+	if (f1_out) HIP_TRY(hipMemcpyAsync(f1_out, e->d_f1, 8, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (regs_out)
+		for (size_t i = 0; i < regs.size(); ++i)
+			regs_out[i] = (uint8_t)regs[i];
+	return drain_events(e);
 }
 
 int ntc_kernel_time(ntc_engine* e, double* ms_total, uint64_t* launches)

@@ -50,6 +50,21 @@ int ntc_estimate(const uint32_t* p_hist, uint32_t r_bits, uint32_t s_bits, uint3
 	return 0;
 }
 
+// nthll.cpp:247-254: alpha * m^2 / sum_j 2^-M[j], alpha halved because the hashes are canonical
+int ntc_hll_estimate(const uint8_t* regs, uint32_t n_bits, double* est_out)
+{
+	if (!regs || !est_out || n_bits > 31) return NTC_ERR_ARG;
+	const unsigned n_buck = 1u << n_bits;
+	double alpha = 1.4426 / (1 + 1.079 / n_buck);
+	alpha /= 2;
+	double p_est = 0.0;
+	for (unsigned j = 0; j < n_buck; ++j)
+		p_est += 1.0 / ((uint64_t)1 << regs[j]);
+	const double z_est = 1.0 / p_est;
+	*est_out = alpha * n_buck * n_buck * z_est;
+	return 0;
+}
+
 int ntc_write_hist(const char* path, uint64_t f1, double F0, const double* f, uint32_t cov_max)
 {
 	if (!path || !f) return NTC_ERR_ARG;

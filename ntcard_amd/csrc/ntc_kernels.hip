@@ -361,6 +361,34 @@ __global__ __launch_bounds__(256) void gen_reads_kernel(unsigned char* __restric
 	}
 }
 
+// nthll: the next batch only needs to look at hashes that can still raise SOME register: run0 > min_j M[j].
+// thr = 2^(32 - (min+1)) on the top 32 bits (hash < thr<<32  <=>  at least min+1 leading zeros).
+__global__ __launch_bounds__(1024) void hll_threshold_kernel(const uint32_t* __restrict__ regs, uint32_t n_regs, uint32_t* thr)
+{
+	__shared__ uint32_t smin[16];
+	uint32_t m = 0xffffffffu;
+	for (uint32_t i = threadIdx.x; i < n_regs; i += blockDim.x)
+		m = regs[i] < m ? regs[i] : m;
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t other = __shfl_xor(m, o);
+		m = other < m ? other : m;
+	}
+	if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (unsigned w = 1; w < blockDim.x / 64; ++w)
+			m = smin[w] < m ? smin[w] : m;
+		const uint32_t need = m + 1u; // leading zeros a hash must have to matter
+		*thr = need >= 31u ? 2u : (1u << (32u - need)); // clamp: always safe to look at MORE hashes
+	}
+}
+
+hipError_t launch_hll_threshold(const uint32_t* regs, uint32_t n_regs, uint32_t* thr, hipStream_t st)
+{
+	hipLaunchKernelGGL(hll_threshold_kernel, dim3(1), dim3(1024), 0, st, regs, n_regs, thr);
+	return hipGetLastError();
+}
+
 // ---- host-side launch helpers (called from ntc_engine.hip) -----------------------------------------
 hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st)
 {

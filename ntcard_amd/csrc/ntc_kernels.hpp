@@ -29,6 +29,8 @@ struct HashArgs {
 	const void* t1;             // H-filter kernel: [ceil(k/2)][16] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seed pairs (device)
 	const void* gapt;           // H-filter kernel, spaced seed: [ceil(gap/2)][16] x {f.Hd, r.Hd, 0, 0} terms to XOR out
 	uint32_t gap, gap_first;    // number of don't-care positions and index of the first one (ntcard.cpp:407-413)
+	uint32_t hll_bits;          // != 0: nthll mode — `sketch` is uint32 M[1<<hll_bits] (max leading-zero runs, nthll.cpp:92-97)
+	const uint32_t* hll_thr;    // nthll mode: device word, only hashes whose top 32 bits are < *hll_thr can raise a register
 	uint32_t init[6];           // fast kernel: strand registers of the k x 'A' window {flo,fB,fHd,rlo,rB,rHd}
 	HashTables tab;
 };
@@ -39,6 +41,7 @@ hipError_t launch_sketch_fast(const HashArgs& a, unsigned grid, size_t smem, hip
 hipError_t set_sketch_fast_smem_limit(size_t smem);
 hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_sketch_hf_smem_limit(size_t smem);
+hipError_t launch_hll_threshold(const uint32_t* regs, uint32_t n_regs, uint32_t* thr, hipStream_t st);
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
                            uint16_t* out16, hipStream_t st);
 hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,

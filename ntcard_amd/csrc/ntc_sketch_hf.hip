@@ -132,6 +132,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	int32_t lo1 = (int32_t)(((1u << (a.s_bits - 1)) - 1u) << (32 - a.s_bits));
 	asm volatile("" : "+v"(lo0), "+v"(lo1));
 	const uint32_t s_bits = a.s_bits;
+	uint32_t hll_thr = a.hll_bits ? *a.hll_thr : 0u;
+	asm volatile("" : "+v"(hll_thr));
 	const uint32_t rmask = (1u << a.r_bits) - 1u;
 	const uint32_t rbuck = 1u << a.r_bits;
 
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 		const int32_t qs = e0 << 2; // first step that is recorded
 		uint32_t f1_lane = 0;       // DIRTY / RAGGED: clean windows of this lane (accumulated on the rare path)
 
-		auto walk = [&](auto wc, auto gapped) {
+		auto walk = [&](auto wc, auto gapped, auto hll) {
 			// a dirty byte at step q closes the current run of clean windows [nextok, q) and reopens at q+k
 			auto on_mark = [&](int32_t q) {
 				if (nextok != 0x7fffffff) {
@@ -319,7 +321,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 						}
 					}
 					const uint32_t mn = fs < rs ? fs : rs; // top bits of min(fh,rh) (of the spaced-seed values when gapped)
-					m = ballot((mn ^ lo0) < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64
+					if (hll.value)
+						m = ballot(mn < hll_thr); // nthll: only a hash with enough leading zeros can raise a register
+					else
+						m = ballot((mn ^ lo0) < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64
 					if (wc.value != CLEAN) m &= ballot(nextok <= q);
 				}
 				push(m);
@@ -383,14 +388,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 #if NTC_EXP_STAGE_ONLY
 		if (mine[lane] == 0x7f && a.k == 9999) // A/B experiment: staging only (never true)
 #endif
-		if (a.gap != 0)
-			walk(std::integral_constant<int, RAGGED>{}, std::true_type{}); // one (general) class keeps the gapped code small
+		if (a.hll_bits != 0)
+			walk(std::integral_constant<int, RAGGED>{}, std::false_type{}, std::true_type{});
+		else if (a.gap != 0)
+			walk(std::integral_constant<int, RAGGED>{}, std::true_type{}, std::false_type{}); // one (general) class keeps the gapped code small
 		else if (wclass == CLEAN)
-			walk(std::integral_constant<int, CLEAN>{}, std::false_type{});
+			walk(std::integral_constant<int, CLEAN>{}, std::false_type{}, std::false_type{});
 		else if (wclass == DIRTY)
-			walk(std::integral_constant<int, DIRTY>{}, std::false_type{});
+			walk(std::integral_constant<int, DIRTY>{}, std::false_type{}, std::false_type{});
 		else
-			walk(std::integral_constant<int, RAGGED>{}, std::false_type{});
+			walk(std::integral_constant<int, RAGGED>{}, std::false_type{}, std::false_type{});
 
 		// ---- resolve: compact (lane, step) pairs, 64 at a time recompute the full hashes ----
 		__builtin_amdgcn_wave_barrier();
@@ -433,6 +440,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
 				const uint32_t hi = rev ? rhi : fhi;
 				const uint32_t lo = rev ? rlo : flo;
+				if (a.hll_bits != 0) {
+					// nthll's ntComp (nthll.cpp:92-97): bucket = low bits, value = leading zeros of the rest
+					const uint32_t bmask = (1u << a.hll_bits) - 1u;
+					const uint32_t lo_rest = lo & ~bmask;
+					if ((hi | lo_rest) != 0u) {
+						const uint32_t run0 = hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo_rest);
+						atomicMax(a.sketch + (lo & bmask), run0);
+					}
+					return;
+				}
 				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
 				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
 				const bool c0 = (hi >> (31 - s_bits)) == 1u;

@@ -22,11 +22,14 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/ntcard_hip.h"
+#include "cli_common.hpp"
+
+const char* const cli::kProgram = "ntCard";
 
 namespace {
 
-const char PROGRAM[] = "ntCard";
+using namespace cli;
+const char* const PROGRAM = cli::kProgram;
 
 void usage(std::ostream& os)
 {
@@ -55,201 +58,6 @@ struct Options {
 	std::vector<unsigned> klist;
 };
 
-[[noreturn]] void die_engine()
-{
-	std::cerr << PROGRAM << ": " << ntc_last_error() << "\n";
-	std::exit(EXIT_FAILURE);
-}
-
-// ---- input: plain file or a pipe from the decompressor the reference would have used ----------
-bool ends_with(const std::string& s, const char* suf)
-{
-	const size_t n = std::strlen(suf);
-	return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
-}
-
-const char* unpack_command(const std::string& path) // Common/Uncompress.cpp:32-53 (same tools, same order)
-{
-	if (ends_with(path, ".ar")) return "ar -p";
-	if (ends_with(path, ".tar")) return "tar -xOf";
-	if (ends_with(path, ".tar.Z") || ends_with(path, ".tar.gz")) return "tar -zxOf";
-	if (ends_with(path, ".tar.bz2")) return "tar -jxOf";
-	if (ends_with(path, ".tar.xz")) return "tar --use-compress-program=xzdec -xOf";
-	if (ends_with(path, ".Z") || ends_with(path, ".gz")) return "gunzip -c";
-	if (ends_with(path, ".bz2")) return "bunzip2 -c";
-	if (ends_with(path, ".xz")) return "xzdec -c";
-	if (ends_with(path, ".zip")) return "unzip -p";
-	if (ends_with(path, ".bam")) return "samtools view -h";
-	return nullptr;
-}
-
-std::string shell_quote(const std::string& s)
-{
-	std::string q = "'";
-	for (char c : s) {
-		if (c == '\'')
-			q += "'\\''";
-		else
-			q += c;
-	}
-	return q + "'";
-}
-
-class LineReader { // std::getline semantics on a FILE*: false only when nothing could be extracted
-public:
-	explicit LineReader(const std::string& path)
-	{
-		struct stat st;
-		if (stat(path.c_str(), &st) != 0) return;
-		if (const char* cmd = unpack_command(path)) {
-			fp_ = popen((std::string(cmd) + " " + shell_quote(path)).c_str(), "r");
-			piped_ = true;
-		} else {
-			fp_ = std::fopen(path.c_str(), "rb");
-		}
-		if (fp_) buf_.resize(1 << 20);
-	}
-	~LineReader()
-	{
-		if (!fp_) return;
-		if (piped_) {
-			if (pclose(fp_) != 0) { // Common/SignalHandler.cpp:32-52: a failed decompressor is fatal
-				std::cerr << PROGRAM << ": the decompressor of an input file failed\n";
-				std::exit(EXIT_FAILURE);
-			}
-		} else {
-			std::fclose(fp_);
-		}
-	}
-	bool ok() const { return fp_ != nullptr; }
-	bool getline(std::string& out)
-	{
-		out.clear();
-		if (!fp_) return false;
-		bool any = false;
-		for (;;) {
-			if (pos_ == len_) {
-				len_ = std::fread(&buf_[0], 1, buf_.size(), fp_);
-				pos_ = 0;
-				if (len_ == 0) return any;
-			}
-			const char* b = &buf_[pos_];
-			const char* nl = static_cast<const char*>(std::memchr(b, '\n', len_ - pos_));
-			any = true;
-			if (nl) {
-				out.append(b, nl - b);
-				pos_ += (nl - b) + 1;
-				return true;
-			}
-			out.append(b, len_ - pos_);
-			pos_ = len_;
-		}
-	}
-
-private:
-	FILE* fp_ = nullptr;
-	bool piped_ = false;
-	std::string buf_;
-	size_t pos_ = 0, len_ = 0;
-};
-
-// ---- the seam: what replaces ntRead / stRead (ntcard.cpp:147-171) ---------------------------------
-class Batcher {
-public:
-	explicit Batcher(ntc_engine* e) : eng_(e) { offsets_.push_back(0); }
-	void add(const std::string& seq)
-	{
-		bases_ += seq;
-		offsets_.push_back(bases_.size());
-		if (bases_.size() >= (48u << 20)) flush();
-	}
-	void flush()
-	{
-		if (offsets_.size() > 1 && ntc_submit(eng_, bases_.data(), offsets_.data(), offsets_.size() - 1) != 0) die_engine();
-		bases_.clear();
-		offsets_.assign(1, 0);
-	}
-
-private:
-	ntc_engine* eng_;
-	std::string bases_;
-	std::vector<uint64_t> offsets_;
-};
-
-bool is_number(const std::string& s) // ntcard.cpp:96-103
-{
-	if (s.empty()) return false;
-	for (char c : s)
-		if (c < '0' || c > '9') return false;
-	return true;
-}
-
-// ntcard.cpp:105-130: classify by the first line; 0 fastq, 1 fasta, 2 sam, 3 unknown
-unsigned sniff(const std::string& first, bool& sam_has_header)
-{
-	const char c0 = first.empty() ? '\0' : first[0];
-	const char c1 = first.size() > 1 ? first[1] : '\0', c2 = first.size() > 2 ? first[2] : '\0';
-	if (c0 == '>') return 1;
-	if (c0 == '@') {
-		const bool tag = (c1 == 'H' && c2 == 'D') || (c1 == 'S' && c2 == 'Q') || (c1 == 'R' && c2 == 'G') ||
-		                 (c1 == 'P' && c2 == 'G') || (c1 == 'C' && c2 == 'O');
-		return tag ? 2 : 0;
-	}
-	std::istringstream fields(first);
-	std::string f[11];
-	for (auto& x : f)
-		fields >> x;
-	if (is_number(f[1]) && is_number(f[4])) {
-		sam_has_header = false;
-		return 2;
-	}
-	return 3;
-}
-
-void parse_fastq(LineReader& in, Batcher& out) // ntcard.cpp:173-189 (4-line records, header already consumed)
-{
-	std::string seq, skip;
-	for (bool good = true; good;) {
-		in.getline(seq);
-		in.getline(skip);
-		good = in.getline(skip);
-		if (good) out.add(seq);
-		good = in.getline(skip);
-	}
-}
-
-void parse_fasta(LineReader& in, Batcher& out) // ntcard.cpp:191-208 (multi-line records are concatenated)
-{
-	std::string line, seq;
-	for (bool good = true; good;) {
-		seq.clear();
-		good = in.getline(line);
-		while (good && (line.empty() || line[0] != '>')) {
-			seq += line;
-			good = in.getline(line);
-		}
-		out.add(seq);
-	}
-}
-
-void parse_sam(LineReader& in, Batcher& out, const std::string& first, bool has_header) // ntcard.cpp:210-235
-{
-	std::string line, seq, f;
-	if (has_header) {
-		while (in.getline(line))
-			if (line.empty() || line[0] != '@') break;
-	} else {
-		line = first;
-	}
-	do {
-		std::istringstream fields(line);
-		for (int i = 0; i < 9; ++i)
-			fields >> f;
-		fields >> seq >> f; // a short line leaves `seq` at its previous value, exactly like the reference
-		out.add(seq);
-	} while (in.getline(line));
-}
-
 void process_file(const std::string& path, ntc_engine* eng)
 {
 	LineReader in(path);
@@ -269,14 +77,6 @@ void process_file(const std::string& path, ntc_engine* eng)
 		std::exit(EXIT_FAILURE);
 	}
 	batch.flush();
-}
-
-template <typename T>
-bool parse_value(const char* text, T& out) // `arg >> value` followed by the reference's `!arg.eof()` check
-{
-	std::istringstream arg(text ? text : "");
-	arg >> out;
-	return arg.eof();
 }
 
 } // namespace

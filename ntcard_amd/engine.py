@@ -111,6 +111,30 @@ class Engine:
         return ms.value, n.value
 
 
+class HllEngine(Engine):
+    """nthll: uint8 M[1<<n_bits] of max leading-zero runs (nthll.cpp:92-105,212-243)"""
+
+    def __init__(self, k, n_bits=16, device=0, stream=None):
+        self._lib = _abi.lib()
+        self.klist, self.gap, self.n_bits, self.device = [int(k)], 0, int(n_bits), int(device)
+        h = C.c_void_p()
+        check(self._lib.ntc_hll_create(int(k), int(n_bits), int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+
+    def finish(self):
+        regs = np.zeros(1 << self.n_bits, dtype=np.uint8)
+        f1 = np.zeros(1, dtype=np.uint64)
+        check(self._lib.ntc_hll_finish(self._h, _np_ptr(regs), _np_ptr(f1)))
+        return regs, int(f1[0])
+
+
+def hll_estimate(regs, n_bits=16):
+    est = C.c_double()
+    r = np.ascontiguousarray(regs, dtype=np.uint8)
+    check(_abi.lib().ntc_hll_estimate(_np_ptr(r), int(n_bits), C.byref(est)))
+    return est.value
+
+
 # -- stateless entry points ---------------------------------------------------------------------
 def estimate(p_hist_k, r_bits, s_bits, cov_max=1000):
     """compEst for one k from p[2][65536] -> (F0, f[0..cov_max])"""

@@ -356,6 +356,61 @@ size_t orc_format_hist(uint64_t f1, double F0, const double *f_mean, uint32_t co
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * a15: nthll.  nthll.cpp:92-97 (bucket = low n_bits, value = clz of the remaining bits, keep max),
+ * :99-105 (every clean window of the read), :221-243 (thread-private registers merged by max),
+ * :247-254 (alpha * m^2 / sum 2^-M, alpha halved for canonical hashes; the reference always is).
+ * ------------------------------------------------------------------------------------------- */
+void orc_hll_update(uint8_t *regs, uint32_t n_bits, const char *bases, const uint64_t *offsets,
+                    uint64_t n_reads, uint32_t k, int n_threads)
+{
+    const uint64_t n_buck = 1ULL << n_bits;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        uint8_t *mine = (uint8_t *)calloc(n_buck, 1);
+        uint64_t *h = NULL;
+        size_t cap = 0;
+#pragma omp for schedule(dynamic, 1024)
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+            if (len + 1 > cap) {
+                cap = 2 * (len + 1);
+                h = (uint64_t *)realloc(h, cap * sizeof *h);
+            }
+            const size_t n = orc_hash_read(bases + offsets[i], len, k, h, NULL, cap);
+            for (size_t j = 0; j < n; ++j) {
+                const uint64_t rest = h[j] & ~(n_buck - 1);
+                if (rest) {
+                    const uint8_t run0 = (uint8_t)__builtin_clzll(rest);
+                    uint8_t *slot = &mine[h[j] & (n_buck - 1)];
+                    if (run0 > *slot) *slot = run0;
+                }
+            }
+        }
+#pragma omp critical(orc_hll_merge)
+        for (uint64_t j = 0; j < n_buck; ++j)
+            if (regs[j] < mine[j]) regs[j] = mine[j];
+        free(mine);
+        free(h);
+    }
+}
+
+double orc_hll_estimate(const uint8_t *regs, uint32_t n_bits)
+{
+    const unsigned n_buck = 1u << n_bits;
+    double alpha = 1.4426 / (1 + 1.079 / n_buck);
+    alpha /= 2;
+    double p_est = 0.0;
+    for (unsigned j = 0; j < n_buck; ++j) p_est += 1.0 / ((uint64_t)1 << regs[j]);
+    const double z_est = 1.0 / p_est;
+    return alpha * n_buck * n_buck * z_est;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * Synthetic workload generator (own spec, DESIGN.md "Synthetic workloads"): counter-based, so a
  * read depends only on (seed, read index) and the CPU and the GPU generator (K0) agree bit for bit.
  * ------------------------------------------------------------------------------------------- */

@@ -73,6 +73,12 @@ void orc_comp_est(const uint16_t *counters_k, uint32_t r_bits, uint32_t s_bits, 
 size_t orc_format_hist(uint64_t f1, double F0, const double *f_mean, uint32_t cov_max,
                        char *buf, size_t cap);
 
+/* ---- a15: nthll (nthll.cpp:92-105 ntComp/ntRead, :238-243 max merge, :247-254 estimate) ------------ */
+/* regs: uint8_t [1<<n_bits], updated with max; n_threads <= 0 -> omp default                      */
+void orc_hll_update(uint8_t *regs, uint32_t n_bits, const char *bases, const uint64_t *offsets,
+                    uint64_t n_reads, uint32_t k, int n_threads);
+double orc_hll_estimate(const uint8_t *regs, uint32_t n_bits);
+
 /* ---- synthetic read generator (spec: DESIGN.md "Synthetic workloads"; no reference analogue) */
 /* dist 0 = uniform i.i.d. ACGT; dist 1 = reads from an implicit random genome, 1 % subs, 0.05 % N */
 void orc_gen_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,

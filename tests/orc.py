@@ -62,6 +62,10 @@ def lib():
     L.orc_comp_est.argtypes = [p, u32, u32, u32, C.POINTER(C.c_double), p]
     L.orc_format_hist.restype = sz
     L.orc_format_hist.argtypes = [u64, C.c_double, p, u32, C.c_char_p, sz]
+    L.orc_hll_update.restype = None
+    L.orc_hll_update.argtypes = [p, u32, p, p, u64, u32, C.c_int]
+    L.orc_hll_estimate.restype = C.c_double
+    L.orc_hll_estimate.argtypes = [p, u32]
     L.orc_gen_reads.restype = None
     L.orc_gen_reads.argtypes = [u64, u64, u64, u32, u32, u32, u64, p]
     L.orc_fnv1a64.restype = u64
@@ -129,6 +133,15 @@ def sketch_reads(reads, klist, gap=0, r_bits=27, s_bits=7, threads=0):
     bases, offs = concat_reads(reads)
     f1 = sketch_update(counters, bases, offs, klist, gap, r_bits, s_bits, threads=threads)
     return counters, f1
+
+
+def hll_reads(reads, k, n_bits=16, threads=0):
+    """-> (regs uint8[1<<n_bits], estimate) as nthll.cpp computes them"""
+    L = lib()
+    regs = np.zeros(1 << n_bits, dtype=np.uint8)
+    bases, offs = concat_reads(reads)
+    L.orc_hll_update(_ptr(regs), n_bits, _ptr(bases), _ptr(offs), len(reads), k, threads)
+    return regs, float(L.orc_hll_estimate(_ptr(regs), n_bits))
 
 
 def value_hist(counters_k, r_bits):
@@ -221,6 +234,23 @@ def _parse_rows(path, h):
         res.append((pos, hs))
         i += 1 + n
     return res
+
+
+REF_HLL_TOOL = os.path.join(REF_DIR, "ref_hll_tool")
+REF_NTHLL = os.path.join(REF_DIR, "nthll_ref")
+
+
+def ref_hll(seqs, k, n_bits=16, tmpdir="/tmp"):
+    """registers + printed estimate of the real nthll code (whitebox tool around nthll.cpp)"""
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        fin, fout = os.path.join(d, "in.txt"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            for s in seqs:
+                f.write(s + b"\n")
+        line = subprocess.check_output([REF_HLL_TOOL, str(k), str(n_bits), fin, fout])
+        regs = np.fromfile(fout, dtype=np.uint8)
+    return regs, line
 
 
 def ref_sketch(seqs, klist, gap, r_bits, s_bits, tmpdir="/tmp"):

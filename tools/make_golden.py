@@ -146,6 +146,23 @@ def sketch_goldens(reads):
         json.dump(out, f, separators=(",", ":"))
 
 
+def hll_goldens(reads, fq):
+    """nthll: registers (digest) + the printed estimate of the real nthll code, and the CLI's stdout line"""
+    out = {"cases": []}
+    for k, nb in ((32, 16), (12, 10), (64, 16), (20, 12), (70, 8)):
+        regs, line = orc.ref_hll(reads, k, nb)
+        out["cases"].append({"k": k, "n_bits": nb, "fnv1a64": "%016x" % orc.fnv1a64(regs), "max": int(regs.max()),
+                             "sum": int(regs.astype(np.uint64).sum()), "line": line.decode()})
+    with tempfile.TemporaryDirectory() as d:
+        fqp = os.path.join(d, "reads.fq")
+        with open(fqp, "wb") as f:
+            f.write(fq)
+        out["cli_k32"] = subprocess.check_output([orc.REF_NTHLL, "-k", "32", fqp], stderr=subprocess.DEVNULL).decode()
+        out["cli_k20_b12"] = subprocess.check_output([orc.REF_NTHLL, "-k", "20", "-b", "12", fqp], stderr=subprocess.DEVNULL).decode()
+    with open(os.path.join(GOLD, "nthll_goldens.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     if not orc.have_ref():
         sys.exit("oracle/_ref is missing: run `make -C oracle ref` in the build container first")
@@ -154,6 +171,7 @@ def main():
     reads, fq = small_reads()
     cli_goldens(reads, fq)
     sketch_goldens(reads)
+    hll_goldens(reads, fq)
     print("golden fixtures written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):
         print("  %8d  %s" % (os.path.getsize(os.path.join(GOLD, fn)), fn))
