@@ -344,8 +344,8 @@ void ntc_destroy(ntc_engine* e)
 		(void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
-	if (e->own_sketch && e->d_sketch) hipFree(e->d_sketch);
-	if (e->own_f1 && e->d_f1) hipFree(e->d_f1);
+	if (e->own_sketch && e->d_sketch) (void)hipFree(e->d_sketch);
+	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_queue) (void)hipFree(e->d_queue);

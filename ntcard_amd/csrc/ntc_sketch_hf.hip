@@ -112,10 +112,17 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	// spaced seed (stRead, ntcard.cpp:160-171): per pair of don't-care positions, the H halves of the terms to XOR out
 	const uint32_t ngp = (a.gap + 1u) >> 1;
 	unsigned char* const gapT = t1 + t1_bytes + (size_t)kWavesPerBlock * (kRing + hm_words * 64u) * 4u;
+	// Sample 0 of ntComp wants the top sBits+1 bits of min(fh,rh) to be 0..01.  Both strands are carried with
+	// that one bit flipped (folded into the step table: x' = x ^ c rolls with the term t ^ c ^ rotl(c)), so the
+	// test becomes min(f',r') < c: a superset (extra: one strand 0..01 while the other is 0..00, p = 2^-2(sBits+1)),
+	// made exact by the resolve stage, which re-derives everything from the bases.  Sample 1 looks at the bits
+	// above c only and is unaffected.  nthll compares against a moving threshold and runs unflipped.
+	const uint32_t flipc = a.hll_bits ? 0u : 1u << (31 - a.s_bits);
+	const uint32_t flipx = flipc ^ (flipc << 1);
 	{
 		for (int i = tid; i < kMainSlots * 4; i += kBlockThreads) {
 			const int slot = i >> 2, w = i & 3;
-			tabH[i] = w == 0 ? a.tab.A[slot][1] : (w == 1 ? a.tab.A[slot][3] : 0u);
+			tabH[i] = w == 0 ? (a.tab.A[slot][1] ^ flipx) : (w == 1 ? (a.tab.A[slot][3] ^ flipx) : 0u);
 		}
 		const uint4* src = reinterpret_cast<const uint4*>(a.t1);
 		for (uint32_t i = tid; i < t1_bytes / 16u; i += kBlockThreads)
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 
 		// The walk starts from the H halves of the hash of k virtual 'A's and feeds 'A' as the outgoing
 		// base of the first k steps, so ONE step body serves window filling and steady state.
-		uint32_t fHd = a.init[2], rHd = a.init[5];
+		uint32_t fHd = a.init[2] ^ flipc, rHd = a.init[5] ^ flipc;
 		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff; // emission allowed from this step on
 		uint32_t hmask = 0;                                      // sampled steps of the current 32-step block
 
@@ -324,8 +331,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 					if (hll.value)
 						m = ballot(mn < hll_thr); // nthll: only a hash with enough leading zeros can raise a register
 					else
-						m = ballot((mn ^ lo0) < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64
-					if (wc.value != CLEAN) m &= ballot(nextok <= q);
+						m = ballot(mn < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64 (mn carries the flipped bit)
+					if (wc.value == RAGGED) m &= ballot(nextok <= q); // DIRTY: windows over a dirty byte are dropped by the resolve stage
 				}
 				push(m);
 			};
