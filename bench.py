@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def klist_of(args):
+    return [int(x) for x in args.klist.split(",")] if args.klist else [args.k]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,6 +38,8 @@ def parse():
     ap.add_argument("--reads-per-step", type=int, default=10_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--klist", type=str, default="", help="comma separated k list (config 4: 32,64,96,128); overrides --k")
+    ap.add_argument("--gap", type=int, default=0, help="gapped seed (config 5), single k only")
     ap.add_argument("--r-bits", type=int, default=27)
     ap.add_argument("--s-bits", type=int, default=7)
     ap.add_argument("--dist", choices=["g", "u"], default="g",
@@ -53,7 +59,7 @@ def cpu_baseline(args, nt_stride):
     cores = os.cpu_count() or 1
     n = args.cpu_sample_reads or min(4_000_000, 250_000 * cores)
     dist = 1 if args.dist == "g" else 0
-    counters = np.zeros((1, 2, 1 << args.r_bits), dtype=np.uint16)
+    counters = np.zeros((len(klist_of(args)), 2, 1 << args.r_bits), dtype=np.uint16)
     offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(args.read_len))
     total_f1, dt, chunks = 0, 0.0, 0
     # successive distinct chunks of the same read stream until ~10 s of timed CPU work (bounded at 12 chunks);
@@ -64,15 +70,15 @@ def cpu_baseline(args, nt_stride):
         bases = np.ascontiguousarray(slots.reshape(n, nt_stride)[:, : args.read_len]).reshape(-1)
         if chunks == 0:  # thread pool + page-fault warm-up on 2 % of the first chunk, then start from zero
             warm = max(1, n // 50)
-            orc.sketch_update(counters, bases, offs[: warm + 1], [args.k], 0, args.r_bits, args.s_bits, threads=cores)
+            orc.sketch_update(counters, bases, offs[: warm + 1], klist_of(args), args.gap, args.r_bits, args.s_bits, threads=cores)
             counters[:] = 0
         t0 = time.perf_counter()
-        f1 = orc.sketch_update(counters, bases, offs, [args.k], 0, args.r_bits, args.s_bits, threads=cores)
+        f1 = orc.sketch_update(counters, bases, offs, klist_of(args), args.gap, args.r_bits, args.s_bits, threads=cores)
         dt += time.perf_counter() - t0
-        total_f1 += int(f1[0])
+        total_f1 += int(sum(int(x) for x in f1))
         chunks += 1
     return {"value": float(total_f1) / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": f"{chunks} x {n} reads x {args.read_len} bp (same generator, dist={args.dist}), k={args.k}, "
+            "sample": f"{chunks} x {n} reads x {args.read_len} bp (same generator, dist={args.dist}), k={klist_of(args)}, gap={args.gap}, "
                       f"oracle OpenMP ntRead+ntComp, {dt:.2f} s timed"}
 
 
@@ -82,6 +88,8 @@ def pmc_traffic(args, reads_per_launch):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as f:
             table = json.load(f)
+        if args.klist or args.gap:
+            return None
         key = f"dist={args.dist},L={args.read_len},k={args.k},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
         return table[key]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
@@ -108,6 +116,8 @@ def main():
     torch.cuda.set_device(dev)
 
     L, k = args.read_len, args.k
+    klist = klist_of(args)
+    nk = len(klist)
     stride = (L + 3) & ~3
     if stride == L:
         stride += 4  # keep at least one separator byte between slots
@@ -128,9 +138,9 @@ def main():
     nt.gen_reads_device(wb.data_ptr(), args.seed ^ 0x5eed, 0, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
 
     # the sketch is a torch tensor so that torch.distributed (RCCL) can reduce it in place
-    sketch = torch.zeros(2 << args.r_bits, dtype=torch.int32, device=dev)
-    f1_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    eng = nt.Engine([k], r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
+    sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
+    f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
+    eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
                     ext_sketch=sketch, ext_f1=f1_dev)
 
     def barrier():
@@ -162,11 +172,11 @@ def main():
 
     ker_ms, launches = eng.kernel_time()
     _, ph, f1 = eng.finish(counters=False, p_hist=True)
-    total_kmers = int(f1[0])  # after the reduce rank 0 holds the sum over ranks
+    total_kmers = int(sum(int(x) for x in f1))  # after the reduce rank 0 holds the sum over ranks (and over the k list)
 
     if rank == 0:
         import numpy as np
-        hits = int((ph[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
+        hits = int(sum((ph[ki].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum() for ki in range(nk)))
         # --- roofline of the dominant kernel (nthash_kernel<0>), per launch, this rank ---
         per_launch_kmers = total_kmers / max(world, 1) / max(launches, 1)
         per_launch_hits = hits / max(world, 1) / max(launches, 1)
@@ -187,9 +197,10 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{world}x{reads_per_rank} synthetic {L} bp reads (dist={args.dist}, seed={args.seed}), "
-                                   f"k={k}, rBits={args.r_bits}, sBits={args.s_bits}, {K} steps x {R} reads per GPU"
+                                   f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
+                                   f"{K} steps x {R} reads per GPU"
                                    + (", RCCL sum-reduce of the sketch to rank 0 inside the timed region" if world > 1 else ""),
-                       "k": k, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
+                       "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
                        "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),

@@ -49,9 +49,17 @@ struct DevInfo {
 
 int device_info(int dev, DevInfo& di)
 {
-	hipDeviceProp_t p;
-	HIP_TRY(hipGetDeviceProperties(&p, dev));
-	di.cus = p.multiProcessorCount;
+	static std::mutex mu;
+	static std::vector<int> cus; // per device, queried once (hipGetDeviceProperties is slow)
+	std::lock_guard<std::mutex> lk(mu);
+	if (dev < 0) return fail(NTC_ERR_ARG, "bad device %d", dev);
+	if ((size_t)dev >= cus.size()) cus.resize(dev + 1, 0);
+	if (cus[dev] == 0) {
+		hipDeviceProp_t p;
+		HIP_TRY(hipGetDeviceProperties(&p, dev));
+		cus[dev] = p.multiProcessorCount;
+	}
+	di.cus = cus[dev];
 	return 0;
 }
 
@@ -67,6 +75,44 @@ size_t smem_for(uint32_t stride, int kind, uint32_t k, uint32_t gap = 0)
 	return 16 + data + (size_t)ntc::t2_pairs(k) * 256u + (size_t)ntc::kWavesPerBlock * 128u * 4u +
 	       (size_t)ntc::kWavesPerBlock * ((stride + 31u) / 32u) * 64u * 4u + // + closed-form table, rings, hit masks
 	       (size_t)((gap + 1u) / 2u) * 256u;                                   // + spaced-seed table
+}
+
+// K1 (sketch_hf_kernel) launch shape.  Every wave parks its 64 slots (+ ring + hit masks) in LDS and the block shares
+// the closed-form tables, so the waves a CU can hold are bounded by its 160 KiB of LDS; pick the block size
+// (1..16 waves) that packs the most waves per CU (a fixed 4-wave block loses a third of them at k = 64).
+struct HfPlan {
+	unsigned grid = 0, wpb = 0;
+	size_t smem = 0;
+};
+int hf_plan(int dev, uint64_t n_slots, uint32_t stride, uint32_t k, uint32_t gap, HfPlan& p)
+{
+	DevInfo di;
+	if (int rc = device_info(dev, di)) return rc;
+	const size_t per_wave = 64u * (size_t)stride + 128u * 4u + (size_t)((stride + 31u) / 32u) * 64u * 4u;
+	const size_t shared = 16 + (size_t)ntc::t2_pairs(k) * 256u + (size_t)((gap + 1u) / 2u) * 256u;
+	const size_t cap = 160 * 1024, fixed = 256 + 1024; // static LDS of the kernel + allocation granularity slack
+	unsigned best_waves = 0;
+	static const int force_wpb = std::getenv("NTC_WPB") ? std::atoi(std::getenv("NTC_WPB")) : 0; // tuning experiments only
+	for (unsigned w = 1; w <= 16; ++w) {
+		if (force_wpb > 0 && (int)w != force_wpb) continue;
+		// whole multiples of the 4 SIMDs keep them evenly loaded (measured: 6 or 13 waves per block cost 5-12 %)
+		if (force_wpb == 0 && w > 4 && (w & 3u) != 0) continue;
+		const size_t blk = shared + w * per_wave + fixed;
+		if (blk > cap) break;
+		const unsigned waves = std::min<unsigned>(16, (unsigned)(cap / blk) * w); // 128 VGPRs: 4 waves per SIMD
+		if (waves >= best_waves) { // ties: the larger block (fewer table copies)
+			best_waves = waves;
+			p.wpb = w;
+		}
+	}
+	if (best_waves == 0)
+		return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs more than 160 KiB of LDS per wave", stride, k);
+	p.smem = shared + p.wpb * per_wave;
+	HIP_TRY(ntc::set_sketch_hf_smem_limit(p.smem));
+	const unsigned per_cu = std::max(1u, best_waves / p.wpb);
+	const uint64_t need = (n_slots + 64ull * p.wpb - 1) / (64ull * p.wpb);
+	p.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)di.cus * per_cu));
+	return 0;
 }
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
@@ -153,7 +199,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	size_t smem = 0;
 	const int kind = e->kernel_kind;
 	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
-	if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem, e->gap)) return rc;
+	if (kind != KIND_HF) // K1 plans its launch per k (hf_plan)
+		if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem, e->gap)) return rc;
 	// every lane can queue at most one hit per window of its slot: `stride` rows always suffice
 	const uint32_t queue_rows = stride;
 	if (kind == KIND_FAST) {
@@ -193,10 +240,9 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.hll_thr = e->d_hll_thr;
 			ntc::build_tables(a.k, a.tab);
 			ntc::poly_a_state(a.k, a.init);
-			unsigned g2 = 0;
-			size_t sm2 = 0;
-			if (int rc = hash_grid(e->device, n, stride, KIND_HF, a.k, g2, sm2)) return rc;
-			HIP_TRY(ntc::launch_sketch_hf(a, g2, sm2, e->stream));
+			HfPlan hp;
+			if (int rc = hf_plan(e->device, n, stride, a.k, 0, hp)) return rc;
+			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
 			done += n;
 			e->hll_reads_seen += n;
 		}
@@ -229,9 +275,12 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		a.gapt = e->d_gapt;
 		a.gap = e->gap;
 		a.gap_first = (a.k - e->gap) / 2;
-		const size_t smem_k = smem_for(stride, kind, a.k, e->gap);
-		if (kind == KIND_HF)
-			HIP_TRY(ntc::launch_sketch_hf(a, grid, smem_k, e->stream));
+		const size_t smem_k = kind == KIND_HF ? 0 : smem_for(stride, kind, a.k, e->gap);
+		if (kind == KIND_HF) {
+			HfPlan hp;
+			if (int rc = hf_plan(e->device, n_slots, stride, a.k, e->gap, hp)) return rc;
+			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
+		}
 		else if (kind == KIND_FAST)
 			HIP_TRY(ntc::launch_sketch_fast(a, grid, smem_k, e->stream));
 		else

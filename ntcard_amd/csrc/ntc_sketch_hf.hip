@@ -90,7 +90,7 @@ constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a 
 
 } // namespace
 
-__global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashArgs a)
+__global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 {
 	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][ceil(k/2) x 256 B closed-form table][waves x ring]
 	//              [waves x ceil(stride/32) x 64 hit-mask words]
@@ -100,18 +100,21 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
+	// waves per block: chosen by the host so that one CU holds as many waves as its 160 KiB of LDS allow
+	// (every wave parks its 64 slots in LDS; the closed-form table is shared by the block)
+	const uint32_t wpb = blockDim.x >> 6;
 	const uint32_t stride = a.stride;
 	const uint32_t k = a.k;
 	unsigned char* const wdata = smem + 16 + (size_t)wave * 64u * stride;
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
-	unsigned char* const t1 = smem + 16 + (size_t)kWavesPerBlock * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
+	unsigned char* const t1 = smem + 16 + (size_t)wpb * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
 	const uint32_t t1_bytes = ((k + 1u) >> 1) * 256u;
 	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + wave * kRing;
 	const uint32_t hm_words = (stride + 31u) >> 5; // 32-step blocks per slot
-	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + kWavesPerBlock * kRing + wave * hm_words * 64u + lane;
+	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + wpb * kRing + wave * hm_words * 64u + lane;
 	// spaced seed (stRead, ntcard.cpp:160-171): per pair of don't-care positions, the H halves of the terms to XOR out
 	const uint32_t ngp = (a.gap + 1u) >> 1;
-	unsigned char* const gapT = t1 + t1_bytes + (size_t)kWavesPerBlock * (kRing + hm_words * 64u) * 4u;
+	unsigned char* const gapT = t1 + t1_bytes + (size_t)wpb * (kRing + hm_words * 64u) * 4u;
 	// Sample 0 of ntComp wants the top sBits+1 bits of min(fh,rh) to be 0..01.  Both strands are carried with
 	// that one bit flipped (folded into the step table: x' = x ^ c rolls with the term t ^ c ^ rotl(c)), so the
 	// test becomes min(f',r') < c: a superset (extra: one strand 0..01 while the other is 0..00, p = 2^-2(sBits+1)),
@@ -120,15 +123,15 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	const uint32_t flipc = a.hll_bits ? 0u : 1u << (31 - a.s_bits);
 	const uint32_t flipx = flipc ^ (flipc << 1);
 	{
-		for (int i = tid; i < kMainSlots * 4; i += kBlockThreads) {
+		for (int i = tid; i < kMainSlots * 4; i += (int)blockDim.x) {
 			const int slot = i >> 2, w = i & 3;
 			tabH[i] = w == 0 ? (a.tab.A[slot][1] ^ flipx) : (w == 1 ? (a.tab.A[slot][3] ^ flipx) : 0u);
 		}
 		const uint4* src = reinterpret_cast<const uint4*>(a.t1);
-		for (uint32_t i = tid; i < t1_bytes / 16u; i += kBlockThreads)
+		for (uint32_t i = tid; i < t1_bytes / 16u; i += blockDim.x)
 			reinterpret_cast<uint4*>(t1)[i] = src[i];
 		const uint4* gsrc = reinterpret_cast<const uint4*>(a.gapt);
-		for (uint32_t i = tid; i < ngp * 16u; i += kBlockThreads)
+		for (uint32_t i = tid; i < ngp * 16u; i += blockDim.x)
 			reinterpret_cast<uint4*>(gapT)[i] = gsrc[i];
 	}
 	__syncthreads();
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	const uint32_t rmask = (1u << a.r_bits) - 1u;
 	const uint32_t rbuck = 1u << a.r_bits;
 
-	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave);
+	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 	const uint64_t n_wb = (a.n_slots + 63) / 64;
 	uint64_t f1_wave = 0;
 	const uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	const uint32_t full_bytes = 64u * stride;
 	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
 	const bool can_prefetch = nchunk <= (uint32_t)kPref;
-	const uint64_t wb_step = (uint64_t)gridDim.x * kWavesPerBlock;
+	const uint64_t wb_step = (uint64_t)gridDim.x * wpb;
 	uint4 pref[kPref];
 	auto load_round = [&](uint64_t wb_, uint32_t c0) {
 		const unsigned char* src = a.slots + wb_ * full_bytes;
@@ -501,9 +504,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_hf_kernel(const HashA
 	if (lane == 0 && f1_wave) atomicAdd(a.f1, (unsigned long long)f1_wave);
 }
 
-hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st)
+hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st)
 {
-	hipLaunchKernelGGL(sketch_hf_kernel, dim3(grid), dim3(kBlockThreads), smem, st, a);
+	hipLaunchKernelGGL(sketch_hf_kernel, dim3(grid), dim3(64u * waves_per_block), smem, st, a);
 	return hipGetLastError();
 }
 
