@@ -77,7 +77,7 @@ size_t smem_for(uint32_t stride, int kind, uint32_t k, uint32_t gap = 0)
 	       (size_t)((gap + 1u) / 2u) * 256u;                                   // + spaced-seed table
 }
 
-// K1 (sketch_hf_kernel) launch shape.  Every wave parks its 64 slots (+ ring + hit masks) in LDS and the block shares
+// K1 (sketch_hf_kernel) launch shape.  Every wave parks its 64 slots in LDS and the block shares
 // the closed-form tables, so the waves a CU can hold are bounded by its 160 KiB of LDS; pick the block size
 // (1..16 waves) that packs the most waves per CU (a fixed 4-wave block loses a third of them at k = 64).
 struct HfPlan {
@@ -88,7 +88,7 @@ int hf_plan(int dev, uint64_t n_slots, uint32_t stride, uint32_t k, uint32_t gap
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
-	const size_t per_wave = 64u * (size_t)stride + 128u * 4u + (size_t)((stride + 31u) / 32u) * 64u * 4u;
+	const size_t per_wave = 64u * (size_t)stride; // the wave's 64 decoded slots; hit masks and the compaction queue are registers
 	const size_t shared = 16 + (size_t)ntc::t2_pairs(k) * 256u + (size_t)((gap + 1u) / 2u) * 256u;
 	const size_t cap = 160 * 1024, fixed = 256 + 1024; // static LDS of the kernel + allocation granularity slack
 	unsigned best_waves = 0;

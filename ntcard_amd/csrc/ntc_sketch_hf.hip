@@ -9,7 +9,7 @@
 //     min(fh, rh); those bits live in the 31-bit rotating half H of the hash (nthash.hpp:186-217), and
 //     H rolls independently of the 33-bit half.  The per-base loop therefore rolls ONLY the two H
 //     halves (3 VALU ops each, one ds_read_b64 of seed terms) and tests min(fHd, rHd);
-//   * a lane that sees a sampled window just sets bit (step & 31) of a mask register (flushed to LDS
+//   * a lane that sees a sampled window just sets bit (step & 31) of a mask register (compacted
 //     every 32 steps): one VALU op, no memory traffic;
 //   * after the read, the wave compacts the (lane, step) pairs and 64 lanes at a time recompute the
 //     full 64-bit forward and reverse hashes of those windows from the closed form
@@ -86,14 +86,14 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 // wave ballot of a bool without the int round trip hipcc's ballot() goes through (saves 2 VALU ops per use)
 __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
-constexpr int kRing = 128; // compaction ring: (lane, step) pairs waiting for a dense resolve round
 
 } // namespace
 
 __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 {
-	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][ceil(k/2) x 256 B closed-form table][waves x ring]
-	//              [waves x ceil(stride/32) x 64 hit-mask words]
+	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][ceil(k/2) x 256 B closed-form table][gap table]
+	// Nothing else lives in LDS: hit masks and the compaction queue stay in registers, so that a CU's 160 KiB
+	// hold 16 waves of 150 bp reads (4 per SIMD) instead of 12.
 	extern __shared__ __align__(16) unsigned char smem[];
 	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
 	__shared__ __align__(16) uint32_t tabH[kMainSlots * 4];
@@ -109,12 +109,9 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
 	unsigned char* const t1 = smem + 16 + (size_t)wpb * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
 	const uint32_t t1_bytes = ((k + 1u) >> 1) * 256u;
-	uint32_t* const ring = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + wave * kRing;
-	const uint32_t hm_words = (stride + 31u) >> 5; // 32-step blocks per slot
-	uint32_t* const hm = reinterpret_cast<uint32_t*>(t1 + t1_bytes) + wpb * kRing + wave * hm_words * 64u + lane;
 	// spaced seed (stRead, ntcard.cpp:160-171): per pair of don't-care positions, the H halves of the terms to XOR out
 	const uint32_t ngp = (a.gap + 1u) >> 1;
-	unsigned char* const gapT = t1 + t1_bytes + (size_t)wpb * (kRing + hm_words * 64u) * 4u;
+	unsigned char* const gapT = t1 + t1_bytes;
 	// Sample 0 of ntComp wants the top sBits+1 bits of min(fh,rh) to be 0..01.  Both strands are carried with
 	// that one bit flipped (folded into the step table: x' = x ^ c rolls with the term t ^ c ^ rotl(c)), so the
 	// test becomes min(f',r') < c: a superset (extra: one strand 0..01 while the other is 0..00, p = 2^-2(sBits+1)),
@@ -241,9 +238,97 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 			const uint32_t xh = rHd ^ t.y;                    // reverse strand: ^ Tr, then rotr31
 			rHd = alignbit(xh >> 1, xh, 1);
 		};
-		auto flush = [&](int32_t blk) { // end of a 32-step block: park the mask in LDS
-			hm[blk * 64] = hmask;
+		// ---- resolve: 64 (lane, step) pairs at a time, recompute the full hashes from the bases ----
+		auto resolve_round = [&](uint32_t e, uint32_t count) {
+			// entry -> window start in LDS (any lane's slot), then the closed form over k bases
+			const bool act = (uint32_t)lane < count;
+			const uint32_t src_lane = e >> 16, q = e & 0xffffu;
+			const uint32_t base = act ? src_lane * stride + q + 1u - k : 0u; // byte offset of the window in wdata
+			const uint32_t sh = base & 3u;
+			const uint32_t* dp = reinterpret_cast<const uint32_t*>(wdata + (base & ~3u));
+			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0, dirty = 0;
+			uint32_t cur = dp[0];
+			const unsigned char* tp = t1;
+			for (uint32_t i = 0; i < k; i += 4) {
+				const uint32_t nxt = dp[(i >> 2) + 1];
+				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes (code<<6) of window positions i..i+3
+				cur = nxt;
+				dirty |= i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k)))); // bit 0 of a byte: not ACGTU
+				// pair offsets (a<<6 | b<<4): bytes 0,1 and bytes 2,3; a base beyond k contributes nothing
+				// because the odd-k table drops the b term and positions >= k are never looked up
+				const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
+				const uint4 t0 = *reinterpret_cast<const uint4*>(tp + o0);
+				flo ^= t0.x;
+				fhi ^= t0.y;
+				rlo ^= t0.z;
+				rhi ^= t0.w;
+				if (i + 2 < k) {
+					const uint32_t w2 = w >> 16;
+					const uint32_t o1 = (w2 & 0xc0u) | ((w2 >> 10) & 0x30u);
+					const uint4 t1v = *reinterpret_cast<const uint4*>(tp + 256 + o1);
+					flo ^= t1v.x;
+					fhi ^= t1v.y;
+					rlo ^= t1v.z;
+					rhi ^= t1v.w;
+				}
+				tp += 512;
+			}
+			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
+				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
+				const uint32_t hi = rev ? rhi : fhi;
+				const uint32_t lo = rev ? rlo : flo;
+				if (a.hll_bits != 0) {
+					// nthll's ntComp (nthll.cpp:92-97): bucket = low bits, value = leading zeros of the rest
+					const uint32_t bmask = (1u << a.hll_bits) - 1u;
+					const uint32_t lo_rest = lo & ~bmask;
+					if ((hi | lo_rest) != 0u) {
+						const uint32_t run0 = hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo_rest);
+						atomicMax(a.sketch + (lo & bmask), run0);
+					}
+					return;
+				}
+				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+				const bool c0 = (hi >> (31 - s_bits)) == 1u;
+#if NTC_EXP_NO_ATOMIC
+				if ((c0 | c1) && lo == 0x12345678u && hi == 0x9abcdef0u) atomicAdd(a.sketch, 1u); // A/B experiment
+#else
+				if (c0 | c1) atomicAdd(a.sketch + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
+#endif
+			}
+		};
+		// End of a 32-step block: queue the block's sampled steps as (lane, step) pairs.  The queue is ONE register
+		// per lane (entry i of the queue lives in lane i); each pass moves one pair per lane with a forward
+		// permute through the LDS crossbar (no LDS memory): a lane with a hit sends it to slot npend + rank, the
+		// others send a dummy to the remaining slots so that the destinations form a permutation.  When 64 are
+		// queued they are resolved; pairs beyond 64 are already sitting in the low lanes of the permute result.
+		uint32_t pend = 0, npend = 0;
+		auto compact = [&](int32_t last) { // `last` = the step recorded at bit 0 of hmask
+			uint32_t cur = hmask;
 			hmask = 0;
+#if NTC_EXP_NO_QUEUE
+			cur = 0;
+#endif
+			for (;;) {
+				const uint64_t m = ballot(cur != 0u);
+				if (m == 0) break;
+				const uint32_t c = (uint32_t)__popcll(m);
+				const bool hit = cur != 0u;
+				uint32_t bit;
+				asm("v_ffbl_b32 %0, %1" : "=v"(bit) : "v"(cur)); // lowest set bit (all ones for 0: the pair is a dummy then)
+				cur &= cur - 1u;
+				const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				const uint32_t entry = ((uint32_t)lane << 16) | (((uint32_t)last - bit) & 0xffffu);
+				const uint32_t dest = (hit ? pos : c + (uint32_t)lane - pos) + npend; // a permutation of 0..63 (mod 64)
+				const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)entry);
+				pend = (uint32_t)lane >= npend ? recv : pend;
+				npend += c;
+				if (npend >= 64u) {
+					resolve_round(pend, 64u);
+					pend = recv;
+					npend -= 64u;
+				}
+			}
 		};
 		// Table offsets (one byte per base: in<<6 | out<<4) of the 4 steps of group q0.
 		//   FILL : every step has q < k     -> outgoing base is the virtual 'A' (code 0)
@@ -368,23 +453,32 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
 						}
 					}
-					if (kind.value != FILL && ((g - e0) & 7) == 7) flush((g - e0) >> 3);
 				}
 			};
 			run(std::integral_constant<int, FILL>{}, 0, e0);
-			run(std::integral_constant<int, MIXED>{}, e0, e1);
-			run(std::integral_constant<int, MAIN>{}, e1, full_groups);
-			for (int32_t q = full_groups << 2; q < maxq; ++q) { // partial last group
-				const uint32_t ain = mine[q];
-				if (wc.value != CLEAN) {
-					if (wc.value == RAGGED) on_end(q);
-					if (ain & 1u) on_mark(q);
+			// recorded steps start at qs = 4*e0 and are handled in blocks of 32 (8 groups): walk, then compact
+			const int32_t nblk = (maxq - qs + 31) >> 5;
+			for (int32_t blk = 0; blk < nblk; ++blk) {
+				const int32_t gb = e0 + (blk << 3);
+				const int32_t ge = gb + 8 < full_groups ? gb + 8 : full_groups;
+				run(std::integral_constant<int, MIXED>{}, gb, ge < e1 ? ge : e1); // only the first block has MIXED groups
+				run(std::integral_constant<int, MAIN>{}, gb > e1 ? gb : e1, ge);
+				int32_t last = (ge << 2) - 1;
+				if (blk == nblk - 1) {
+					for (int32_t q = full_groups << 2; q < maxq; ++q) { // partial last group
+						const uint32_t ain = mine[q];
+						if (wc.value != CLEAN) {
+							if (wc.value == RAGGED) on_end(q);
+							if (ain & 1u) on_mark(q);
+						}
+						const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
+						roll(*reinterpret_cast<const uint2*>(tabHb + off));
+						record(q, q >= (int32_t)k - 1);
+					}
+					last = maxq - 1;
 				}
-				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
-				roll(*reinterpret_cast<const uint2*>(tabHb + off));
-				record(q, q >= (int32_t)k - 1);
+				compact(last);
 			}
-			if (maxq > qs && ((maxq - qs) & 31) != 0) flush((maxq - qs) >> 5);
 			if (wc.value == CLEAN) {
 				if (maxq >= (int32_t)k) f1_wave += (uint64_t)__popcll(ballot(true)) * (uint32_t)(maxq - (int32_t)k + 1);
 			} else {
@@ -409,97 +503,8 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 		else
 			walk(std::integral_constant<int, RAGGED>{}, std::false_type{}, std::false_type{});
 
-		// ---- resolve: compact (lane, step) pairs, 64 at a time recompute the full hashes ----
-		__builtin_amdgcn_wave_barrier();
-		auto resolve_round = [&](uint32_t first, uint32_t count) {
-			// entry -> window start in LDS (any lane's slot), then the closed form over k bases
-			const bool act = (uint32_t)lane < count;
-			const uint32_t e = act ? ring[(first + lane) & (kRing - 1)] : 0u;
-			const uint32_t src_lane = e >> 16, q = e & 0xffffu;
-			const uint32_t base = act ? src_lane * stride + q + 1u - k : 0u; // byte offset of the window in wdata
-			const uint32_t sh = base & 3u;
-			const uint32_t* dp = reinterpret_cast<const uint32_t*>(wdata + (base & ~3u));
-			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0, dirty = 0;
-			uint32_t cur = dp[0];
-			const unsigned char* tp = t1;
-			for (uint32_t i = 0; i < k; i += 4) {
-				const uint32_t nxt = dp[(i >> 2) + 1];
-				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes (code<<6) of window positions i..i+3
-				cur = nxt;
-				dirty |= i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k)))); // bit 0 of a byte: not ACGTU
-				// pair offsets (a<<6 | b<<4): bytes 0,1 and bytes 2,3; a base beyond k contributes nothing
-				// because the odd-k table drops the b term and positions >= k are never looked up
-				const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
-				const uint4 t0 = *reinterpret_cast<const uint4*>(tp + o0);
-				flo ^= t0.x;
-				fhi ^= t0.y;
-				rlo ^= t0.z;
-				rhi ^= t0.w;
-				if (i + 2 < k) {
-					const uint32_t w2 = w >> 16;
-					const uint32_t o1 = (w2 & 0xc0u) | ((w2 >> 10) & 0x30u);
-					const uint4 t1v = *reinterpret_cast<const uint4*>(tp + 256 + o1);
-					flo ^= t1v.x;
-					fhi ^= t1v.y;
-					rlo ^= t1v.z;
-					rhi ^= t1v.w;
-				}
-				tp += 512;
-			}
-			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
-				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
-				const uint32_t hi = rev ? rhi : fhi;
-				const uint32_t lo = rev ? rlo : flo;
-				if (a.hll_bits != 0) {
-					// nthll's ntComp (nthll.cpp:92-97): bucket = low bits, value = leading zeros of the rest
-					const uint32_t bmask = (1u << a.hll_bits) - 1u;
-					const uint32_t lo_rest = lo & ~bmask;
-					if ((hi | lo_rest) != 0u) {
-						const uint32_t run0 = hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo_rest);
-						atomicMax(a.sketch + (lo & bmask), run0);
-					}
-					return;
-				}
-				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
-				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
-				const bool c0 = (hi >> (31 - s_bits)) == 1u;
-#if NTC_EXP_NO_ATOMIC
-				if ((c0 | c1) && lo == 0x12345678u && hi == 0x9abcdef0u) atomicAdd(a.sketch, 1u); // A/B experiment
-#else
-				if (c0 | c1) atomicAdd(a.sketch + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
-#endif
-			}
-		};
-		uint32_t head = 0, tail = 0; // ring indices (wave-uniform)
-		const int32_t nrec_steps = maxq > qs ? maxq - qs : 0;
-		const int32_t nblk = (nrec_steps + 31) >> 5;
-		for (int32_t blk = 0; blk < nblk; ++blk) {
-			// the block's first step sits at its highest recorded bit
-			const int32_t in_blk = nrec_steps - blk * 32 < 32 ? nrec_steps - blk * 32 : 32;
-			const uint32_t top = (uint32_t)(qs + blk * 32 + in_blk - 1);
-			uint32_t cur = hm[blk * 64];
-#if NTC_EXP_NO_QUEUE
-			cur = 0;
-#endif
-			for (;;) {
-				const uint64_t m = ballot(cur != 0u);
-				if (m == 0) break;
-				if (cur != 0u) {
-					const uint32_t bit = __builtin_ctz(cur);
-					cur &= cur - 1u;
-					const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-					ring[(tail + pos) & (kRing - 1)] = ((uint32_t)lane << 16) | (top - bit);
-				}
-				tail += (uint32_t)__popcll(m);
-				__builtin_amdgcn_wave_barrier();
-				if (tail - head >= 64u) {
-					resolve_round(head, 64u);
-					head += 64u;
-					__builtin_amdgcn_wave_barrier();
-				}
-			}
-		}
-		if (tail != head) resolve_round(head, tail - head);
+		// ---- leftovers of the compaction queue: one last, partially filled resolve round ----
+		if (npend != 0) resolve_round(pend, npend);
 	}
 	if (lane == 0 && f1_wave) atomicAdd(a.f1, (unsigned long long)f1_wave);
 }
