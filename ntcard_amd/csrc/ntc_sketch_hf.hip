@@ -436,12 +436,27 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 						fixm = ballot((((ain & 0x01010101u) != 0u) | (endq < q0 + 4)) & (nextok != 0x7fffffff));
 					uint32_t fix = (uint32_t)(fixm | (fixm >> 32));
 					asm volatile("" : "+s"(fix)); // opaque SGPR: the test below must stay a scalar branch
-					// two copies of the group body behind ONE scalar branch: the common (no dirty byte, no read
-					// end in this group) copy carries no per-lane bookkeeping at all
-					if (wc.value != CLEAN && fix) {
+					if (wc.value == DIRTY) {
+						// the marks only feed F1 here (dirty windows are dropped by the resolve stage), so they are
+						// booked in one rare divergent region ahead of the group and the steps stay on the fast path
+						if (fix) {
+							uint32_t mk = ain & 0x01010101u;
+							while (mk != 0u) {
+								on_mark(q0 + (int32_t)((uint32_t)__builtin_ctz(mk) >> 3));
+								mk &= mk - 1u;
+							}
+						}
 #pragma unroll
 						for (int b = 0; b < 4; ++b) {
-							if (wc.value == RAGGED) on_end(q0 + b);
+							roll(T.t[b]);
+							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
+						}
+					} else if (wc.value == RAGGED && fix) {
+						// two copies of the group body behind ONE scalar branch: the common (no dirty byte, no read
+						// end in this group) copy carries no per-lane bookkeeping at all
+#pragma unroll
+						for (int b = 0; b < 4; ++b) {
+							on_end(q0 + b);
 							if ((ain >> (8 * b)) & 1u) on_mark(q0 + b);
 							roll(T.t[b]);
 							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
