@@ -35,6 +35,15 @@ def reduce_sketch(sketch, f1, dst=0):
     return sketch, f1
 
 
+def reduce_hll(regs, f1, dst=0):
+    """in-place MAX reduce of nthll's register file (any integer tensor) and SUM of F1 to rank dst.
+    The reference merges its per-thread register files the same way (nthll.cpp:240-245)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(regs, dst=dst, op=dist.ReduceOp.MAX)
+        dist.reduce(f1, dst=dst, op=dist.ReduceOp.SUM)
+    return regs, f1
+
+
 def to_uint16_counters(sketch_i32):
     """the reference's t_Counter view of a merged sketch: wrap to 16 bits (ntcard.cpp:142-143,439)"""
     return (sketch_i32 & 0xFFFF).to(torch.int32)

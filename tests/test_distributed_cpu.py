@@ -55,6 +55,33 @@ def test_two_rank_merge_equals_single_process(tmp_path):
     assert np.array_equal(sk.astype(np.int64), expect)
 
 
+def _hll_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, n = parallel.split_reads(N, world)[rank]
+    slots = orc.gen_reads(3, first, n, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(n)]
+    regs, _ = orc.hll_reads(reads, K, 10)
+    rt = torch.from_numpy(regs.astype(np.int32))
+    f1t = torch.tensor([sum(len(orc.hash_read(r, K)[0]) for r in reads)], dtype=torch.int64)
+    parallel.reduce_hll(rt, f1t, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "regs.npy"), rt.numpy())
+        np.save(os.path.join(out_dir, "f1.npy"), f1t.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_hll_merge_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_hll_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    slots = orc.gen_reads(3, 0, N, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(N)]
+    regs, _ = orc.hll_reads(reads, K, 10)
+    assert np.array_equal(np.load(tmp_path / "regs.npy"), regs.astype(np.int32))
+    assert int(np.load(tmp_path / "f1.npy")[0]) == sum(len(orc.hash_read(r, K)[0]) for r in reads)
+
+
 def test_split_reads_covers_everything():
     for n, w in ((10, 3), (100_000_000, 8), (7, 8)):
         parts = parallel.split_reads(n, w)
