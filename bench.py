@@ -129,8 +129,11 @@ def main():
     # ---- resident inputs: K step batches (+1 warmup batch), generated on the device (K0) ----
     reads_per_rank = R * K
     first, _ = parallel.read_range(rank, world, reads_per_rank)
+    # at most `nb` distinct batches stay resident (all K when they fit in half of the free HBM); a larger K cycles over them
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    nb = max(1, min(K, int(free_b * 0.5) // (R * stride + 16)))
     batches = []
-    for s in range(K):
+    for s in range(nb):
         b = torch.empty(R * stride + 16, dtype=torch.uint8, device=dev)
         nt.gen_reads_device(b.data_ptr(), args.seed, first + s * R, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
         batches.append(b)
@@ -160,7 +163,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for s in range(K):
-        eng.submit_device(batches[s].data_ptr(), R, L, stride)
+        eng.submit_device(batches[s % nb].data_ptr(), R, L, stride)
     parallel.reduce_sketch(sketch, f1_dev, dst=0)  # the path's one exchange step (no-op for N=1)
     barrier()
     dt = time.perf_counter() - t0
@@ -198,7 +201,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{world}x{reads_per_rank} synthetic {L} bp reads (dist={args.dist}, seed={args.seed}), "
                                    f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
-                                   f"{K} steps x {R} reads per GPU"
+                                   f"{K} steps x {R} reads per GPU" + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
                                    + (", RCCL sum-reduce of the sketch to rank 0 inside the timed region" if world > 1 else ""),
                        "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
                        "parallelism": f"read-sharded x{world}"},
