@@ -63,8 +63,8 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 	const uint32_t sel = w & 0x07070707u;
 	const uint32_t bad = (perm(kExpS0, kExpS1, sel) ^ w) & 0xdfdfdfdfu;
 	uint32_t code = perm(kIn6S0, kIn6S1, sel);
-	badacc |= bad;
 	if (bad != 0u) {
+		badacc = 1u; // noted on the rare path only
 		const uint32_t nz = (((bad & 0x7f7f7f7fu) + 0x7f7f7f7fu) | bad) & 0x80808080u;
 		code = (code & ~(nz >> 1) & ~nz) | (nz >> 7); // dirty byte: code 0, mark bit 0
 	}
