@@ -470,29 +470,92 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 					}
 				}
 			};
-			run(std::integral_constant<int, FILL>{}, 0, e0);
-			// recorded steps start at qs = 4*e0 and are handled in blocks of 32 (8 groups): walk, then compact
-			const int32_t nblk = (maxq - qs + 31) >> 5;
-			for (int32_t blk = 0; blk < nblk; ++blk) {
-				const int32_t gb = e0 + (blk << 3);
-				const int32_t ge = gb + 8 < full_groups ? gb + 8 : full_groups;
-				run(std::integral_constant<int, MIXED>{}, gb, ge < e1 ? ge : e1); // only the first block has MIXED groups
-				run(std::integral_constant<int, MAIN>{}, gb > e1 ? gb : e1, ge);
-				int32_t last = (ge << 2) - 1;
-				if (blk == nblk - 1) {
-					for (int32_t q = full_groups << 2; q < maxq; ++q) { // partial last group
-						const uint32_t ain = mine[q];
-						if (wc.value != CLEAN) {
-							if (wc.value == RAGGED) on_end(q);
-							if (ain & 1u) on_mark(q);
-						}
-						const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
-						roll(*reinterpret_cast<const uint2*>(tabHb + off));
-						record(q, q >= (int32_t)k - 1);
-					}
-					last = maxq - 1;
+			auto single = [&](int32_t q) { // one step outside the 4-step groups (q >= k - 1 only on the closed-form path)
+				const uint32_t ain = mine[q];
+				if (wc.value != CLEAN) {
+					if (wc.value == RAGGED) on_end(q);
+					if (ain & 1u) on_mark(q);
 				}
-				compact(last);
+				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
+				roll(*reinterpret_cast<const uint2*>(tabHb + off));
+				record(q, q >= (int32_t)k - 1);
+			};
+			if (wc.value != RAGGED && !gapped.value && !hll.value) {
+				// Equal-length waves skip the k-1 window-filling steps: the H halves of window 0 come from the closed
+				// form over the first k bases (the resolve stage's pair table, 2 bases per lookup), which costs about
+				// half of rolling them in and far less for large k.  Steps k .. A-1 (A = k rounded up to a group
+				// boundary) run singly, the rest in 4-step groups; every step from k-1 on is recorded.
+				if (maxq >= (int32_t)k) {
+					uint32_t fhi = 0, rhi = 0;
+					const uint32_t* dp = reinterpret_cast<const uint32_t*>(mine);
+					const unsigned char* tp = t1;
+					for (uint32_t i = 0; i < k; i += 4) {
+						const uint32_t w = dp[i >> 2];
+						if (wc.value == DIRTY) { // marks among the first k bases only feed F1 (rare divergent region)
+							uint32_t mk = (i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k))))) & 0x01010101u;
+							if (ballot(mk != 0u) != 0)
+								while (mk != 0u) {
+									on_mark((int32_t)i + (int32_t)((uint32_t)__builtin_ctz(mk) >> 3));
+									mk &= mk - 1u;
+								}
+						}
+						const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
+						const uint4 t0 = *reinterpret_cast<const uint4*>(tp + o0);
+						fhi ^= t0.y;
+						rhi ^= t0.w;
+						if (i + 2 < k) {
+							const uint32_t w2 = w >> 16;
+							const uint32_t o1 = (w2 & 0xc0u) | ((w2 >> 10) & 0x30u);
+							const uint4 t1v = *reinterpret_cast<const uint4*>(tp + 256 + o1);
+							fhi ^= t1v.y;
+							rhi ^= t1v.w;
+						}
+						tp += 512;
+					}
+					// high word of the 64-bit hash = (H << 1) | L[32]  ->  walk layout (H << 1) | H[30], plus the sample-bit flip
+					fHd = ((fhi & ~1u) | (fhi >> 31)) ^ flipc;
+					rHd = ((rhi & ~1u) | (rhi >> 31)) ^ flipc;
+					record((int32_t)k - 1, true);
+					const int32_t A = ((int32_t)k + 3) & ~3;
+					for (int32_t q = (int32_t)k; q < (A < maxq ? A : maxq); ++q)
+						single(q);
+					if (A >= maxq) {
+						compact(maxq - 1);
+					} else {
+						int32_t g = A >> 2, room = 7; // the first block also holds the (at most 4) steps recorded above
+						for (;;) {
+							const int32_t ge = g + room < full_groups ? g + room : full_groups;
+							run(std::integral_constant<int, MAIN>{}, g, ge);
+							if (ge == full_groups) {
+								if (ge - g == room && (maxq & 3) != 0) compact((ge << 2) - 1); // block is full: the tail gets its own
+								for (int32_t q = full_groups << 2; q < maxq; ++q) // partial last group
+									single(q);
+								compact(maxq - 1);
+								break;
+							}
+							compact((ge << 2) - 1);
+							g = ge;
+							room = 8;
+						}
+					}
+				}
+			} else {
+				run(std::integral_constant<int, FILL>{}, 0, e0);
+				// recorded steps start at qs = 4*e0 and are handled in blocks of 32 (8 groups): walk, then compact
+				const int32_t nblk = (maxq - qs + 31) >> 5;
+				for (int32_t blk = 0; blk < nblk; ++blk) {
+					const int32_t gb = e0 + (blk << 3);
+					const int32_t ge = gb + 8 < full_groups ? gb + 8 : full_groups;
+					run(std::integral_constant<int, MIXED>{}, gb, ge < e1 ? ge : e1); // only the first block has MIXED groups
+					run(std::integral_constant<int, MAIN>{}, gb > e1 ? gb : e1, ge);
+					int32_t last = (ge << 2) - 1;
+					if (blk == nblk - 1) {
+						for (int32_t q = full_groups << 2; q < maxq; ++q) // partial last group
+							single(q);
+						last = maxq - 1;
+					}
+					compact(last);
+				}
 			}
 			if (wc.value == CLEAN) {
 				if (maxq >= (int32_t)k) f1_wave += (uint64_t)__popcll(ballot(true)) * (uint32_t)(maxq - (int32_t)k + 1);
