@@ -480,7 +480,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 				roll(*reinterpret_cast<const uint2*>(tabHb + off));
 				record(q, q >= (int32_t)k - 1);
 			};
-			if (wc.value != RAGGED && !gapped.value && !hll.value) {
+			if (wc.value != RAGGED && !gapped.value) {
 				// Equal-length waves skip the k-1 window-filling steps: the H halves of window 0 come from the closed
 				// form over the first k bases (the resolve stage's pair table, 2 bases per lookup), which costs about
 				// half of rolling them in and far less for large k.  Steps k .. A-1 (A = k rounded up to a group
@@ -570,7 +570,11 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 #if NTC_EXP_STAGE_ONLY
 		if (mine[lane] == 0x7f && a.k == 9999) // A/B experiment: staging only (never true)
 #endif
-		if (a.hll_bits != 0)
+		if (a.hll_bits != 0 && wclass == CLEAN)
+			walk(std::integral_constant<int, CLEAN>{}, std::false_type{}, std::true_type{});
+		else if (a.hll_bits != 0 && wclass == DIRTY)
+			walk(std::integral_constant<int, DIRTY>{}, std::false_type{}, std::true_type{});
+		else if (a.hll_bits != 0)
 			walk(std::integral_constant<int, RAGGED>{}, std::false_type{}, std::true_type{});
 		else if (a.gap != 0)
 			walk(std::integral_constant<int, RAGGED>{}, std::true_type{}, std::false_type{}); // one (general) class keeps the gapped code small
