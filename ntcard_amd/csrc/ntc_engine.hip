@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -81,16 +82,38 @@ size_t smem_for(uint32_t stride, int kind, uint32_t k, uint32_t gap = 0)
 // the closed-form tables, so the waves a CU can hold are bounded by its 160 KiB of LDS; pick the block size
 // (1..16 waves) that packs the most waves per CU (a fixed 4-wave block loses a third of them at k = 64).
 struct HfPlan {
-	unsigned grid = 0, wpb = 0;
+	unsigned grid = 0, wpb = 0, waves_per_cu = 0;
 	size_t smem = 0;
 };
-int hf_plan(int dev, uint64_t n_slots, uint32_t stride, uint32_t k, uint32_t gap, HfPlan& p)
+
+// per-k block of the K1 argument struct
+void fill_hfk(ntc::HfK& o, uint32_t k, uint32_t* sketch, unsigned long long* f1, const void* t1)
+{
+	ntc::HashTables tab;
+	uint32_t init[6];
+	ntc::build_tables(k, tab);
+	ntc::poly_a_state(k, init);
+	o.k = k;
+	o.init_f = init[2];
+	o.init_r = init[5];
+	o.pad_ = 0;
+	o.sketch = sketch;
+	o.f1 = f1;
+	o.t1 = t1;
+	for (int slot = 0; slot < ntc::kMainSlots; ++slot) {
+		o.tabh[slot][0] = tab.A[slot][1];
+		o.tabh[slot][1] = tab.A[slot][3];
+	}
+}
+int hf_plan(int dev, uint64_t n_slots, uint32_t stride, const uint32_t* ks, uint32_t n_k, uint32_t gap, HfPlan& p)
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
 	const size_t per_wave = 64u * (size_t)stride; // the wave's 64 decoded slots; hit masks and the compaction queue are registers
-	const size_t shared = 16 + (size_t)ntc::t2_pairs(k) * 256u + (size_t)((gap + 1u) / 2u) * 256u;
-	const size_t cap = 160 * 1024, fixed = 256 + 1024; // static LDS of the kernel + allocation granularity slack
+	size_t shared = 16 + (size_t)((gap + 1u) / 2u) * 256u;
+	for (uint32_t j = 0; j < n_k; ++j)
+		shared += (size_t)ntc::t2_pairs(ks[j]) * 256u; // the closed-form tables of every fused k are resident
+	const size_t cap = 160 * 1024, fixed = 1024 + 1024; // static LDS of the kernel (step tables of up to 4 k) + allocation slack // static LDS of the kernel + allocation granularity slack
 	unsigned best_waves = 0;
 	static const int force_wpb = std::getenv("NTC_WPB") ? std::atoi(std::getenv("NTC_WPB")) : 0; // tuning experiments only
 	for (unsigned w = 1; w <= 16; ++w) {
@@ -106,8 +129,9 @@ int hf_plan(int dev, uint64_t n_slots, uint32_t stride, uint32_t k, uint32_t gap
 		}
 	}
 	if (best_waves == 0)
-		return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs more than 160 KiB of LDS per wave", stride, k);
+		return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs more than 160 KiB of LDS per wave", stride, ks[0]);
 	p.smem = shared + p.wpb * per_wave;
+	p.waves_per_cu = best_waves;
 	HIP_TRY(ntc::set_sketch_hf_smem_limit(p.smem));
 	const unsigned per_cu = std::max(1u, best_waves / p.wpb);
 	const uint64_t need = (n_slots + 64ull * p.wpb - 1) / (64ull * p.wpb);
@@ -143,6 +167,7 @@ struct ntc_engine {
 	hipStream_t stream = nullptr;
 	std::vector<uint32_t> klist;
 	uint32_t gap = 0, r_bits = 27, s_bits = 7;
+	std::vector<ntc::HfK> hfk;    // per-k argument blocks of K1 (tables derived once at create)
 	uint32_t* d_sketch = nullptr; // [nk][2][1<<r_bits]
 	unsigned long long* d_f1 = nullptr;
 	bool own_sketch = false, own_f1 = false;
@@ -223,29 +248,70 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			uint64_t n = std::max<uint64_t>(16384, e->hll_reads_seen);
 			n = std::min<uint64_t>((n + 1) & ~1ull, n_slots - done); // even: keeps 16-byte alignment of uniform slots
 			HIP_TRY(ntc::launch_hll_threshold(e->d_sketch, 1u << e->hll_bits, e->d_hll_thr, e->stream));
-			ntc::HashArgs a;
+			ntc::HfArgs a;
 			std::memset(&a, 0, sizeof a);
 			a.slots = d_slots + done * stride;
 			a.meta = d_meta ? d_meta + done : nullptr;
 			a.n_slots = n;
 			a.stride = stride;
 			a.read_len = read_len;
-			a.k = e->klist[0];
 			a.r_bits = 27;
 			a.s_bits = 7;
-			a.sketch = e->d_sketch;
-			a.f1 = e->d_f1;
-			a.t1 = e->d_t1[0];
+			a.n_k = 1;
 			a.hll_bits = e->hll_bits;
 			a.hll_thr = e->d_hll_thr;
-			ntc::build_tables(a.k, a.tab);
-			ntc::poly_a_state(a.k, a.init);
+			a.ks[0] = e->hfk[0];
 			HfPlan hp;
-			if (int rc = hf_plan(e->device, n, stride, a.k, 0, hp)) return rc;
+			if (int rc = hf_plan(e->device, n, stride, &e->klist[0], 1, 0, hp)) return rc;
 			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
 			done += n;
 			e->hll_reads_seen += n;
 		}
+		return 0;
+	}
+	if (kind == KIND_HF) {
+		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
+		// a group whose closed-form tables would push the CU below 12 waves is split in two
+		std::function<int(size_t, size_t)> launch_group = [&](size_t b, size_t n) -> int {
+			HfPlan hp;
+			if (int rc = hf_plan(e->device, n_slots, stride, &e->klist[b], (uint32_t)n, e->gap, hp)) {
+				if (n == 1) return rc;
+				hp.waves_per_cu = 0;
+			}
+			if (n > 1 && hp.waves_per_cu < 12) {
+				if (int rc = launch_group(b, n / 2)) return rc;
+				return launch_group(b + n / 2, n - n / 2);
+			}
+			ntc::HfArgs a;
+			std::memset(&a, 0, sizeof a);
+			a.slots = d_slots;
+			a.meta = d_meta;
+			a.n_slots = n_slots;
+			a.stride = stride;
+			a.read_len = read_len;
+			a.r_bits = e->r_bits;
+			a.s_bits = e->s_bits;
+			a.n_k = (uint32_t)n;
+			a.gap = e->gap;
+			a.gap_first = (e->klist[b] - e->gap) / 2;
+			a.gapt = e->d_gapt;
+			for (size_t j = 0; j < n; ++j)
+				a.ks[j] = e->hfk[b + j];
+			hipEvent_t ev0 = nullptr, ev1 = nullptr;
+			if (e->profiling) {
+				HIP_TRY(hipEventCreate(&ev0));
+				HIP_TRY(hipEventCreate(&ev1));
+				HIP_TRY(hipEventRecord(ev0, e->stream));
+			}
+			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
+			if (e->profiling) {
+				HIP_TRY(hipEventRecord(ev1, e->stream));
+				e->pending.emplace_back(ev0, ev1);
+			}
+			return 0;
+		};
+		for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)
+			if (int rc = launch_group(b, std::min<size_t>(ntc::kMaxFusedK, e->klist.size() - b))) return rc;
 		return 0;
 	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
@@ -275,13 +341,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		a.gapt = e->d_gapt;
 		a.gap = e->gap;
 		a.gap_first = (a.k - e->gap) / 2;
-		const size_t smem_k = kind == KIND_HF ? 0 : smem_for(stride, kind, a.k, e->gap);
-		if (kind == KIND_HF) {
-			HfPlan hp;
-			if (int rc = hf_plan(e->device, n_slots, stride, a.k, e->gap, hp)) return rc;
-			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
-		}
-		else if (kind == KIND_FAST)
+		const size_t smem_k = smem_for(stride, kind, a.k, e->gap);
+		if (kind == KIND_FAST)
 			HIP_TRY(ntc::launch_sketch_fast(a, grid, smem_k, e->stream));
 		else
 			HIP_TRY(ntc::launch_hash(0, a, grid, smem_k, e->stream));
@@ -375,6 +436,9 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the spaced-seed table on device");
 		}
 	}
+	e->hfk.resize(e->klist.size());
+	for (size_t ki = 0; ki < e->klist.size(); ++ki)
+		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki]);
 	int rc = ntc_reset(e);
 	if (rc) {
 		ntc_destroy(e);
@@ -673,6 +737,9 @@ int ntc_hll_create(uint32_t k, uint32_t n_bits, int32_t device, void* stream, nt
 	}
 	e->own_sketch = e->own_f1 = true;
 	e->d_t1.push_back(d);
+	e->hfk.resize(e->klist.size());
+	for (size_t ki = 0; ki < e->klist.size(); ++ki)
+		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki]);
 	int rc = ntc_reset(e);
 	if (rc) {
 		ntc_destroy(e);

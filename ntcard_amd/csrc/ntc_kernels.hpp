@@ -35,11 +35,37 @@ struct HashArgs {
 	HashTables tab;
 };
 
+// K1 (sketch_hf_kernel): one launch hashes a resident batch for up to kMaxFusedK values of k (the reference's
+// ntRead loops over its k list per read, ntcard.cpp:147-158): the batch is staged and decoded once.
+constexpr int kMaxFusedK = 4;
+struct HfK {
+	uint32_t k;
+	uint32_t init_f, init_r;    // H halves ((H << 1) | H[30]) of the hash of k x 'A', forward / reverse
+	uint32_t pad_;
+	uint32_t* sketch;           // uint32 [2][1<<r_bits] plane pair of this k (nthll: uint32 M[1<<hll_bits])
+	unsigned long long* f1;     // F1 of this k
+	const void* t1;             // [ceil(k/2)][16] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seed pairs (device)
+	uint32_t tabh[kMainSlots][2]; // per (in,out) base pair: {Tf.Hd, Tr.Hd} step terms of the H halves
+};
+struct HfArgs {
+	const unsigned char* slots; // as HashArgs
+	const uint32_t* meta;
+	uint64_t n_slots;
+	uint32_t stride, read_len;
+	uint32_t r_bits, s_bits;
+	uint32_t n_k;               // 1..kMaxFusedK
+	uint32_t gap, gap_first;    // spaced seed: single k only
+	uint32_t hll_bits;          // nthll mode: single k only
+	const void* gapt;
+	const uint32_t* hll_thr;
+	HfK ks[kMaxFusedK];
+};
+
 hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_hash_smem_limit(size_t smem);
 hipError_t launch_sketch_fast(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_sketch_fast_smem_limit(size_t smem);
-hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st);
+hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st);
 hipError_t set_sketch_hf_smem_limit(size_t smem);
 hipError_t launch_hll_threshold(const uint32_t* regs, uint32_t n_regs, uint32_t* thr, hipStream_t st);
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,

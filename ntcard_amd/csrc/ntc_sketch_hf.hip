@@ -89,14 +89,17 @@ __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_bal
 
 } // namespace
 
-__global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
+// kMulti = false: exactly one k (the loop over the k list folds away and every per-k value is a launch constant)
+template <bool kMulti>
+__global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 {
+	const uint32_t n_k = kMulti ? a.n_k : 1u;
 	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][ceil(k/2) x 256 B closed-form table][gap table]
 	// Nothing else lives in LDS: hit masks and the compaction queue stay in registers, so that a CU's 160 KiB
 	// hold 16 waves of 150 bp reads (4 per SIMD) instead of 12.
 	extern __shared__ __align__(16) unsigned char smem[];
 	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
-	__shared__ __align__(16) uint32_t tabH[kMainSlots * 4];
+	__shared__ __align__(16) uint32_t tabH[kMaxFusedK][kMainSlots * 4];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
@@ -104,14 +107,19 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 	// (every wave parks its 64 slots in LDS; the closed-form table is shared by the block)
 	const uint32_t wpb = blockDim.x >> 6;
 	const uint32_t stride = a.stride;
-	const uint32_t k = a.k;
+	// per-k state of the fused multi-k loop (the lambdas below see the current values)
+	uint32_t k = a.ks[0].k;
+	uint32_t t1_off[kMaxFusedK + 1]; // LDS offsets of the closed-form tables, [n_k] = total
+	t1_off[0] = 0;
+	for (uint32_t j = 0; j < (uint32_t)kMaxFusedK; ++j)
+		t1_off[j + 1] = t1_off[j] + (j < n_k ? ((a.ks[j].k + 1u) >> 1) * 256u : 0u);
 	unsigned char* const wdata = smem + 16 + (size_t)wave * 64u * stride;
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
-	unsigned char* const t1 = smem + 16 + (size_t)wpb * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
-	const uint32_t t1_bytes = ((k + 1u) >> 1) * 256u;
+	unsigned char* const t1_base = smem + 16 + (size_t)wpb * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
+	unsigned char* t1 = t1_base;
 	// spaced seed (stRead, ntcard.cpp:160-171): per pair of don't-care positions, the H halves of the terms to XOR out
 	const uint32_t ngp = (a.gap + 1u) >> 1;
-	unsigned char* const gapT = t1 + t1_bytes;
+	unsigned char* const gapT = t1_base + t1_off[kMaxFusedK];
 	// Sample 0 of ntComp wants the top sBits+1 bits of min(fh,rh) to be 0..01.  Both strands are carried with
 	// that one bit flipped (folded into the step table: x' = x ^ c rolls with the term t ^ c ^ rotl(c)), so the
 	// test becomes min(f',r') < c: a superset (extra: one strand 0..01 while the other is 0..00, p = 2^-2(sBits+1)),
@@ -120,19 +128,23 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 	const uint32_t flipc = a.hll_bits ? 0u : 1u << (31 - a.s_bits);
 	const uint32_t flipx = flipc ^ (flipc << 1);
 	{
-		for (int i = tid; i < kMainSlots * 4; i += (int)blockDim.x) {
-			const int slot = i >> 2, w = i & 3;
-			tabH[i] = w == 0 ? (a.tab.A[slot][1] ^ flipx) : (w == 1 ? (a.tab.A[slot][3] ^ flipx) : 0u);
+		for (uint32_t j = 0; j < n_k; ++j) {
+			for (int i = tid; i < kMainSlots * 4; i += (int)blockDim.x) {
+				const int slot = i >> 2, w = i & 3;
+				tabH[j][i] = w < 2 ? (a.ks[j].tabh[slot][w] ^ flipx) : 0u;
+			}
+			const uint4* src = reinterpret_cast<const uint4*>(a.ks[j].t1);
+			uint4* dst = reinterpret_cast<uint4*>(t1_base + t1_off[j]);
+			for (uint32_t i = tid; i < (t1_off[j + 1] - t1_off[j]) / 16u; i += blockDim.x)
+				dst[i] = src[i];
 		}
-		const uint4* src = reinterpret_cast<const uint4*>(a.t1);
-		for (uint32_t i = tid; i < t1_bytes / 16u; i += blockDim.x)
-			reinterpret_cast<uint4*>(t1)[i] = src[i];
 		const uint4* gsrc = reinterpret_cast<const uint4*>(a.gapt);
 		for (uint32_t i = tid; i < ngp * 16u; i += blockDim.x)
 			reinterpret_cast<uint4*>(gapT)[i] = gsrc[i];
 	}
 	__syncthreads();
-	const unsigned char* const tabHb = reinterpret_cast<const unsigned char*>(tabH);
+	const unsigned char* tabHb = reinterpret_cast<const unsigned char*>(tabH[0]);
+	uint32_t* sketch_k = a.ks[0].sketch;
 
 	// sample windows on the top bits (ntcard.cpp:135-138); VGPR-resident on purpose (SGPR sources halve the VALU rate)
 	uint32_t lo0 = 1u << (31 - a.s_bits);
@@ -146,8 +158,8 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 	const uint64_t n_wb = (a.n_slots + 63) / 64;
-	uint64_t f1_wave = 0;
-	const uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
+	uint64_t f1_acc[kMaxFusedK] = {0, 0, 0, 0};
+	uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
 
 	// ---- global -> LDS staging with register prefetch of the next batch (see ntc_sketch_fast.hip) ----
 	constexpr int kPref = 10;
@@ -212,6 +224,14 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 			len = m & 0xffffu;
 			wlim = m >> 16;
 		}
+		// ---- every k of the list over the staged batch (ntRead's loop over kList, ntcard.cpp:147-158) ----
+		for (uint32_t ki = 0; ki < n_k; ++ki) {
+		k = a.ks[ki].k;
+		t1 = t1_base + t1_off[ki];
+		tabHb = reinterpret_cast<const unsigned char*>(tabH[ki]);
+		sketch_k = a.ks[ki].sketch;
+		shb = (0u - k) & 3u;
+		uint64_t f1_wave = 0;
 		int32_t endq = (int32_t)(len < wlim + k - 1 ? len : wlim + k - 1); // steps q in [0,endq)
 		if (!in_batch || len < k) endq = 0;
 		int32_t maxq = endq, minq = endq;
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 
 		// The walk starts from the H halves of the hash of k virtual 'A's and feeds 'A' as the outgoing
 		// base of the first k steps, so ONE step body serves window filling and steady state.
-		uint32_t fHd = a.init[2] ^ flipc, rHd = a.init[5] ^ flipc;
+		uint32_t fHd = a.ks[ki].init_f ^ flipc, rHd = a.ks[ki].init_r ^ flipc;
 		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff; // emission allowed from this step on
 		uint32_t hmask = 0;                                      // sampled steps of the current 32-step block
 
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 					const uint32_t lo_rest = lo & ~bmask;
 					if ((hi | lo_rest) != 0u) {
 						const uint32_t run0 = hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo_rest);
-						atomicMax(a.sketch + (lo & bmask), run0);
+						atomicMax(sketch_k + (lo & bmask), run0);
 					}
 					return;
 				}
@@ -291,9 +311,9 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
 				const bool c0 = (hi >> (31 - s_bits)) == 1u;
 #if NTC_EXP_NO_ATOMIC
-				if ((c0 | c1) && lo == 0x12345678u && hi == 0x9abcdef0u) atomicAdd(a.sketch, 1u); // A/B experiment
+				if ((c0 | c1) && lo == 0x12345678u && hi == 0x9abcdef0u) atomicAdd(sketch_k, 1u); // A/B experiment
 #else
-				if (c0 | c1) atomicAdd(a.sketch + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
+				if (c0 | c1) atomicAdd(sketch_k + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
 #endif
 			}
 		};
@@ -568,7 +588,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 			}
 		};
 #if NTC_EXP_STAGE_ONLY
-		if (mine[lane] == 0x7f && a.k == 9999) // A/B experiment: staging only (never true)
+		if (mine[lane] == 0x7f && k == 9999) // A/B experiment: staging only (never true)
 #endif
 		if (a.hll_bits != 0 && wclass == CLEAN)
 			walk(std::integral_constant<int, CLEAN>{}, std::false_type{}, std::true_type{});
@@ -587,19 +607,28 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HashArgs a)
 
 		// ---- leftovers of the compaction queue: one last, partially filled resolve round ----
 		if (npend != 0) resolve_round(pend, npend);
+		f1_acc[ki] += f1_wave;
+		} // k list
 	}
-	if (lane == 0 && f1_wave) atomicAdd(a.f1, (unsigned long long)f1_wave);
+	for (uint32_t j = 0; j < n_k; ++j)
+		if (lane == 0 && f1_acc[j]) atomicAdd(a.ks[j].f1, (unsigned long long)f1_acc[j]);
 }
 
-hipError_t launch_sketch_hf(const HashArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st)
+hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st)
 {
-	hipLaunchKernelGGL(sketch_hf_kernel, dim3(grid), dim3(64u * waves_per_block), smem, st, a);
+	if (a.n_k > 1)
+		hipLaunchKernelGGL(sketch_hf_kernel<true>, dim3(grid), dim3(64u * waves_per_block), smem, st, a);
+	else
+		hipLaunchKernelGGL(sketch_hf_kernel<false>, dim3(grid), dim3(64u * waves_per_block), smem, st, a);
 	return hipGetLastError();
 }
 
 hipError_t set_sketch_hf_smem_limit(size_t smem)
 {
-	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_hf_kernel),
+	hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_hf_kernel<false>),
+	                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	if (rc != hipSuccess) return rc;
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_hf_kernel<true>),
 	                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 

@@ -103,6 +103,8 @@ def test_known_answer_on_device(nt):
 @pytest.mark.parametrize("dist,klist,r_bits,s_bits", [
     (1, [32], 20, 7), (0, [32], 20, 7), (1, [32], 22, 11), (1, [12], 18, 7), (1, [33], 20, 7),
     (1, [31], 19, 5), (1, [16, 24, 32, 48], 19, 7), (1, [32, 64, 96, 128], 20, 7), (0, [150], 16, 2),
+    (1, [12, 20, 31, 33, 47, 64], 18, 7),   # more than one fused launch group (4 + 2)
+    (1, [100, 120, 140, 150], 16, 7),       # tables too big to fuse all four: the group is split
 ])
 def test_sketch_device_batch_matches_oracle(nt, dist, klist, r_bits, s_bits):
     n, L, stride = 20_000, 150, 152
