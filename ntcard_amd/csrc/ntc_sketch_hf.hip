@@ -596,8 +596,12 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 			walk(std::integral_constant<int, DIRTY>{}, std::false_type{}, std::true_type{});
 		else if (a.hll_bits != 0)
 			walk(std::integral_constant<int, RAGGED>{}, std::false_type{}, std::true_type{});
+		else if (a.gap != 0 && wclass == CLEAN)
+			walk(std::integral_constant<int, CLEAN>{}, std::true_type{}, std::false_type{});
+		else if (a.gap != 0 && wclass == DIRTY)
+			walk(std::integral_constant<int, DIRTY>{}, std::true_type{}, std::false_type{});
 		else if (a.gap != 0)
-			walk(std::integral_constant<int, RAGGED>{}, std::true_type{}, std::false_type{}); // one (general) class keeps the gapped code small
+			walk(std::integral_constant<int, RAGGED>{}, std::true_type{}, std::false_type{});
 		else if (wclass == CLEAN)
 			walk(std::integral_constant<int, CLEAN>{}, std::false_type{}, std::false_type{});
 		else if (wclass == DIRTY)
