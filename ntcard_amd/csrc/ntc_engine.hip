@@ -295,6 +295,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.gap = e->gap;
 			a.gap_first = (e->klist[b] - e->gap) / 2;
 			a.gapt = e->d_gapt;
+			if (e->gap) ntc::build_gap_roll_table(e->klist[b], a.gap_first, e->gap, a.tabg);
 			for (size_t j = 0; j < n; ++j)
 				a.ks[j] = e->hfk[b + j];
 			hipEvent_t ev0 = nullptr, ev1 = nullptr;

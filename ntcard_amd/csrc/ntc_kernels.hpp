@@ -58,6 +58,7 @@ struct HfArgs {
 	uint32_t hll_bits;          // nthll mode: single k only
 	const void* gapt;
 	const uint32_t* hll_thr;
+	uint32_t tabg[kMainSlots][2]; // spaced seed, rolling form: per (leaving, entering) base pair of the don't-care block
 	HfK ks[kMaxFusedK];
 };
 

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 	extern __shared__ __align__(16) unsigned char smem[];
 	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
 	__shared__ __align__(16) uint32_t tabH[kMaxFusedK][kMainSlots * 4];
+	__shared__ __align__(16) uint32_t tabG[kMainSlots * 4]; // spaced seed, rolling form (same addressing as tabH)
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 			for (uint32_t i = tid; i < (t1_off[j + 1] - t1_off[j]) / 16u; i += blockDim.x)
 				dst[i] = src[i];
 		}
+		if (a.gap != 0)
+			for (int i = tid; i < kMainSlots * 4; i += (int)blockDim.x)
+				tabG[i] = (i & 3) < 2 ? a.tabg[i >> 2][i & 3] : 0u;
 		const uint4* gsrc = reinterpret_cast<const uint4*>(a.gapt);
 		for (uint32_t i = tid; i < ngp * 16u; i += blockDim.x)
 			reinterpret_cast<uint4*>(gapT)[i] = gsrc[i];
@@ -253,6 +257,12 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 		int32_t nextok = endq > 0 ? (int32_t)k - 1 : 0x7fffffff; // emission allowed from this step on
 		uint32_t hmask = 0;                                      // sampled steps of the current 32-step block
 
+		const unsigned char* const tabGb = reinterpret_cast<const unsigned char*>(tabG);
+		auto roll2 = [&](const uint2 t, const uint2 g) { // spaced seed, rolling form: two more terms per strand
+			fHd = alignbit(fHd, dbl(fHd), 31) ^ t.x ^ g.x;
+			const uint32_t xh = rHd ^ t.y ^ g.y;
+			rHd = alignbit(xh >> 1, xh, 1);
+		};
 		auto roll = [&](const uint2 t) {
 			fHd = alignbit(fHd, dbl(fHd), 31) ^ t.x;          // rotl31 in the (H<<1)|H[30] layout, then ^ Tf
 			const uint32_t xh = rHd ^ t.y;                    // reverse strand: ^ Tr, then rotr31
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 				uint64_t m = 0;
 				if (emitting) {
 					uint32_t fs = fHd, rs = rHd;
-					if (gapped.value) {
+					if (gapped.value && wc.value == RAGGED) {
 						// NTMSM64 (nthash.hpp:641-646,665-670): XOR the don't-care bases' rotated seeds back out
 						const unsigned char* gp = mine + (q - (int32_t)k + 1 + (int32_t)a.gap_first);
 						for (uint32_t p = 0; p < ngp; ++p) {
@@ -448,8 +458,29 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 				for (int32_t g = g0; g < g1; ++g) {
 					const int32_t q0 = g << 2;
 					uint32_t ain;
-					Tab4 T;
+					Tab4 T, TG;
 					issue(group_idx(kind, q0, ain), T);
+					constexpr bool kGapRoll = gapped.value && wc.value != RAGGED; // equal lengths: the spaced value itself rolls
+					if (kGapRoll) {
+						// the bases leaving / entering the don't-care block during the 4 steps of this group
+						const int32_t o1 = q0 - (int32_t)k + (int32_t)a.gap_first, o2 = o1 + (int32_t)a.gap;
+						const uint32_t* p1 = reinterpret_cast<const uint32_t*>(mine + (o1 & ~3));
+						const uint32_t* p2 = reinterpret_cast<const uint32_t*>(mine + (o2 & ~3));
+						const uint32_t w1 = alignbyte(p1[1], p1[0], (uint32_t)o1 & 3u);
+						const uint32_t w2 = alignbyte(p2[1], p2[0], (uint32_t)o2 & 3u);
+						uint32_t ig = (w1 & 0xc0c0c0c0u) | ((w2 >> 2) & 0x30303030u);
+						asm volatile("" : "+v"(ig));
+						TG.t[0] = *reinterpret_cast<const uint2*>(tabGb + (ig & 0xffu));
+						TG.t[1] = *reinterpret_cast<const uint2*>(tabGb + ((ig >> 8) & 0xffu));
+						TG.t[2] = *reinterpret_cast<const uint2*>(tabGb + ((ig >> 16) & 0xffu));
+						TG.t[3] = *reinterpret_cast<const uint2*>(tabGb + (ig >> 24));
+					}
+					auto step = [&](int b) {
+						if (kGapRoll)
+							roll2(T.t[b], TG.t[b]);
+						else
+							roll(T.t[b]);
+					};
 					uint64_t fixm = 0;
 					if (wc.value == DIRTY) fixm = ballot((ain & 0x01010101u) != 0u);
 					if (wc.value == RAGGED) // lanes that are shut off never trigger the extra work
@@ -468,7 +499,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 						}
 #pragma unroll
 						for (int b = 0; b < 4; ++b) {
-							roll(T.t[b]);
+							step(b);
 							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
 						}
 					} else if (wc.value == RAGGED && fix) {
@@ -478,13 +509,13 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 						for (int b = 0; b < 4; ++b) {
 							on_end(q0 + b);
 							if ((ain >> (8 * b)) & 1u) on_mark(q0 + b);
-							roll(T.t[b]);
+							step(b);
 							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
 						}
 					} else {
 #pragma unroll
 						for (int b = 0; b < 4; ++b) {
-							roll(T.t[b]);
+							step(b);
 							if (kind.value != FILL) record(q0 + b, kind.value == MAIN || q0 + b >= (int32_t)k - 1);
 						}
 					}
@@ -497,10 +528,16 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 					if (ain & 1u) on_mark(q);
 				}
 				const uint32_t off = (ain & 0xc0u) | (q >= (int32_t)k ? ((mine[q - (int32_t)k] >> 2) & 0x30u) : 0u);
-				roll(*reinterpret_cast<const uint2*>(tabHb + off));
+				if (gapped.value && wc.value != RAGGED) { // only reached with q >= k (closed-form start)
+					const int32_t o1 = q - (int32_t)k + (int32_t)a.gap_first;
+					const uint32_t og = (mine[o1] & 0xc0u) | ((mine[o1 + (int32_t)a.gap] >> 2) & 0x30u);
+					roll2(*reinterpret_cast<const uint2*>(tabHb + off), *reinterpret_cast<const uint2*>(tabGb + og));
+				} else {
+					roll(*reinterpret_cast<const uint2*>(tabHb + off));
+				}
 				record(q, q >= (int32_t)k - 1);
 			};
-			if (wc.value != RAGGED && !gapped.value) {
+			if (wc.value != RAGGED) {
 				// Equal-length waves skip the k-1 window-filling steps: the H halves of window 0 come from the closed
 				// form over the first k bases (the resolve stage's pair table, 2 bases per lookup), which costs about
 				// half of rolling them in and far less for large k.  Steps k .. A-1 (A = k rounded up to a group

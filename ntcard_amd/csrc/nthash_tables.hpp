@@ -137,4 +137,21 @@ inline void build_gap_table(unsigned k, unsigned gap_first, unsigned gap, uint32
 			}
 }
 
+// Rolling form of the spaced seed (equal-length waves): shifting the window by one base changes four terms — the
+// incoming and outgoing base (the ordinary step table) plus the base that leaves the don't-care block at its low
+// end (a, window index gap_first -> gap_first-1, now cared for) and the one that enters it at its high end
+// (b, index gap_first+gap -> gap_first+gap-1).  Entry (a, b): {f, r} H halves (Hd layout) of
+//   f: srol^(k-gap_first)(seed(a)) ^ srol^(k-gap_first-gap)(seed(b))        (XORed in after the forward rotate)
+//   r: srol^(gap_first)(comp(a))   ^ srol^(gap_first+gap)(comp(b))          (XORed in before the reverse rotate)
+inline void build_gap_roll_table(unsigned k, unsigned gap_first, unsigned gap, uint32_t out[16][2])
+{
+	for (unsigned a = 0; a < 4; ++a)
+		for (unsigned b = 0; b < 4; ++b) {
+			const uint64_t f = srol(seed_of(a), k - gap_first) ^ srol(seed_of(b), k - gap_first - gap);
+			const uint64_t r = srol(comp_of(a), gap_first) ^ srol(comp_of(b), gap_first + gap);
+			out[a * 4 + b][0] = hd_of(f);
+			out[a * 4 + b][1] = hd_of(r);
+		}
+}
+
 } // namespace ntc
