@@ -73,8 +73,11 @@ int ntc_reset(ntc_engine *e);                    /* re-zero sketch and F1 */
 /* ntRead/stRead for a batch of sequences (ntcard.cpp:147-171).  HOST buffers:
  * bases = concatenated raw sequence bytes exactly as the parsers produced them (any case, any
  * IUPAC/N byte), offsets[n_reads+1] delimits read i = bases[offsets[i], offsets[i+1]).
- * The engine copies what it needs before returning (caller keeps ownership).  Thread-safe:
- * may be called concurrently from several parser threads like the reference's seam.            */
+ * The engine copies what it needs before returning (caller keeps ownership): reads are packed
+ * into one of a few pinned staging buffers, then copy + kernels are queued on the engine's
+ * stream; device-side errors surface at ntc_sync/ntc_finish.  Thread-safe: may be called
+ * concurrently from several parser threads like the reference's seam (packing runs in parallel,
+ * only the enqueue is serialised).                                                             */
 int ntc_submit(ntc_engine *e, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 
 /* Same for a batch that is already DEVICE-resident in the engine's slot layout: read i occupies

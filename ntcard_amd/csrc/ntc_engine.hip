@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -182,12 +183,23 @@ struct ntc_engine {
 	void* d_gapt = nullptr;      // spaced seed: filter table of the don't-care positions
 	std::vector<void*> d_t1;     // per k: closed-form table of the H-filter kernel's resolve stage
 	// host-submit staging (grow-only)
-	unsigned char* h_stage = nullptr;
-	uint32_t* h_meta = nullptr;
-	size_t h_stage_cap = 0, h_meta_cap = 0;
-	unsigned char* d_stage = nullptr;
-	uint32_t* d_meta = nullptr;
-	size_t d_stage_cap = 0, d_meta_cap = 0;
+	// ntc_submit staging: a small pool of pinned host + device buffer pairs.  A caller packs its reads into a free
+	// pair WITHOUT holding the engine lock (the reference's per-file parser threads pack in parallel), then enqueues
+	// copy + kernels under the lock; `done` marks the point on the stream after which the pair may be reused.
+	struct StageSlot {
+		unsigned char* h_stage = nullptr;
+		uint32_t* h_meta = nullptr;
+		size_t h_stage_cap = 0, h_meta_cap = 0;
+		unsigned char* d_stage = nullptr;
+		uint32_t* d_meta = nullptr;
+		size_t d_stage_cap = 0;
+		hipEvent_t done = nullptr;
+		bool busy = false, used = false;
+	};
+	static constexpr int kStageSlots = 4;
+	StageSlot stage[kStageSlots];
+	std::mutex stage_mu;
+	std::condition_variable stage_cv;
 	std::mutex mu;
 	// profiling of the hash kernel (HIP events on the engine stream)
 	bool profiling = false;
@@ -466,10 +478,13 @@ void ntc_destroy(ntc_engine* e)
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);
-	if (e->d_stage) (void)hipFree(e->d_stage);
-	if (e->d_meta) (void)hipFree(e->d_meta);
-	if (e->h_stage) (void)hipHostFree(e->h_stage);
-	if (e->h_meta) (void)hipHostFree(e->h_meta);
+	for (auto& sl : e->stage) {
+		if (sl.d_stage) (void)hipFree(sl.d_stage);
+		if (sl.d_meta) (void)hipFree(sl.d_meta);
+		if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+		if (sl.h_meta) (void)hipHostFree(sl.h_meta);
+		if (sl.done) (void)hipEventDestroy(sl.done);
+	}
 	delete e;
 }
 
@@ -532,47 +547,74 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 			n_slots += l <= cap_chunk ? 1 : (l - (kmax - 1) + ch - 1) / ch;
 		}
 	}
-	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	// previous batch may still be reading the staging buffers
-	HIP_TRY(hipStreamSynchronize(e->stream));
+	// ---- take a staging pair; wait (this thread only) until the GPU is done with its previous contents ----
+	ntc_engine::StageSlot* sl = nullptr;
+	{
+		std::unique_lock<std::mutex> lk(e->stage_mu);
+		e->stage_cv.wait(lk, [&] {
+			for (auto& c : e->stage)
+				if (!c.busy) return true;
+			return false;
+		});
+		for (auto& c : e->stage)
+			if (!c.busy) {
+				sl = &c;
+				break;
+			}
+		sl->busy = true;
+	}
+	struct Release {
+		ntc_engine* e;
+		ntc_engine::StageSlot* sl;
+		~Release()
+		{
+			{
+				std::lock_guard<std::mutex> lk(e->stage_mu);
+				sl->busy = false;
+			}
+			e->stage_cv.notify_one();
+		}
+	} release{e, sl};
+	if (sl->done == nullptr) HIP_TRY(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+	if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));
 	const size_t need = (size_t)n_slots * stride + 16;
-	if (need > e->h_stage_cap) {
-		if (e->h_stage) (void)hipHostFree(e->h_stage);
-		e->h_stage = nullptr;
-		size_t cap = std::max(need, e->h_stage_cap * 2);
-		if (hipHostMalloc((void**)&e->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
-			e->h_stage_cap = 0;
+	if (need > sl->h_stage_cap) {
+		if (sl->h_stage) (void)hipHostFree(sl->h_stage);
+		sl->h_stage = nullptr;
+		size_t cap = std::max(need, sl->h_stage_cap * 2);
+		if (hipHostMalloc((void**)&sl->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
+			sl->h_stage_cap = 0;
 			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot pin %zu B", cap);
 		}
-		e->h_stage_cap = cap;
+		sl->h_stage_cap = cap;
 	}
-	if (need > e->d_stage_cap) {
-		if (e->d_stage) (void)hipFree(e->d_stage);
-		e->d_stage = nullptr;
-		size_t cap = std::max(need, e->d_stage_cap * 2);
-		if (hipMalloc((void**)&e->d_stage, cap) != hipSuccess) {
-			e->d_stage_cap = 0;
+	if (need > sl->d_stage_cap) {
+		if (sl->d_stage) (void)hipFree(sl->d_stage);
+		sl->d_stage = nullptr;
+		size_t cap = std::max(need, sl->d_stage_cap * 2);
+		if (hipMalloc((void**)&sl->d_stage, cap) != hipSuccess) {
+			sl->d_stage_cap = 0;
 			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot allocate %zu B on device", cap);
 		}
-		e->d_stage_cap = cap;
+		sl->d_stage_cap = cap;
 	}
 	const bool need_meta = chunked || !uniform;
-	if (need_meta && n_slots > e->h_meta_cap) {
-		if (e->h_meta) (void)hipHostFree(e->h_meta);
-		if (e->d_meta) (void)hipFree(e->d_meta);
-		e->h_meta = nullptr;
-		e->d_meta = nullptr;
-		size_t cap = std::max<size_t>(n_slots, e->h_meta_cap * 2);
-		if (hipHostMalloc((void**)&e->h_meta, cap * 4, hipHostMallocDefault) != hipSuccess ||
-		    hipMalloc((void**)&e->d_meta, cap * 4) != hipSuccess) {
-			e->h_meta_cap = 0;
+	if (need_meta && n_slots > sl->h_meta_cap) {
+		if (sl->h_meta) (void)hipHostFree(sl->h_meta);
+		if (sl->d_meta) (void)hipFree(sl->d_meta);
+		sl->h_meta = nullptr;
+		sl->d_meta = nullptr;
+		size_t cap = std::max<size_t>(n_slots, sl->h_meta_cap * 2);
+		if (hipHostMalloc((void**)&sl->h_meta, cap * 4, hipHostMallocDefault) != hipSuccess ||
+		    hipMalloc((void**)&sl->d_meta, cap * 4) != hipSuccess) {
+			sl->h_meta_cap = 0;
 			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot allocate slot metadata");
 		}
-		e->h_meta_cap = cap;
+		sl->h_meta_cap = cap;
 	}
 	// ---- pack (the copy the ABI promises: caller's buffers are free on return) ----
-	unsigned char* hs = e->h_stage;
+	unsigned char* hs = sl->h_stage;
 	uint64_t slot = 0;
 	for (uint64_t i = 0; i < n_reads; ++i) {
 		const uint64_t l = offsets[i + 1] - offsets[i];
@@ -581,7 +623,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src, l);
 			std::memset(dst + l, 'A', stride - l);
-			if (need_meta) e->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
+			if (need_meta) sl->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
 			++slot;
 			continue;
 		}
@@ -590,7 +632,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src, l);
 			std::memset(dst + l, 'A', stride - l);
-			e->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
+			sl->h_meta[slot] = (uint32_t)l | ((uint32_t)l << 16);
 			++slot;
 			continue;
 		}
@@ -600,18 +642,22 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src + start, nbytes);
 			std::memset(dst + nbytes, 'A', stride - nbytes);
-			e->h_meta[slot] = (uint32_t)nbytes | ((uint32_t)(last ? nbytes : ch) << 16);
+			sl->h_meta[slot] = (uint32_t)nbytes | ((uint32_t)(last ? nbytes : ch) << 16);
 			++slot;
 			if (last) break;
 		}
 	}
 	if (slot != n_slots) return fail(NTC_ERR_STATE, "ntc_submit: internal slot plan mismatch (%llu != %llu)", (unsigned long long)slot, (unsigned long long)n_slots);
-	HIP_TRY(hipMemcpyAsync(e->d_stage, hs, (size_t)n_slots * stride, hipMemcpyHostToDevice, e->stream));
-	if (need_meta) HIP_TRY(hipMemcpyAsync(e->d_meta, e->h_meta, n_slots * 4, hipMemcpyHostToDevice, e->stream));
-	int rc = run_batch(e, e->d_stage, need_meta ? e->d_meta : nullptr, n_slots, (uint32_t)len0, stride);
-	if (rc) return rc;
-	// the pinned staging buffer is reused by the next call; the device copy is ordered on the stream
-	HIP_TRY(hipStreamSynchronize(e->stream));
+	// ---- enqueue: copy + kernels, in order on the engine's stream (asynchronous; ntc_sync / ntc_finish wait) ----
+	{
+		std::lock_guard<std::mutex> lk(e->mu);
+		HIP_TRY(hipMemcpyAsync(sl->d_stage, hs, (size_t)n_slots * stride, hipMemcpyHostToDevice, e->stream));
+		if (need_meta) HIP_TRY(hipMemcpyAsync(sl->d_meta, sl->h_meta, n_slots * 4, hipMemcpyHostToDevice, e->stream));
+		int rc = run_batch(e, sl->d_stage, need_meta ? sl->d_meta : nullptr, n_slots, (uint32_t)len0, stride);
+		if (rc) return rc;
+		HIP_TRY(hipEventRecord(sl->done, e->stream));
+		sl->used = true;
+	}
 	return 0;
 }
 

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""tools/ragged_time.py — K1 time on host-submitted batches: equal-length vs variable-length reads (same total bases)"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import orc
+import ntcard_amd as nt
+n, L = 2_000_000, 150
+slots = orc.gen_reads(3, 0, n, L, 152, 1, genome_len=100_000_000).reshape(n, 152)
+rng = np.random.default_rng(1)
+for name, lens in (("equal 150", np.full(n, 150)), ("95% 150, 5% shorter", np.where(rng.random(n) < 0.95, 150, rng.integers(50, 150, n))),
+                   ("uniform 100..150", rng.integers(100, 151, n))):
+    offs = np.zeros(n + 1, dtype=np.uint64); offs[1:] = np.cumsum(lens)
+    bases = np.empty(int(offs[-1]), dtype=np.uint8)
+    idx = np.arange(152)[None, :] < lens[:, None]
+    bases[:] = slots[idx]
+    with nt.Engine([32], r_bits=27, s_bits=7) as e:
+        e.set_profiling(True)
+        e.submit(bases, offs)
+        e.sync()
+        ms, launches = e.kernel_time()
+        _, _, f1 = e.finish(counters=False, p_hist=True)
+    print("%-22s kernel %.3f ms for %d k-mers -> %.1f G k-mers/s" % (name, ms, int(f1[0]), f1[0] / ms / 1e6))
