@@ -217,6 +217,25 @@ def test_gap_seeds_match_oracle(nt, k, gap):
     assert np.array_equal(tc, oc)
 
 
+@pytest.mark.parametrize("L,k,gap", [
+    (150, 12, 2), (150, 13, 3), (150, 20, 8), (150, 32, 8), (151, 33, 1), (149, 31, 29), (150, 64, 10), (70, 12, 4),
+    (250, 32, 0), (1000, 32, 0), (1000, 33, 5), (32, 32, 0), (33, 32, 0), (35, 32, 0), (36, 32, 0), (37, 33, 0),
+    (31, 32, 0), (40, 12, 2), (13, 12, 2), (12, 12, 2), (163, 150, 0), (64, 61, 0), (68, 64, 0), (300, 200, 0),
+])
+def test_equal_length_batches_match_oracle(nt, L, k, gap):
+    """equal-length waves take the closed-form start and (with -g) the rolling spaced-seed step; shapes around the
+    group / block boundaries, staging without register prefetch (long slots), reads shorter than k"""
+    rng = random.Random(L * 1000 + k * 7 + gap)
+    reads = [rseq(rng, L, pn=rng.choice([0, 0, 0.003, 0.02])) for _ in range(3000)]
+    with nt.Engine([k], gap=gap, r_bits=18, s_bits=5) as e:
+        e.submit_reads(reads[:1000])
+        e.submit_reads(reads[1000:])
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads(reads, [k], gap, 18, 5)
+    assert np.array_equal(f1, of1)
+    assert np.array_equal(tc, oc)
+
+
 def test_golden_gap_hist_from_reference(nt, golden_dir, tmp_path):
     """the reference CLI's `-k 12 -g 2` output (the shape of its own check-dna-gap target, Makefile.am:53-54,71-72)"""
     reads = small_reads(golden_dir)
