@@ -99,6 +99,11 @@ int ntc_sync(ntc_engine *e); /* wait for all submitted work */
 int ntc_finish(ntc_engine *e, uint16_t *t_counter_out, uint32_t *p_hist_out, uint64_t *f1_out);
 
 /* Device pointers of the live sketch / F1 (for a host framework's collective) */
+/* Sketch load / merge: adds a t_Counter image dumped by ntc_finish (same k list, r_bits;
+ * uint16 [n_k][2][1<<r_bits]) and its F1 values (may be NULL) into this engine.  Counting is a commutative sum
+ * mod 2^16 (ntcard.cpp:142-143), so runs split across processes, nodes or days merge exactly.               */
+int ntc_merge_counters(ntc_engine *e, const uint16_t *t_counter, const uint64_t *f1);
+
 int ntc_device_state(ntc_engine *e, void **d_sketch_u32, uint64_t *n_counters, void **d_f1_u64);
 
 /* Validation kernel (K1d): canonical hash of every window of ONE k for a device-resident slot

@@ -699,6 +699,32 @@ int ntc_finish(ntc_engine* e, uint16_t* t_counter_out, uint32_t* p_hist_out, uin
 	return drain_events(e);
 }
 
+int ntc_merge_counters(ntc_engine* e, const uint16_t* t_counter, const uint64_t* f1)
+{
+	if (!e || !t_counter) return fail(NTC_ERR_ARG, "ntc_merge_counters: null argument");
+	if (e->hll_bits) return fail(NTC_ERR_STATE, "ntc_merge_counters: not for an nthll engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	const size_t nk = e->klist.size();
+	const uint64_t per_k = e->plane_elems(); // counters per k (both samples)
+	if (!e->d_out16 && hipMalloc((void**)&e->d_out16, per_k * sizeof(uint16_t)) != hipSuccess)
+		return fail(NTC_ERR_MEMORY, "ntc_merge_counters: cannot allocate uint16 staging");
+	for (size_t ki = 0; ki < nk; ++ki) {
+		HIP_TRY(hipMemcpyAsync(e->d_out16, t_counter + ki * per_k, per_k * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(ntc::launch_add_counters(e->d_sketch + ki * per_k, e->d_out16, per_k, e->stream));
+	}
+	if (f1) {
+		std::vector<unsigned long long> cur(nk);
+		HIP_TRY(hipMemcpyAsync(cur.data(), e->d_f1, nk * 8, hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		for (size_t ki = 0; ki < nk; ++ki)
+			cur[ki] += f1[ki];
+		HIP_TRY(hipMemcpyAsync(e->d_f1, cur.data(), nk * 8, hipMemcpyHostToDevice, e->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
 int ntc_device_state(ntc_engine* e, void** d_sketch_u32, uint64_t* n_counters, void** d_f1_u64)
 {
 	if (!e) return fail(NTC_ERR_ARG, "ntc_device_state: null engine");

@@ -408,6 +408,24 @@ hipError_t set_hash_smem_limit(size_t smem)
 	                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
+// merge of a dumped sketch: sketch[i] += add16[i]; the uint16 wrap happens at finalize
+__global__ __launch_bounds__(256) void add_counters_kernel(uint32_t* __restrict__ sketch, const uint16_t* __restrict__ add16, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t v = reinterpret_cast<const uint32_t*>(add16)[i];
+		uint2 s = reinterpret_cast<uint2*>(sketch)[i];
+		s.x += v & 0xffffu;
+		s.y += v >> 16;
+		reinterpret_cast<uint2*>(sketch)[i] = s;
+	}
+}
+
+hipError_t launch_add_counters(uint32_t* sketch, const uint16_t* add16, uint64_t n, hipStream_t st)
+{
+	hipLaunchKernelGGL(add_counters_kernel, dim3(4096), dim3(256), 0, st, sketch, add16, n);
+	return hipGetLastError();
+}
+
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
                            uint16_t* out16, hipStream_t st)
 {

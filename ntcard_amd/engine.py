@@ -97,6 +97,13 @@ class Engine:
         check(self._lib.ntc_finish(self._h, _np_ptr(tc) if counters else None, _np_ptr(ph) if p_hist else None, _np_ptr(f1)))
         return tc, ph, f1
 
+    def merge_counters(self, t_counter, f1=None):
+        """add a dumped t_Counter image (uint16[nk,2,2^r], from finish(counters=True)) and its F1 into this engine"""
+        tc = np.ascontiguousarray(t_counter, dtype=np.uint16)
+        assert tc.size == len(self.klist) * (2 << self.r_bits)
+        f = np.ascontiguousarray(f1, dtype=np.uint64) if f1 is not None else None
+        check(self._lib.ntc_merge_counters(self._h, _np_ptr(tc), _np_ptr(f) if f is not None else None))
+
     def device_state(self):
         sk, n, f1 = C.c_void_p(), C.c_uint64(), C.c_void_p()
         check(self._lib.ntc_device_state(self._h, C.byref(sk), C.byref(n), C.byref(f1)))

@@ -261,6 +261,25 @@ def test_uint16_wraparound(nt):
     assert int(ph[0].sum()) == 2 << 12
 
 
+def test_sketch_dump_and_merge(nt):
+    """§8(f)-3: a dumped t_Counter image merged into another engine == one run over all reads (mod 2^16)"""
+    rng = random.Random(5)
+    reads = [rseq(rng, rng.choice([60, 100, 150]), pn=0.01) for _ in range(6000)]
+    klist = [16, 33]
+    with nt.Engine(klist, r_bits=16, s_bits=3) as a:
+        a.submit_reads(reads[:2500])
+        tc_a, _, f1_a = a.finish(counters=True)
+    with nt.Engine(klist, r_bits=16, s_bits=3) as b:
+        b.submit_reads(reads[2500:])
+        b.merge_counters(tc_a, f1_a)
+        b.submit_reads([])
+        tc, ph, f1 = b.finish(counters=True)
+    oc, of1 = orc.sketch_reads(reads, klist, 0, 16, 3)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+    for ki in range(len(klist)):
+        assert np.array_equal(ph[ki], orc.value_hist(oc[ki], 16))
+
+
 def test_batching_order_and_reset_invariance(nt):
     """results do not depend on batch boundaries or submit order (commutative atomics)"""
     n, L, stride = 50_000, 150, 152
