@@ -106,7 +106,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # any torch.distributed.run launch
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -148,13 +149,13 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(W):
         eng.submit_device(wb.data_ptr(), R, L, stride)
-    if world > 1 and W > 0:  # warm the RCCL path too
+    if use_dist and W > 0:  # warm the RCCL path too
         parallel.reduce_sketch(sketch, f1_dev, dst=0)
     eng.sync()
     eng.reset()
@@ -169,7 +170,7 @@ def main():
     dt = time.perf_counter() - t0
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
@@ -227,7 +228,7 @@ def main():
                                        "sample": f"failed: {ex}"}
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -29,7 +29,7 @@ def split_reads(n_reads, world):
 
 def reduce_sketch(sketch, f1, dst=0):
     """in-place SUM reduce of the sketch (int32 view of uint32 counters) and F1 (int64) to rank dst"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(sketch, dst=dst, op=dist.ReduceOp.SUM)
         dist.reduce(f1, dst=dst, op=dist.ReduceOp.SUM)
     return sketch, f1
@@ -38,7 +38,7 @@ def reduce_sketch(sketch, f1, dst=0):
 def reduce_hll(regs, f1, dst=0):
     """in-place MAX reduce of nthll's register file (any integer tensor) and SUM of F1 to rank dst.
     The reference merges its per-thread register files the same way (nthll.cpp:240-245)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(regs, dst=dst, op=dist.ReduceOp.MAX)
         dist.reduce(f1, dst=dst, op=dist.ReduceOp.SUM)
     return regs, f1
