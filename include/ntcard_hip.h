@@ -84,7 +84,9 @@ int ntc_submit(ntc_engine *e, const char *bases, const uint64_t *offsets, uint64
  * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Padding bytes
  * (read_len..stride) are never hashed; filling them with a base letter ('A') keeps the kernel on
  * its fast path (a non-ACGTU byte anywhere in a wave's 64 slots selects the dirty-window path).
- * Asynchronous on the engine's stream; the buffer must stay valid until ntc_sync/ntc_finish.    */
+ * Asynchronous on the engine's stream; the buffer must stay valid until ntc_sync/ntc_finish.
+ * A wave parks its 64 slots in LDS, so stride is limited to about 2.4 KB (64 * stride + tables <= 160 KiB);
+ * longer sequences go through ntc_submit, which splits them into overlapping chunks.            */
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
                       uint32_t stride);
 
