@@ -9,13 +9,18 @@
 //     min(fh, rh); those bits live in the 31-bit rotating half H of the hash (nthash.hpp:186-217), and
 //     H rolls independently of the 33-bit half.  The per-base loop therefore rolls ONLY the two H
 //     halves (3 VALU ops each, one ds_read_b64 of seed terms) and tests min(fHd, rHd);
-//   * a lane that sees a sampled window just sets bit (step & 31) of a mask register (compacted
-//     every 32 steps): one VALU op, no memory traffic;
-//   * after the read, the wave compacts the (lane, step) pairs and 64 lanes at a time recompute the
-//     full 64-bit forward and reverse hashes of those windows from the closed form
+//   * a lane that sees a sampled window just shifts a 1 into a mask register (one v_addc): no branch, no
+//     memory traffic;
+//   * every 32 steps the wave queues the sampled (lane, step) pairs (one register per lane, filled through
+//     ds_permute) and, 64 pairs at a time, recomputes the full 64-bit forward and reverse hashes of those windows
+//     from the closed form
 //     fh = XOR_i srol^(k-1-i)(seed(c_i)), rh = XOR_i srol^i(comp(c_i))      (nthash.hpp:220-239)
-//     with a ceil(k/2) x 16 table of pre-rotated seed PAIRS in LDS (two bases per lookup), take the canonical min (nthash.hpp:275-279),
-//     and update the sketch.  Full 64-bit compare: exact, no tie special case.
+//     with a ceil(k/2) x 16 table of pre-rotated seed PAIRS in LDS (two bases per lookup), takes the canonical
+//     min (nthash.hpp:275-279) and updates the sketch.  Full 64-bit compare: exact, no tie special case;
+//   * equal-length waves start from the same closed form instead of rolling the k-1 window-filling steps; up to
+//     four values of k share one launch (the batch is staged and decoded once); spaced seeds roll the spaced
+//     value itself; nthll swaps the sample test for a register threshold.  LDS holds nothing but the decoded
+//     slots and the tables, which is what lets 16 waves of 150 bp reads share a CU.
 //
 // Semantics reproduced: ntRead (ntcard.cpp:147-158), ntHashIterator (ntHashIterator.hpp:59-86),
 // NTMC64 (nthash.hpp:381-390,467-492), ntComp (ntcard.cpp:132-145).
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(1024) void sketch_hf_kernel(const HfArgs a)
 
 		// Sampled steps are recorded without a branch: every step from the first non-FILL group on shifts
 		// the lane's mask left and shifts the wave's "sampled" condition in as carry (one v_addc_co_u32);
-		// after 32 steps the mask is parked in LDS.  Step q of block b sits at bit (steps_in_block-1-(q-q_b)).
+		// after 32 steps the mask is compacted into the resolve queue.  The block's last step sits at bit 0.
 		auto push = [&](uint64_t m) { asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(hmask), "+s"(m)); };
 		const int32_t qs = e0 << 2; // first step that is recorded
 		uint32_t f1_lane = 0;       // DIRTY / RAGGED: clean windows of this lane (accumulated on the rare path)
