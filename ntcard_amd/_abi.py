@@ -63,7 +63,8 @@ def lib():
     L.ntc_submit_device.argtypes = [p, p, u64, u32, u32]
     L.ntc_sync.argtypes = [p]
     L.ntc_finish.argtypes = [p, p, p, p]
-    L.ntc_merge_counters.argtypes = [p, p, p]
+    if hasattr(L, "ntc_merge_counters") or not os.environ.get("NTCARD_HIP_LIB"):  # A/B builds of older sources may lack it
+        L.ntc_merge_counters.argtypes = [p, p, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_gen_reads_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u32, u64]
@@ -75,6 +76,8 @@ def lib():
     L.ntc_hll_finish.argtypes = [p, p, p]
     L.ntc_hll_estimate.argtypes = [p, u32, C.POINTER(C.c_double)]
     for name in ABI_SYMBOLS:
+        if os.environ.get("NTCARD_HIP_LIB") and not hasattr(L, name):
+            continue  # A/B build of an older source
         fn = getattr(L, name)
         if name not in ("ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_destroy"):
             fn.restype = C.c_int

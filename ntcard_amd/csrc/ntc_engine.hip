@@ -106,38 +106,72 @@ void fill_hfk(ntc::HfK& o, uint32_t k, uint32_t* sketch, unsigned long long* f1,
 		o.tabh[slot][1] = tab.A[slot][3];
 	}
 }
+// block shape only (no device call): waves per CU and waves per block for a slot stride, 0 waves = does not fit
+void hf_shape(uint32_t stride, const uint32_t* ks, uint32_t n_k, uint32_t gap, HfPlan& p, size_t& shared_out);
+
 int hf_plan(int dev, uint64_t n_slots, uint32_t stride, const uint32_t* ks, uint32_t n_k, uint32_t gap, HfPlan& p)
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
+	size_t shared = 0;
+	hf_shape(stride, ks, n_k, gap, p, shared);
+	if (p.waves_per_cu == 0)
+		return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs more than 160 KiB of LDS per wave", stride, ks[0]);
+	p.smem = shared + p.wpb * (64u * (size_t)stride);
+	HIP_TRY(ntc::set_sketch_hf_smem_limit(p.smem));
+	const unsigned per_cu = std::max(1u, p.waves_per_cu / p.wpb);
+	const uint64_t need = (n_slots + 64ull * p.wpb - 1) / (64ull * p.wpb);
+	p.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)di.cus * per_cu));
+	return 0;
+}
+
+void hf_shape(uint32_t stride, const uint32_t* ks, uint32_t n_k, uint32_t gap, HfPlan& p, size_t& shared_out)
+{
 	const size_t per_wave = 64u * (size_t)stride; // the wave's 64 decoded slots; hit masks and the compaction queue are registers
 	size_t shared = 16 + (size_t)((gap + 1u) / 2u) * 256u;
 	for (uint32_t j = 0; j < n_k; ++j)
 		shared += (size_t)ntc::t2_pairs(ks[j]) * 256u; // the closed-form tables of every fused k are resident
-	const size_t cap = 160 * 1024, fixed = 1024 + 1024; // static LDS of the kernel (step tables of up to 4 k) + allocation slack // static LDS of the kernel + allocation granularity slack
+	// A workgroup's LDS (dynamic + the kernel's static tables) is allocated in granules of 1280 B, 128 of them per
+	// CU (measured: 3 blocks of 43 granules do not co-reside, 3 of 42 do).  A plan that overestimates the resident
+	// blocks leaves part of the persistent grid waiting for a second round, which costs far more than a wave less.
+	const size_t granule = 1280, granules_per_cu = 128, static_lds = 1024 + 256 + 64;
 	unsigned best_waves = 0;
 	static const int force_wpb = std::getenv("NTC_WPB") ? std::atoi(std::getenv("NTC_WPB")) : 0; // tuning experiments only
-	for (unsigned w = 1; w <= 16; ++w) {
-		if (force_wpb > 0 && (int)w != force_wpb) continue;
-		// whole multiples of the 4 SIMDs keep them evenly loaded (measured: 6 or 13 waves per block cost 5-12 %)
-		if (force_wpb == 0 && w > 4 && (w & 3u) != 0) continue;
-		const size_t blk = shared + w * per_wave + fixed;
-		if (blk > cap) break;
-		const unsigned waves = std::min<unsigned>(16, (unsigned)(cap / blk) * w); // 128 VGPRs: 4 waves per SIMD
+	auto consider = [&](unsigned w) {
+		const size_t alloc = (shared + w * per_wave + static_lds + granule - 1) / granule;
+		if (alloc > granules_per_cu) return;
+		const unsigned waves = std::min<unsigned>(16, (unsigned)(granules_per_cu / alloc) * w); // 128 VGPRs: 4 waves per SIMD
 		if (waves >= best_waves) { // ties: the larger block (fewer table copies)
 			best_waves = waves;
 			p.wpb = w;
 		}
+	};
+	if (force_wpb > 0) {
+		consider((unsigned)force_wpb);
+	} else {
+		// whole multiples of the 4 SIMDs keep them evenly loaded (measured: 6 or 13 waves per block cost 5-12 %,
+		// 3 blocks of 3 waves lose to 2 blocks of 4); smaller blocks only when not even 4 waves fit
+		for (unsigned w = 4; w <= 16; w += 4)
+			consider(w);
+		for (unsigned w = 3; best_waves == 0 && w >= 1; --w)
+			consider(w);
 	}
-	if (best_waves == 0)
-		return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs more than 160 KiB of LDS per wave", stride, ks[0]);
-	p.smem = shared + p.wpb * per_wave;
 	p.waves_per_cu = best_waves;
-	HIP_TRY(ntc::set_sketch_hf_smem_limit(p.smem));
-	const unsigned per_cu = std::max(1u, best_waves / p.wpb);
-	const uint64_t need = (n_slots + 64ull * p.wpb - 1) / (64ull * p.wpb);
-	p.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)di.cus * per_cu));
-	return 0;
+	shared_out = shared;
+}
+
+// Slot stride the host packer uses for reads of up to `maxlen` bytes: a multiple of 4; an ODD number of dwords keeps
+// the 64 lanes of a wave on distinct LDS banks when they read the same column of their slots (160 B = 40 dwords is
+// an 8-way conflict: 1.54 vs ~1.2 ms per 10 M reads), taken whenever it does not cost a wave of occupancy.
+uint32_t pick_stride(uint64_t maxlen, const std::vector<uint32_t>& klist, uint32_t gap)
+{
+	const uint32_t s0 = (uint32_t)((maxlen + 3) & ~3ull);
+	if ((s0 / 4) & 1u) return s0;
+	HfPlan a, b;
+	size_t sh;
+	hf_shape(s0, klist.data(), (uint32_t)std::min<size_t>(klist.size(), ntc::kMaxFusedK), gap, a, sh);
+	hf_shape(s0 + 4, klist.data(), (uint32_t)std::min<size_t>(klist.size(), ntc::kMaxFusedK), gap, b, sh);
+	return b.waves_per_cu >= a.waves_per_cu && b.waves_per_cu > 0 ? s0 + 4 : s0;
 }
 
 // grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
@@ -283,14 +317,21 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	}
 	if (kind == KIND_HF) {
 		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
-		// a group whose closed-form tables would push the CU below 12 waves is split in two
+		// a group whose closed-form tables would push the CU below 12 waves (and below what its members reach alone) is split in two
 		std::function<int(size_t, size_t)> launch_group = [&](size_t b, size_t n) -> int {
 			HfPlan hp;
 			if (int rc = hf_plan(e->device, n_slots, stride, &e->klist[b], (uint32_t)n, e->gap, hp)) {
 				if (n == 1) return rc;
 				hp.waves_per_cu = 0;
 			}
-			if (n > 1 && hp.waves_per_cu < 12) {
+			unsigned worst_single = 16; // waves per CU of the least favourable member launched on its own
+			for (size_t j = 0; n > 1 && j < n; ++j) {
+				HfPlan one;
+				size_t sh;
+				hf_shape(stride, &e->klist[b + j], 1, e->gap, one, sh);
+				worst_single = std::min(worst_single, one.waves_per_cu);
+			}
+			if (n > 1 && hp.waves_per_cu < 12 && hp.waves_per_cu < worst_single) {
 				if (int rc = launch_group(b, n / 2)) return rc;
 				return launch_group(b + n / 2, n - n / 2);
 			}
@@ -535,7 +576,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 	if (maxlen < kmin) return 0; // nothing can produce a k-mer (ntHashIterator.hpp:61-64)
 	const uint32_t cap_chunk = std::max<uint32_t>(kSlotCapMin, ((2 * kmax + 64) + 3) & ~3u);
 	const bool chunked = maxlen > cap_chunk;
-	const uint32_t stride = chunked ? cap_chunk : (uint32_t)((maxlen + 3) & ~3ull);
+	const uint32_t stride = pick_stride(chunked ? cap_chunk : maxlen, e->klist, e->gap);
 	const uint32_t ch = cap_chunk - (kmax - 1); // window starts per chunk
 	uint64_t n_slots = 0;
 	if (!chunked) {

@@ -68,6 +68,7 @@ hipError_t launch_sketch_fast(const HashArgs& a, unsigned grid, size_t smem, hip
 hipError_t set_sketch_fast_smem_limit(size_t smem);
 hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st);
 hipError_t set_sketch_hf_smem_limit(size_t smem);
+bool sketch_hf_deep_prefetch(uint32_t stride);
 hipError_t launch_hll_threshold(const uint32_t* regs, uint32_t n_regs, uint32_t* thr, hipStream_t st);
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
                            uint16_t* out16, hipStream_t st);
