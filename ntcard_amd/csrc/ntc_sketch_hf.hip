@@ -48,6 +48,14 @@ __device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
 	return __builtin_amdgcn_perm(s0, s1, sel);
 }
 
+// LDS by integer offset: lets a table address be formed with one v_and_or_b32 / SDWA v_or (index | aligned base)
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4u32* lds_v4_ptr;
+typedef __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
+__device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(lds_byte_ptr)p; }
+__device__ __forceinline__ v4u32 lds_read4(uint32_t off) { return *(lds_v4_ptr)(uintptr_t)off; }
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 // v_perm tables indexed by (byte & 7): 1:A 3:C 7:G 4:T 5:U, 0/2/6: not a base (nthash.hpp:16,32 trick)
 constexpr uint32_t kExpS0 = 0x47ff5554u; // 'G', ff, 'U', 'T'
 constexpr uint32_t kExpS1 = 0x43ff41ffu; // 'C', ff, 'A', ff
@@ -103,8 +111,7 @@ template <bool kMulti, int kMode, int kPref>
 __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(const HfArgs a)
 {
 	const uint32_t n_k = kMulti ? a.n_k : 1u;
-	// dynamic LDS: [16 B pad][waves x 64 x stride code bytes][ceil(k/2) x 256 B closed-form table][gap table]
-	// Nothing else lives in LDS: hit masks and the compaction queue stay in registers, so that a CU's 160 KiB
+	// Nothing but the tables and the decoded slots lives in LDS: hit masks and the compaction queue stay in registers, so that a CU's 160 KiB
 	// hold 16 waves of 150 bp reads (4 per SIMD) instead of 12.
 	extern __shared__ __align__(16) unsigned char smem[];
 	// static LDS: per-(in,out) seed terms of the H halves {Tf.Hd, Tr.Hd}, 16-byte stride (offset = idx byte)
@@ -123,9 +130,13 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	t1_off[0] = 0;
 	for (uint32_t j = 0; j < (uint32_t)kMaxFusedK; ++j)
 		t1_off[j + 1] = t1_off[j] + (j < n_k ? ((a.ks[j].k + 1u) >> 1) * 256u : 0u);
-	unsigned char* const wdata = smem + 16 + (size_t)wave * 64u * stride;
+	// dynamic LDS: [closed-form tables of every fused k][gap table][16 B pad][waves x 64 slots].  The tables come first:
+	// with 1280 B of static LDS in front they start 256-byte aligned, so `index | base` addresses them.
+	const uint32_t tables_bytes = t1_off[kMaxFusedK] + ((a.gap + 1u) >> 1) * 256u;
+	unsigned char* const wdata = smem + tables_bytes + 16 + (size_t)wave * 64u * stride;
 	const unsigned char* const mine = wdata + (size_t)lane * stride;
-	unsigned char* const t1_base = smem + 16 + (size_t)wpb * 64u * stride; // 16-byte aligned: stride % 4 == 0 -> 256*stride
+	unsigned char* const t1_base = smem;
+	if ((lds_off(smem) & 255u) != 0u) __builtin_trap(); // the static tables are sized to keep this aligned
 	unsigned char* t1 = t1_base;
 	// spaced seed (stRead, ntcard.cpp:160-171): per pair of don't-care positions, the H halves of the terms to XOR out
 	const uint32_t ngp = (a.gap + 1u) >> 1;
@@ -293,30 +304,29 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			const uint32_t* dp = reinterpret_cast<const uint32_t*>(wdata + (base & ~3u));
 			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0, dirty = 0;
 			uint32_t cur = dp[0];
-			const unsigned char* tp = t1;
+			uint32_t tp = lds_off(t1); // 256-byte aligned: a pair offset (a<<6 | b<<4) is OR-ed in
 			for (uint32_t i = 0; i < k; i += 4) {
 				const uint32_t nxt = dp[(i >> 2) + 1];
 				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes (code<<6) of window positions i..i+3
 				cur = nxt;
 				dirty |= i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k)))); // bit 0 of a byte: not ACGTU
-				// pair offsets (a<<6 | b<<4): bytes 0,1 and bytes 2,3; a base beyond k contributes nothing
-				// because the odd-k table drops the b term and positions >= k are never looked up
-				const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
-				const uint4 t0 = *reinterpret_cast<const uint4*>(tp + o0);
-				flo ^= t0.x;
-				fhi ^= t0.y;
-				rlo ^= t0.z;
-				rhi ^= t0.w;
+				// pair offsets of bytes (0,1) and (2,3) side by side in bytes 0 and 2 of y; a base beyond k contributes
+				// nothing because the odd-k table drops the b term and positions >= k are never looked up
+				const uint32_t y = (w & 0x00c000c0u) | ((w >> 10) & 0x00300030u);
+				const v4u32 t0 = lds_read4((y & 0xffu) | tp);
 				if (i + 2 < k) {
-					const uint32_t w2 = w >> 16;
-					const uint32_t o1 = (w2 & 0xc0u) | ((w2 >> 10) & 0x30u);
-					const uint4 t1v = *reinterpret_cast<const uint4*>(tp + 256 + o1);
-					flo ^= t1v.x;
-					fhi ^= t1v.y;
-					rlo ^= t1v.z;
-					rhi ^= t1v.w;
+					const v4u32 t1v = lds_read4((y >> 16) | (tp + 256u));
+					flo = xor3(flo, t0.x, t1v.x);
+					fhi = xor3(fhi, t0.y, t1v.y);
+					rlo = xor3(rlo, t0.z, t1v.z);
+					rhi = xor3(rhi, t0.w, t1v.w);
+				} else {
+					flo ^= t0.x;
+					fhi ^= t0.y;
+					rlo ^= t0.z;
+					rhi ^= t0.w;
 				}
-				tp += 512;
+				tp += 512u;
 			}
 			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
@@ -392,12 +402,15 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			uint32_t aout = 0;
 			if (kind.value == MAIN || q0 + 3 >= (int32_t)k) {
 				const uint32_t* p = reinterpret_cast<const uint32_t*>(mine + ((q0 - (int32_t)k) & ~3));
-				aout = alignbyte(p[1], p[0], shb); // shb == 0 returns p[0]; unconditional: no per-group branch
+				// one funnel shift aligns the outgoing bytes to the group AND moves their codes from bits 7:6 to 5:4
+				// (what spills over from the neighbouring bytes lands in bits 7:6 / 3:0..: 7:6 are replaced below, the
+				// low nibble of a code byte holds nothing but its mark in bit 0, which is shifted out of the byte)
+				aout = alignbit(p[1], p[0], 8u * shb + 2u);
 				if (kind.value == MIXED && q0 < (int32_t)k) aout &= 0xffffffffu << (8 * ((int32_t)k - q0));
 			}
-			// bits 7:6 of every byte from ain (incoming code), bits 5:4 from aout >> 2 (outgoing code): one v_bfi_b32
+			// bits 7:6 of every byte from ain (incoming code), bits 5:4 from the shifted outgoing code: one v_bfi_b32
 			constexpr uint32_t M = 0xc0c0c0c0u;
-			uint32_t idx4 = (ain & M) | ((aout >> 2) & ~M);
+			uint32_t idx4 = (ain & M) | (aout & ~M);
 			asm volatile("" : "+v"(idx4)); // keep it ONE v_bfi_b32: stops hipcc from re-deriving byte 0 with three more ops
 			return idx4;
 		};
@@ -484,8 +497,8 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 						const uint32_t* p1 = reinterpret_cast<const uint32_t*>(mine + (o1 & ~3));
 						const uint32_t* p2 = reinterpret_cast<const uint32_t*>(mine + (o2 & ~3));
 						const uint32_t w1 = alignbyte(p1[1], p1[0], (uint32_t)o1 & 3u);
-						const uint32_t w2 = alignbyte(p2[1], p2[0], (uint32_t)o2 & 3u);
-						uint32_t ig = (w1 & 0xc0c0c0c0u) | ((w2 >> 2) & 0x30303030u);
+						const uint32_t w2 = alignbit(p2[1], p2[0], 8u * ((uint32_t)o2 & 3u) + 2u); // aligned and >> 2 in one funnel shift
+						uint32_t ig = (w1 & 0xc0c0c0c0u) | (w2 & 0x3f3f3f3fu);
 						asm volatile("" : "+v"(ig));
 						TG.t[0] = *reinterpret_cast<const uint2*>(tabGb + (ig & 0xffu));
 						TG.t[1] = *reinterpret_cast<const uint2*>(tabGb + ((ig >> 8) & 0xffu));
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				if (maxq >= (int32_t)k) {
 					uint32_t fhi = 0, rhi = 0;
 					const uint32_t* dp = reinterpret_cast<const uint32_t*>(mine);
-					const unsigned char* tp = t1;
+					uint32_t tp = lds_off(t1);
 					for (uint32_t i = 0; i < k; i += 4) {
 						const uint32_t w = dp[i >> 2];
 						if (wc.value == DIRTY) { // marks among the first k bases only feed F1 (rare divergent region)
@@ -573,18 +586,17 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 									mk &= mk - 1u;
 								}
 						}
-						const uint32_t o0 = (w & 0xc0u) | ((w >> 10) & 0x30u);
-						const uint4 t0 = *reinterpret_cast<const uint4*>(tp + o0);
-						fhi ^= t0.y;
-						rhi ^= t0.w;
+						const uint32_t y = (w & 0x00c000c0u) | ((w >> 10) & 0x00300030u);
+						const v4u32 t0 = lds_read4((y & 0xffu) | tp);
 						if (i + 2 < k) {
-							const uint32_t w2 = w >> 16;
-							const uint32_t o1 = (w2 & 0xc0u) | ((w2 >> 10) & 0x30u);
-							const uint4 t1v = *reinterpret_cast<const uint4*>(tp + 256 + o1);
-							fhi ^= t1v.y;
-							rhi ^= t1v.w;
+							const v4u32 t1v = lds_read4((y >> 16) | (tp + 256u));
+							fhi = xor3(fhi, t0.y, t1v.y);
+							rhi = xor3(rhi, t0.w, t1v.w);
+						} else {
+							fhi ^= t0.y;
+							rhi ^= t0.w;
 						}
-						tp += 512;
+						tp += 512u;
 					}
 					// high word of the 64-bit hash = (H << 1) | L[32]  ->  walk layout (H << 1) | H[30], plus the sample-bit flip
 					fHd = ((fhi & ~1u) | (fhi >> 31)) ^ flipc;
