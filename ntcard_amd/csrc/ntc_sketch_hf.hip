@@ -56,6 +56,20 @@ __device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(u
 __device__ __forceinline__ v4u32 lds_read4(uint32_t off) { return *(lds_v4_ptr)(uintptr_t)off; }
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
+// Closed-form table addresses of 4 window bases w = [c0 c1 c2 c3] (code<<6 per byte): pair (c0,c1) -> a0, (c2,c3) -> a1.
+// Entry offset of a pair is c_even<<6 | c_odd<<4; `tp` is the 256-byte aligned LDS offset of the table of this pair
+// position (the next position's table follows 256 B later).  5 VALU instead of the 9 hipcc derives from the C form.
+__device__ __forceinline__ void pair_addresses(uint32_t w, uint32_t tp, uint32_t& a0, uint32_t& a1)
+{
+	uint32_t m_even = 0x00c000c0u, m_odd = 0x00300030u, tp1 = tp + 256u;
+	uint32_t hi, y;
+	asm("v_lshrrev_b32_e32 %0, 10, %1" : "=v"(hi) : "v"(w));
+	asm("v_and_b32_e32 %0, %1, %2" : "=v"(y) : "s"(m_even), "v"(w));
+	asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(y) : "v"(hi), "s"(m_odd), "v"(y));
+	asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(a0) : "v"(y), "s"(tp));
+	asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(a1) : "v"(y), "s"(tp1));
+}
+
 // v_perm tables indexed by (byte & 7): 1:A 3:C 7:G 4:T 5:U, 0/2/6: not a base (nthash.hpp:16,32 trick)
 constexpr uint32_t kExpS0 = 0x47ff5554u; // 'G', ff, 'U', 'T'
 constexpr uint32_t kExpS1 = 0x43ff41ffu; // 'C', ff, 'A', ff
@@ -304,29 +318,40 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			const uint32_t* dp = reinterpret_cast<const uint32_t*>(wdata + (base & ~3u));
 			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0, dirty = 0;
 			uint32_t cur = dp[0];
-			uint32_t tp = lds_off(t1); // 256-byte aligned: a pair offset (a<<6 | b<<4) is OR-ed in
-			for (uint32_t i = 0; i < k; i += 4) {
+			uint32_t tp = __builtin_amdgcn_readfirstlane(lds_off(t1)); // 256-byte aligned: a pair offset (a<<6 | b<<4) is OR-ed in
+			const uint32_t kfull = k & ~3u;
+			uint32_t i = 0;
+			for (; i < kfull; i += 4) { // 4 window bases = 2 pair lookups per iteration, no branch inside
 				const uint32_t nxt = dp[(i >> 2) + 1];
 				const uint32_t w = alignbyte(nxt, cur, sh); // 4 code bytes (code<<6) of window positions i..i+3
 				cur = nxt;
-				dirty |= i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k)))); // bit 0 of a byte: not ACGTU
-				// pair offsets of bytes (0,1) and (2,3) side by side in bytes 0 and 2 of y; a base beyond k contributes
-				// nothing because the odd-k table drops the b term and positions >= k are never looked up
-				const uint32_t y = (w & 0x00c000c0u) | ((w >> 10) & 0x00300030u);
-				const v4u32 t0 = lds_read4((y & 0xffu) | tp);
-				if (i + 2 < k) {
-					const v4u32 t1v = lds_read4((y >> 16) | (tp + 256u));
-					flo = xor3(flo, t0.x, t1v.x);
-					fhi = xor3(fhi, t0.y, t1v.y);
-					rlo = xor3(rlo, t0.z, t1v.z);
-					rhi = xor3(rhi, t0.w, t1v.w);
-				} else {
-					flo ^= t0.x;
-					fhi ^= t0.y;
-					rlo ^= t0.z;
-					rhi ^= t0.w;
-				}
+				dirty |= w; // bit 0 of a byte: not ACGTU
+				uint32_t a0, a1;
+				pair_addresses(w, tp, a0, a1);
+				const v4u32 t0 = lds_read4(a0), t1v = lds_read4(a1);
+				flo = xor3(flo, t0.x, t1v.x);
+				fhi = xor3(fhi, t0.y, t1v.y);
+				rlo = xor3(rlo, t0.z, t1v.z);
+				rhi = xor3(rhi, t0.w, t1v.w);
 				tp += 512u;
+			}
+			if (k & 3u) { // 1..3 bases left: a base beyond k contributes nothing because the odd-k table drops the b term
+				const uint32_t w = alignbyte(dp[(i >> 2) + 1], cur, sh);
+				dirty |= w & (0xffffffffu >> (8 * (4 - (k & 3u))));
+				uint32_t a0, a1;
+				pair_addresses(w, tp, a0, a1);
+				const v4u32 t0 = lds_read4(a0);
+				flo ^= t0.x;
+				fhi ^= t0.y;
+				rlo ^= t0.z;
+				rhi ^= t0.w;
+				if ((k & 3u) == 3u) {
+					const v4u32 t1v = lds_read4(a1);
+					flo ^= t1v.x;
+					fhi ^= t1v.y;
+					rlo ^= t1v.z;
+					rhi ^= t1v.w;
+				}
 			}
 			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
@@ -575,28 +600,40 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				if (maxq >= (int32_t)k) {
 					uint32_t fhi = 0, rhi = 0;
 					const uint32_t* dp = reinterpret_cast<const uint32_t*>(mine);
-					uint32_t tp = lds_off(t1);
-					for (uint32_t i = 0; i < k; i += 4) {
+					uint32_t tp = __builtin_amdgcn_readfirstlane(lds_off(t1));
+					const uint32_t kfull = k & ~3u;
+					auto book_marks = [&](uint32_t i, uint32_t w) { // marks among the first k bases only feed F1 (rare divergent region)
+						uint32_t mk = w & 0x01010101u;
+						if (ballot(mk != 0u) != 0)
+							while (mk != 0u) {
+								on_mark((int32_t)i + (int32_t)((uint32_t)__builtin_ctz(mk) >> 3));
+								mk &= mk - 1u;
+							}
+					};
+					uint32_t i = 0;
+					for (; i < kfull; i += 4) {
 						const uint32_t w = dp[i >> 2];
-						if (wc.value == DIRTY) { // marks among the first k bases only feed F1 (rare divergent region)
-							uint32_t mk = (i + 4 <= k ? w : (w & (0xffffffffu >> (8 * (i + 4 - k))))) & 0x01010101u;
-							if (ballot(mk != 0u) != 0)
-								while (mk != 0u) {
-									on_mark((int32_t)i + (int32_t)((uint32_t)__builtin_ctz(mk) >> 3));
-									mk &= mk - 1u;
-								}
-						}
-						const uint32_t y = (w & 0x00c000c0u) | ((w >> 10) & 0x00300030u);
-						const v4u32 t0 = lds_read4((y & 0xffu) | tp);
-						if (i + 2 < k) {
-							const v4u32 t1v = lds_read4((y >> 16) | (tp + 256u));
-							fhi = xor3(fhi, t0.y, t1v.y);
-							rhi = xor3(rhi, t0.w, t1v.w);
-						} else {
-							fhi ^= t0.y;
-							rhi ^= t0.w;
-						}
+						if (wc.value == DIRTY) book_marks(i, w);
+						uint32_t a0, a1;
+						pair_addresses(w, tp, a0, a1);
+						const v4u32 t0 = lds_read4(a0), t1v = lds_read4(a1);
+						fhi = xor3(fhi, t0.y, t1v.y);
+						rhi = xor3(rhi, t0.w, t1v.w);
 						tp += 512u;
+					}
+					if (k & 3u) {
+						const uint32_t w = dp[i >> 2];
+						if (wc.value == DIRTY) book_marks(i, w & (0xffffffffu >> (8 * (4 - (k & 3u)))));
+						uint32_t a0, a1;
+						pair_addresses(w, tp, a0, a1);
+						const v4u32 t0 = lds_read4(a0);
+						fhi ^= t0.y;
+						rhi ^= t0.w;
+						if ((k & 3u) == 3u) {
+							const v4u32 t1v = lds_read4(a1);
+							fhi ^= t1v.y;
+							rhi ^= t1v.w;
+						}
 					}
 					// high word of the 64-bit hash = (H << 1) | L[32]  ->  walk layout (H << 1) | H[30], plus the sample-bit flip
 					fHd = ((fhi & ~1u) | (fhi >> 31)) ^ flipc;
