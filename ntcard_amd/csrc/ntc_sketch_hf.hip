@@ -390,6 +390,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 #if NTC_EXP_NO_QUEUE
 			cur = 0;
 #endif
+			uint32_t np = __builtin_amdgcn_readfirstlane(npend); // wave-uniform: the queue fill lives on the scalar unit
 			for (;;) {
 				const uint64_t m = ballot(cur != 0u);
 				if (m == 0) break;
@@ -400,16 +401,17 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				cur &= cur - 1u;
 				const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 				const uint32_t entry = ((uint32_t)lane << 16) | (((uint32_t)last - bit) & 0xffffu);
-				const uint32_t dest = (hit ? pos : c + (uint32_t)lane - pos) + npend; // a permutation of 0..63 (mod 64)
+				const uint32_t dest = (hit ? pos : c + (uint32_t)lane - pos) + np; // a permutation of 0..63 (mod 64)
 				const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)entry);
-				pend = (uint32_t)lane >= npend ? recv : pend;
-				npend += c;
-				if (npend >= 64u) {
+				pend = (uint32_t)lane >= np ? recv : pend;
+				np += c;
+				if (np >= 64u) {
 					resolve_round(pend, 64u);
 					pend = recv;
-					npend -= 64u;
+					np -= 64u;
 				}
 			}
+			npend = np;
 			if (can_prefetch) __builtin_amdgcn_s_setprio(2);
 		};
 		// Table offsets (one byte per base: in<<6 | out<<4) of the 4 steps of group q0.
