@@ -189,16 +189,29 @@ int main(int argc, char** argv)
 	cfg.gap = opt.gap;
 	cfg.r_bits = opt.r_bits;
 	cfg.s_bits = opt.s_bits;
-	cfg.device = 0;
-	if (const char* dev = std::getenv("NTCARD_DEVICE")) cfg.device = std::atoi(dev);
-	ntc_engine* eng = nullptr;
-	if (ntc_create(&cfg, &eng) != 0) die_engine();
+	// Devices: NTCARD_DEVICES="0,1,2,..." spreads the input files over several GPUs (one private sketch each, merged
+	// at the end: counting is a commutative sum); NTCARD_DEVICE=<n> or nothing selects a single one.
+	std::vector<int> devices;
+	if (const char* devs = std::getenv("NTCARD_DEVICES")) {
+		std::istringstream ds(devs);
+		std::string tok;
+		while (std::getline(ds, tok, ','))
+			if (!tok.empty()) devices.push_back(std::atoi(tok.c_str()));
+	}
+	if (devices.empty()) devices.push_back(std::getenv("NTCARD_DEVICE") ? std::atoi(std::getenv("NTCARD_DEVICE")) : 0);
+	if (devices.size() > files.size()) devices.resize(std::max<size_t>(1, files.size()));
+	std::vector<ntc_engine*> engines(devices.size(), nullptr);
+	for (size_t d = 0; d < devices.size(); ++d) {
+		cfg.device = devices[d];
+		if (ntc_create(&cfg, &engines[d]) != 0) die_engine();
+	}
+	ntc_engine* eng = engines[0];
 
 	// ntcard.cpp:445-446: `#pragma omp parallel for schedule(dynamic)` over the files
 	std::atomic<size_t> next(0);
 	auto worker = [&]() {
 		for (size_t i; (i = next.fetch_add(1)) < files.size();)
-			process_file(files[i], eng);
+			process_file(files[i], engines[i % engines.size()]);
 	};
 	std::vector<std::thread> pool;
 	const unsigned n_threads = opt.threads == 0 ? 1 : opt.threads;
@@ -211,6 +224,14 @@ int main(int argc, char** argv)
 	const size_t nk = opt.klist.size();
 	std::vector<uint32_t> p(nk * 2 * 65536);
 	std::vector<uint64_t> f1(nk);
+	if (engines.size() > 1) { // fold the other devices' sketches into the first (ntc_merge_counters: exact, mod 2^16)
+		std::vector<uint16_t> image(nk * 2 * ((size_t)1 << opt.r_bits));
+		for (size_t d = 1; d < engines.size(); ++d) {
+			if (ntc_finish(engines[d], image.data(), nullptr, f1.data()) != 0) die_engine();
+			if (ntc_merge_counters(eng, image.data(), f1.data()) != 0) die_engine();
+			ntc_destroy(engines[d]);
+		}
+	}
 	if (ntc_finish(eng, nullptr, p.data(), f1.data()) != 0) die_engine();
 	std::vector<double> f(opt.cov_max + 1);
 	if (opt.output.empty()) { // outDefault, ntcard.cpp:277-298

@@ -101,6 +101,18 @@ def test_multi_k_cov_rbits_compact_and_lists(inputs):
 
 
 @pytest.mark.gpu
+def test_files_spread_over_several_engines_merge_exactly(inputs):
+    """NTCARD_DEVICES: one engine (private sketch) per listed device, files dealt round-robin, sketches merged at the
+    end.  Listing device 0 twice exercises the whole path on a one-GPU box."""
+    env = dict(os.environ, NTCARD_DEVICES="0,0")
+    r = subprocess.run([BIN, "-t", "2", "-k", "16,24,32,48", "-p", "md", "part_a.fq", "part_b.fq"], cwd=inputs, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for k in (16, 24, 32, 48):
+        assert (inputs / f"md_k{k}.hist").read_bytes() == gold(f"ref_multi__out_k{k}.hist")
+
+
+@pytest.mark.gpu
 def test_unreadable_input_fails_like_the_reference(inputs):
     r = run(["-k", "12", "-p", "x", "does_not_exist.fq"], cwd=inputs)
     assert r.returncode == 1 and b"Error in reading file: does_not_exist.fq" in r.stderr
