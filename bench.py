@@ -212,11 +212,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_launch_kmers},
             # the kernel is VALU-issue bound, so also price it against the vector ALUs.  ops_per_step is
-            # read off the ISA of the steady-state walk (10 VALU per base-step + 9 per 4-step group); the whole kernel
-            # issues ~20.8 VALU per base-step (PMC SQ_INSTS_VALU, profiles/), peak = 256 CUs x 128 lanes x 2.4 GHz.
-            "valu": {"ops_per_step_walk": 12.25, "lane_ops_per_s": R * L * 12.25 / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
+            # read off the ISA of the steady-state walk (10 VALU per base-step + 8 per 4-step group); the whole kernel
+            # issues ~19.4 VALU per base-step (PMC SQ_INSTS_VALU, profiles/), peak = 256 CUs x 128 lanes x 2.4 GHz.
+            "valu": {"ops_per_step_walk": 12.0, "lane_ops_per_s": R * L * 12.0 / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
                      "peak_lane_ops_per_s": 256 * 128 * 2.4e9,
-                     "frac_walk": (R * L * 12.25 / (avg_ms * 1e-3)) / (256 * 128 * 2.4e9) if avg_ms > 0 else 0.0},
+                     "frac_walk": (R * L * 12.0 / (avg_ms * 1e-3)) / (256 * 128 * 2.4e9) if avg_ms > 0 else 0.0},
             "f1_total": total_kmers,
             "sampled_increments": hits,
         }
