@@ -162,7 +162,7 @@ void hf_shape(uint32_t stride, const uint32_t* ks, uint32_t n_k, uint32_t gap, H
 
 // Slot stride the host packer uses for reads of up to `maxlen` bytes: a multiple of 4; an ODD number of dwords keeps
 // the 64 lanes of a wave on distinct LDS banks when they read the same column of their slots (160 B = 40 dwords is
-// an 8-way conflict: 1.54 vs ~1.2 ms per 10 M reads), taken whenever it does not cost a wave of occupancy.
+// an 8-way conflict, measured 8 % slower than 156 B), taken whenever it does not cost a wave of occupancy.
 uint32_t pick_stride(uint64_t maxlen, const std::vector<uint32_t>& klist, uint32_t gap)
 {
 	const uint32_t s0 = (uint32_t)((maxlen + 3) & ~3ull);
