@@ -148,7 +148,6 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 	const uint64_t n_wb = (a.n_slots + 63) / 64;
 	uint64_t f1_wave = 0;
 
-	const uint32_t gA = (k - 1) >> 2;   // group that contains step k-1
 	const uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
 
 	// ---- global -> LDS staging.  A full wave batch (64 slots) is 64*stride contiguous bytes =
@@ -281,7 +280,6 @@ __global__ __launch_bounds__(kBlockThreads, 4) void sketch_fast_kernel(const Has
 		const int32_t full_groups = maxq >> 2;                       // groups with 4 steps for the longest lane
 		const int32_t first_main = ((int32_t)k - 1 + 3) >> 2;        // first group with q0 >= k-1
 		const int32_t fill_end = ((int32_t)k - 1) >> 2;              // groups [0, fill_end) are pure FILL
-		auto kind_of = [&](int32_t g) { return g < fill_end ? FILL : (g >= first_main ? MAIN : MIXED); };
 
 		if (uniform) {
 			// ---- clean wave: every lane walks the same steps, no per-lane bookkeeping at all ----
