@@ -50,6 +50,12 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ntcard_amd/csrc`). The HIP extension is mandatory; there is no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime; if this process uses torch on the GPU as well, torch has to bring its
+    # runtime up before ours touches the device (the other order leaves torch without visible GPUs).
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.init()
     L = C.CDLL(LIB_PATH)
     u32, u64, i32, p = C.c_uint32, C.c_uint64, C.c_int32, C.c_void_p
     L.ntc_abi_version.restype = u32

@@ -116,3 +116,55 @@ def test_files_spread_over_several_engines_merge_exactly(inputs):
 def test_unreadable_input_fails_like_the_reference(inputs):
     r = run(["-k", "12", "-p", "x", "does_not_exist.fq"], cwd=inputs)
     assert r.returncode == 1 and b"Error in reading file: does_not_exist.fq" in r.stderr
+
+
+REF_NTCARD = os.path.join(ROOT, "oracle", "_ref", "ntcard_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_NTCARD), reason="the real reference binary (oracle/_ref) was not built")
+def test_live_differential_against_reference_binary(tmp_path):
+    """adversarial inputs through BOTH command lines (the reference binary built from its own sources travels in
+    oracle/_ref): multi-line FASTA with long contigs, N runs, lower case, IUPAC codes, empty and short records,
+    a gzip'ed FASTQ with ragged read lengths, and a file list with two parser threads"""
+    import random
+    rng = random.Random(99)
+
+    def seq(n, pn):
+        out = []
+        i = 0
+        while i < n:
+            r = rng.random()
+            if r < pn:                      # a run of N / IUPAC
+                m = rng.choice([1, 1, 2, 5, 40])
+                out.append("".join(rng.choice("NnRYKM") for _ in range(m)))
+                i += m
+            else:
+                m = rng.randint(1, 60)
+                out.append("".join(rng.choice("ACGTacgt") for _ in range(m)))
+                i += m
+        return "".join(out)[:n]
+
+    fa = []
+    for i, n in enumerate([0, 5, 31, 32, 33, 200, 1000, 30_000, 150_000, 70]):
+        s = seq(n, 0.01)
+        fa.append(">c%d some description\n" % i + "\n".join(s[j:j + 60] for j in range(0, len(s), 60)) + ("\n" if s else ""))
+    (tmp_path / "contigs.fa").write_text("".join(fa))
+    recs = []
+    for i in range(20_000):
+        s = seq(rng.choice([20, 36, 75, 100, 150, 151, 250]), 0.002)
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    with gzip.open(tmp_path / "ragged.fq.gz", "wt") as f:
+        f.write("".join(recs))
+    (tmp_path / "both.txt").write_text("contigs.fa\nragged.fq.gz\n")
+    cases = [(["-k", "25"], ["contigs.fa"]), (["-k", "12,33,64"], ["ragged.fq.gz"]), (["-k", "31", "-g", "5"], ["contigs.fa", "ragged.fq.gz"]),
+             (["-t", "2", "-k", "32", "-c", "200"], ["@both.txt"])]
+    for n, (args, files) in enumerate(cases):
+        ours = subprocess.run([BIN] + args + ["-p", "gpu%d" % n] + files, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        ref = subprocess.run([REF_NTCARD] + args + ["-p", "ref%d" % n] + files, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert ours.returncode == 0 and ref.returncode == 0, (ours.stderr, ref.stderr)
+        ks = args[args.index("-k") + 1].split(",")
+        for k in ks:
+            a = (tmp_path / ("gpu%d_k%s.hist" % (n, k))).read_bytes()
+            b = (tmp_path / ("ref%d_k%s.hist" % (n, k))).read_bytes()
+            assert a == b, (args, files, k)

@@ -111,3 +111,28 @@ def test_nthll_cli_argument_errors():
     assert r.returncode == 1 and b"nthll: missing arguments" in r.stderr
     r = subprocess.run([NTHLL, "--version"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and b"nthll" in r.stderr
+
+
+REF_NTHLL = os.path.join(ROOT, "oracle", "_ref", "nthll_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_NTHLL), reason="the real reference binary (oracle/_ref) was not built")
+def test_nthll_live_differential_against_reference_binary(tmp_path):
+    """both nthll command lines on a multi-line FASTA with long, dirty contigs and on ragged FASTQ reads"""
+    rng = random.Random(4)
+    fa = []
+    for i, n in enumerate([0, 10, 64, 5000, 90_000]):
+        s = "".join(rng.choice("ACGT" * 12 + "Nacgt") for _ in range(n))
+        fa.append(">s%d\n" % i + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + ("\n" if s else ""))
+    (tmp_path / "c.fa").write_text("".join(fa))
+    fq = []
+    for i in range(8000):
+        s = "".join(rng.choice("ACGT" * 20 + "N") for _ in range(rng.choice([30, 100, 150, 151])))
+        fq.append("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    (tmp_path / "r.fq").write_text("".join(fq))
+    for args in (["-k", "32", "c.fa"], ["-k", "21", "-b", "14", "r.fq"], ["-k", "48", "c.fa", "r.fq"]):
+        ours = subprocess.run([NTHLL] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        ref = subprocess.run([REF_NTHLL] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert ours.returncode == 0 and ref.returncode == 0, (ours.stderr, ref.stderr)
+        assert ours.stdout == ref.stdout, (args, ours.stdout, ref.stdout)
