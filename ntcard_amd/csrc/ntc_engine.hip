@@ -657,7 +657,22 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 	// ---- pack (the copy the ABI promises: caller's buffers are free on return) ----
 	unsigned char* hs = sl->h_stage;
 	uint64_t slot = 0;
-	for (uint64_t i = 0; i < n_reads; ++i) {
+	// Reads of different lengths are packed longest first (counting sort: counting is order-independent, ntcard.cpp:142-143).
+	// 64 consecutive slots form a wave, and a wave whose reads are equally long takes the kernel's fast path: with 5 % of
+	// trimmed reads scattered through a batch almost every wave would be ragged (0.95 vs 0.76 ms per 8 M reads).
+	std::vector<uint32_t> order;
+	if (!chunked && !uniform && n_reads < 0xffffffffull) {
+		std::vector<uint64_t> first(maxlen + 2, 0);
+		for (uint64_t i = 0; i < n_reads; ++i)
+			++first[maxlen - (offsets[i + 1] - offsets[i]) + 1];
+		for (uint64_t l = 1; l <= maxlen + 1; ++l)
+			first[l] += first[l - 1];
+		order.resize(n_reads);
+		for (uint64_t i = 0; i < n_reads; ++i)
+			order[first[maxlen - (offsets[i + 1] - offsets[i])]++] = (uint32_t)i;
+	}
+	for (uint64_t j = 0; j < n_reads; ++j) {
+		const uint64_t i = order.empty() ? j : order[j];
 		const uint64_t l = offsets[i + 1] - offsets[i];
 		const char* src = bases + offsets[i];
 		if (!chunked) {
