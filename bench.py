@@ -155,8 +155,9 @@ def main():
 
     for _ in range(W):
         eng.submit_device(wb.data_ptr(), R, L, stride)
-    if use_dist and W > 0:  # warm the RCCL path too
-        parallel.reduce_sketch(sketch, f1_dev, dst=0)
+    if use_dist and W > 0:  # warm the RCCL path too (same collectives as the timed merge)
+        parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits,
+                                           lambda c, h: nt.value_hist_device(c.data_ptr(), c.numel(), h.data_ptr(), device=local_rank, stream=stream), dst=0)
     eng.sync()
     eng.reset()
     eng.set_profiling(True)
@@ -165,7 +166,13 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         eng.submit_device(batches[s % nb].data_ptr(), R, L, stride)
-    parallel.reduce_sketch(sketch, f1_dev, dst=0)  # the path's one exchange step (no-op for N=1)
+    ph_merged = None
+    if use_dist:
+        # the path's one exchange step: reduce-scatter of the sketches, per-rank value histograms of the summed slices,
+        # histograms to rank 0 (what compEst consumes) — see parallel.merge_to_value_histograms
+        def value_hist(counters, hist):
+            nt.value_hist_device(counters.data_ptr(), counters.numel(), hist.data_ptr(), device=local_rank, stream=stream)
+        ph_merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -175,7 +182,11 @@ def main():
     dt_max = float(tmax.item())
 
     ker_ms, launches = eng.kernel_time()
-    _, ph, f1 = eng.finish(counters=False, p_hist=True)
+    if ph_merged is not None:
+        eng.sync()
+        ph, f1 = ph_merged.cpu().numpy().astype("uint32"), f1_dev.cpu().numpy().astype("uint64")
+    else:
+        _, ph, f1 = eng.finish(counters=False, p_hist=True)
     total_kmers = int(sum(int(x) for x in f1))  # after the reduce rank 0 holds the sum over ranks (and over the k list)
 
     if rank == 0:
@@ -203,7 +214,7 @@ def main():
             "config": {"workload": f"{world}x{reads_per_rank} synthetic {L} bp reads (dist={args.dist}, seed={args.seed}), "
                                    f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
                                    f"{K} steps x {R} reads per GPU" + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
-                                   + (", RCCL sum-reduce of the sketch to rank 0 inside the timed region" if world > 1 else ""),
+                                   + (", RCCL reduce-scatter of the sketches + value histograms to rank 0 inside the timed region" if world > 1 else ""),
                        "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
                        "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -101,6 +101,12 @@ int ntc_sync(ntc_engine *e); /* wait for all submitted work */
 int ntc_finish(ntc_engine *e, uint16_t *t_counter_out, uint32_t *p_hist_out, uint64_t *f1_out);
 
 /* Device pointers of the live sketch / F1 (for a host framework's collective) */
+/* compEst's first loop (ntcard.cpp:240-247) over an arbitrary run of DEVICE counters: for each of the n uint32
+ * counters, ++d_hist_u32[counter & 0xffff] (the histogram is accumulated, not zeroed).  Asynchronous on `stream`.
+ * Used by the multi-GPU merge: after a reduce-scatter every rank histograms its own slice of the summed sketch and
+ * only the 256 KiB histograms travel to rank 0 (ntcard_amd/parallel.py).                                      */
+int ntc_value_hist_device(int32_t device, void *stream, const void *d_counters_u32, uint64_t n, void *d_hist_u32);
+
 /* Sketch load / merge: adds a t_Counter image dumped by ntc_finish (same k list, r_bits;
  * uint16 [n_k][2][1<<r_bits]) and its F1 values (may be NULL) into this engine.  Counting is a commutative sum
  * mod 2^16 (ntcard.cpp:142-143), so runs split across processes, nodes or days merge exactly.               */

@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
     "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
-    "ntc_kernel_time", "ntc_set_profiling", "ntc_merge_counters", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
+    "ntc_kernel_time", "ntc_set_profiling", "ntc_merge_counters", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
 ]
 
 
@@ -71,6 +71,8 @@ def lib():
     L.ntc_finish.argtypes = [p, p, p, p]
     if hasattr(L, "ntc_merge_counters") or not os.environ.get("NTCARD_HIP_LIB"):  # A/B builds of older sources may lack it
         L.ntc_merge_counters.argtypes = [p, p, p]
+    if hasattr(L, "ntc_value_hist_device") or not os.environ.get("NTCARD_HIP_LIB"):
+        L.ntc_value_hist_device.argtypes = [i32, p, p, u64, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_gen_reads_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u32, u64]

@@ -755,6 +755,16 @@ int ntc_finish(ntc_engine* e, uint16_t* t_counter_out, uint32_t* p_hist_out, uin
 	return drain_events(e);
 }
 
+int ntc_value_hist_device(int32_t device, void* stream, const void* d_counters_u32, uint64_t n, void* d_hist_u32)
+{
+	if (!d_counters_u32 || !d_hist_u32) return fail(NTC_ERR_ARG, "ntc_value_hist_device: null buffer");
+	if ((n & 3u) || ((uintptr_t)d_counters_u32 & 15u)) return fail(NTC_ERR_ARG, "ntc_value_hist_device: need n %% 4 == 0 and 16-byte aligned counters");
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(ntc::launch_value_hist((const uint32_t*)d_counters_u32, n, (uint32_t*)d_hist_u32, (hipStream_t)stream));
+	return 0;
+}
+
 int ntc_merge_counters(ntc_engine* e, const uint16_t* t_counter, const uint64_t* f1)
 {
 	if (!e || !t_counter) return fail(NTC_ERR_ARG, "ntc_merge_counters: null argument");

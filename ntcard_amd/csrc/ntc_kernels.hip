@@ -433,6 +433,13 @@ hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32
 	return hipGetLastError();
 }
 
+// value histogram of an arbitrary run of counters (one "sample" of n counters), ADDED to p_hist[65536]
+hipError_t launch_value_hist(const uint32_t* counters, uint64_t n, uint32_t* p_hist, hipStream_t st)
+{
+	hipLaunchKernelGGL(finalize_kernel, dim3(2048, 1), dim3(256), 0, st, counters, n, p_hist, (uint16_t*)nullptr);
+	return hipGetLastError();
+}
+
 hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
                       uint32_t stride, uint32_t dist, uint64_t glen, hipStream_t st)
 {

@@ -164,6 +164,12 @@ def gen_reads_device(d_ptr, seed, first, n, read_len, stride, dist, genome_len=1
                                           read_len, stride, dist, genome_len))
 
 
+def value_hist_device(d_counters_ptr, n, d_hist_ptr, device=0, stream=None):
+    """accumulate the value histogram (counter & 0xffff) of n device uint32 counters into a device uint32[65536]"""
+    check(_abi.lib().ntc_value_hist_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_counters_ptr), n,
+                                           C.c_void_p(d_hist_ptr)))
+
+
 def hash_dump_device(d_slots_ptr, n_reads, read_len, stride, k, gap, max_win, d_hash_ptr, d_count_ptr, device=0, stream=None):
     check(_abi.lib().ntc_hash_dump_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_slots_ptr), n_reads,
                                           read_len, stride, k, gap, max_win, C.c_void_p(d_hash_ptr), C.c_void_p(d_count_ptr)))

@@ -82,6 +82,43 @@ def test_two_rank_hll_merge_equals_single_process(tmp_path):
     assert int(np.load(tmp_path / "f1.npy")[0]) == sum(len(orc.hash_read(r, K)[0]) for r in reads)
 
 
+def _hist_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    klist = [21, 40]
+    first, n = parallel.split_reads(N, world)[rank]
+    slots = orc.gen_reads(3, first, n, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(n)]
+    counters, f1 = orc.sketch_reads(reads, klist, 0, RB, SB)
+    sk = torch.from_numpy(counters.astype(np.int64).reshape(-1)).to(torch.int32)
+    sk[5] += 50000  # the merged counter wraps past 65535
+
+    def value_hist(c, h):
+        h += torch.bincount((c & 0xFFFF).to(torch.int64), minlength=65536).to(torch.int32)
+
+    ph, f1t = parallel.merge_to_value_histograms(sk, torch.from_numpy(f1.astype(np.int64)), len(klist), RB, value_hist, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ph.npy"), ph.numpy())
+        np.save(os.path.join(out_dir, "f1.npy"), f1t.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_value_histogram_merge(tmp_path):
+    """reduce-scatter + per-rank histograms of the summed slices == histogram of the single-process sketch"""
+    world, klist = 2, [21, 40]
+    mp.spawn(_hist_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    slots = orc.gen_reads(3, 0, N, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(N)]
+    oc, of1 = orc.sketch_reads(reads, klist, 0, RB, SB)
+    oc = oc.astype(np.int64)
+    oc[0, 0, 5] = (oc[0, 0, 5] + 100000) & 0xFFFF
+    ph = np.load(tmp_path / "ph.npy")
+    for ki in range(len(klist)):
+        assert np.array_equal(ph[ki].astype(np.uint32), orc.value_hist(oc[ki].astype(np.uint16), RB))
+    assert np.array_equal(np.load(tmp_path / "f1.npy").astype(np.uint64), of1)
+
+
 def test_split_reads_covers_everything():
     for n, w in ((10, 3), (100_000_000, 8), (7, 8)):
         parts = parallel.split_reads(n, w)

@@ -336,3 +336,34 @@ def test_full_size_properties(nt):
     h1 = int((p1[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
     h2 = int((p2[0].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum())
     assert h1 + h2 == hits
+
+
+def test_value_hist_device_matches_numpy(nt):
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 70000, size=1 << 20, dtype=np.uint32)
+    c[::7] = 0
+    d = torch.from_numpy(c.view(np.int32)).cuda()
+    h = torch.zeros(65536, dtype=torch.int32, device="cuda")
+    nt.value_hist_device(d.data_ptr(), d.numel(), h.data_ptr())
+    nt.value_hist_device(d[: 1 << 18].data_ptr(), 1 << 18, h.data_ptr())  # accumulates
+    torch.cuda.synchronize()
+    want = np.bincount(c & 0xFFFF, minlength=65536) + np.bincount(c[: 1 << 18] & 0xFFFF, minlength=65536)
+    assert np.array_equal(h.cpu().numpy().astype(np.int64), want)
+
+
+def test_bench_under_torchrun_single_rank(tmp_path):
+    """the multi-GPU code path of bench.py (RCCL init, reduce-scatter merge, histogram reduce) with one rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--reads-per-step", "1000000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--reads-per-step", "1000000",
+                          "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+    k = json.loads(ref.stdout.decode().strip().splitlines()[-1])
+    assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"] and j["n_gpus"] == 1
