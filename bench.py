@@ -8,7 +8,7 @@ device-resident t_Counter sketch) over one batch of synthetic reads that is alre
 Default workload = BASELINE.json configs[1]: 100 M synthetic 150 bp reads, k=32, rBits=27, sBits=7,
 as 10 steps x 10 M reads.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
 rank processes its own read-index range of the same size (weak scaling), then the per-GPU sketches
-are merged with one RCCL sum-reduce to rank 0 (inside the timed region).
+are merged inside the timed region: RCCL reduce-scatter, per-rank value histograms of the summed slices, histograms to rank 0.
 
 One JSON line on rank 0: value = total k-mers (sum of F1 over ranks) / max-over-ranks wall time.
 Extra objects: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes) and "cpu_baseline"
