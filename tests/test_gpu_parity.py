@@ -367,3 +367,13 @@ def test_bench_under_torchrun_single_rank(tmp_path):
                           "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
     k = json.loads(ref.stdout.decode().strip().splitlines()[-1])
     assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"] and j["n_gpus"] == 1
+
+
+def test_randomised_shapes_small():
+    """a short run of the randomised sweep (tools/fuzz_parity.py: random k lists, gaps, lengths, dirt, submit patterns)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "2024"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]
