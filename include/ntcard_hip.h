@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NTC_ABI_VERSION 1
+#define NTC_ABI_VERSION 2
 #define NTC_MAX_K_LIST 32
 
 typedef enum {
@@ -55,11 +55,17 @@ typedef struct {
                                   (lets a host framework own/merge the buffer, e.g. RCCL reduce) */
     void *ext_f1;              /* optional caller-owned DEVICE uint64_t [n_k]; NULL -> engine    */
     uint32_t flags;            /* NTC_FLAG_*                                                      */
+    uint64_t log_entries;      /* capacity of the hit log in 4-byte entries, 0 = default (2^28 at
+                                  rBits = 27).  ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is
+                                  deferred: the kernels log the counter index of every sampled k-mer
+                                  and the log is applied to the sketch when it fills up and whenever
+                                  the counters are needed (ntc_finish, ntc_flush, ...)              */
 } ntc_config;
 
 #define NTC_FLAG_NONE 0u
-#define NTC_FLAG_SIMPLE_KERNEL 1u /* run the simple validation kernel instead of the tuned one */
-#define NTC_FLAG_FAST_KERNEL 2u   /* run the first tuned kernel (full hash in the loop) instead of the H-filter one */
+#define NTC_FLAG_SIMPLE_KERNEL 1u  /* run the simple validation kernel instead of the production ones */
+#define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
+                                      (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 
 uint32_t ntc_abi_version(void);
 uint32_t ntc_max_k(void);
@@ -92,6 +98,10 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
 
 int ntc_sync(ntc_engine *e); /* wait for all submitted work */
 
+/* Apply the pending hit log to the device sketch (asynchronous on the engine's stream).  After it the
+ * device counters are the reference's t_Counter state for everything submitted so far (ntcard.cpp:142-143). */
+int ntc_flush(ntc_engine *e);
+
 /* End of stream: the state compEst/outDefault consume.
  * t_counter_out: HOST uint16_t [n_k][2][1<<r_bits] (== the reference's t_Counter) or NULL
  * p_hist_out:    HOST uint32_t [n_k][2][65536], p[s][v] = #buckets of sample s whose counter == v
@@ -100,7 +110,6 @@ int ntc_sync(ntc_engine *e); /* wait for all submitted work */
  * May be called repeatedly; does not clear the sketch.                                          */
 int ntc_finish(ntc_engine *e, uint16_t *t_counter_out, uint32_t *p_hist_out, uint64_t *f1_out);
 
-/* Device pointers of the live sketch / F1 (for a host framework's collective) */
 /* compEst's first loop (ntcard.cpp:240-247) over an arbitrary run of DEVICE counters: for each of the n uint32
  * counters, ++d_hist_u32[counter & 0xffff] (the histogram is accumulated, not zeroed).  Asynchronous on `stream`.
  * Used by the multi-GPU merge: after a reduce-scatter every rank histograms its own slice of the summed sketch and
@@ -112,6 +121,7 @@ int ntc_value_hist_device(int32_t device, void *stream, const void *d_counters_u
  * mod 2^16 (ntcard.cpp:142-143), so runs split across processes, nodes or days merge exactly.               */
 int ntc_merge_counters(ntc_engine *e, const uint16_t *t_counter, const uint64_t *f1);
 
+/* Device pointers of the live sketch / F1 (for a host framework's collective); flushes the hit log first */
 int ntc_device_state(ntc_engine *e, void **d_sketch_u32, uint64_t *n_counters, void **d_f1_u64);
 
 /* Validation kernel (K1d): canonical hash of every window of ONE k for a device-resident slot
@@ -152,6 +162,8 @@ int ntc_hll_estimate(const uint8_t *regs, uint32_t n_bits, double *est_out);
 /* Timing of the hot kernel as measured with HIP events on the engine's stream (for bench.py's
  * roofline leg): accumulated milliseconds and launch count since create/reset.                  */
 int ntc_kernel_time(ntc_engine *e, double *ms_total, uint64_t *launches);
+/* same for the deferred sketch update (partition + count passes): milliseconds and number of applies */
+int ntc_apply_time(ntc_engine *e, double *ms_total, uint64_t *applies);
 int ntc_set_profiling(ntc_engine *e, int enable);
 
 #ifdef __cplusplus

@@ -7,14 +7,14 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NTCARD_HIP_LIB") or os.path.join(HERE, "lib", "libntcard_hip.so")  # env override: A/B builds
+LIB_PATH = os.path.join(HERE, "lib", "libntcard_hip.so")
 
 # every symbol include/ntcard_hip.h declares
 ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
     "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
-    "ntc_kernel_time", "ntc_set_profiling", "ntc_merge_counters", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
+    "ntc_kernel_time", "ntc_apply_time", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
 ]
 
 
@@ -30,6 +30,7 @@ class NtcConfig(C.Structure):
         ("ext_sketch", C.c_void_p),
         ("ext_f1", C.c_void_p),
         ("flags", C.c_uint32),
+        ("log_entries", C.c_uint64),
     ]
 
 
@@ -69,23 +70,21 @@ def lib():
     L.ntc_submit_device.argtypes = [p, p, u64, u32, u32]
     L.ntc_sync.argtypes = [p]
     L.ntc_finish.argtypes = [p, p, p, p]
-    if hasattr(L, "ntc_merge_counters") or not os.environ.get("NTCARD_HIP_LIB"):  # A/B builds of older sources may lack it
-        L.ntc_merge_counters.argtypes = [p, p, p]
-    if hasattr(L, "ntc_value_hist_device") or not os.environ.get("NTCARD_HIP_LIB"):
-        L.ntc_value_hist_device.argtypes = [i32, p, p, u64, p]
+    L.ntc_merge_counters.argtypes = [p, p, p]
+    L.ntc_value_hist_device.argtypes = [i32, p, p, u64, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_gen_reads_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u32, u64]
     L.ntc_estimate.argtypes = [p, u32, u32, u32, C.POINTER(C.c_double), p]
     L.ntc_write_hist.argtypes = [C.c_char_p, u64, C.c_double, p, u32]
     L.ntc_kernel_time.argtypes = [p, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.ntc_apply_time.argtypes = [p, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.ntc_flush.argtypes = [p]
     L.ntc_set_profiling.argtypes = [p, C.c_int]
     L.ntc_hll_create.argtypes = [u32, u32, i32, p, C.POINTER(p)]
     L.ntc_hll_finish.argtypes = [p, p, p]
     L.ntc_hll_estimate.argtypes = [p, u32, C.POINTER(C.c_double)]
     for name in ABI_SYMBOLS:
-        if os.environ.get("NTCARD_HIP_LIB") and not hasattr(L, name):
-            continue  # A/B build of an older source
         fn = getattr(L, name)
         if name not in ("ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_destroy"):
             fn.restype = C.c_int

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -65,18 +66,28 @@ int device_info(int dev, DevInfo& di)
 	return 0;
 }
 
-// dynamic LDS per block: the simple kernel keeps its tables in the dynamic region, the fast one statically
-// kernel kinds: the simple validation kernel, the first tuned kernel, the H-filter kernel (default)
-enum { KIND_SIMPLE = 0, KIND_FAST = 1, KIND_HF = 2 };
+// kernel kinds: the simple validation kernel (K1s/K1d) and the production kernels (K1)
+enum { KIND_SIMPLE = 0, KIND_HF = 2 };
 
-size_t smem_for(uint32_t stride, int kind, uint32_t k, uint32_t gap = 0)
+// dynamic LDS per block of the simple kernel: its seed tables + the 4 waves' slots
+size_t smem_simple(uint32_t stride) { return (size_t)ntc::kTableBytes + (size_t)ntc::kWavesPerBlock * 64u * stride; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel function, not of a launch: it
+// is raised ONCE per device to the most any plan can ask for (under a process-wide lock), so that engines driven from
+// different threads never lower each other's limit between "set" and "launch".
+constexpr size_t kMaxDynLds = 160 * 1024 - 2048; // 160 KiB minus the largest static LDS of any kernel here
+int ensure_kernel_attrs(int dev)
 {
-	const size_t data = (size_t)ntc::kWavesPerBlock * 64u * stride;
-	if (kind == KIND_SIMPLE) return (size_t)ntc::kTableBytes + data;
-	if (kind == KIND_FAST) return 16 + data;
-	return 16 + data + (size_t)ntc::t2_pairs(k) * 256u + (size_t)ntc::kWavesPerBlock * 128u * 4u +
-	       (size_t)ntc::kWavesPerBlock * ((stride + 31u) / 32u) * 64u * 4u + // + closed-form table, rings, hit masks
-	       (size_t)((gap + 1u) / 2u) * 256u;                                   // + spaced-seed table
+	static std::mutex mu;
+	static std::vector<char> done;
+	std::lock_guard<std::mutex> lk(mu);
+	if ((size_t)dev >= done.size()) done.resize(dev + 1, 0);
+	if (done[dev]) return 0;
+	HIP_TRY(ntc::set_sketch_hf_smem_limit(kMaxDynLds));
+	HIP_TRY(ntc::set_hash_smem_limit(kMaxDynLds));
+	HIP_TRY(ntc::set_apply_smem_limit());
+	done[dev] = 1;
+	return 0;
 }
 
 // K1 (sketch_hf_kernel) launch shape.  Every wave parks its 64 slots in LDS and the block shares
@@ -88,7 +99,7 @@ struct HfPlan {
 };
 
 // per-k block of the K1 argument struct
-void fill_hfk(ntc::HfK& o, uint32_t k, uint32_t* sketch, unsigned long long* f1, const void* t1)
+void fill_hfk(ntc::HfK& o, uint32_t k, uint32_t* sketch, unsigned long long* f1, const void* t1, uint32_t key_base = 0)
 {
 	ntc::HashTables tab;
 	uint32_t init[6];
@@ -98,6 +109,8 @@ void fill_hfk(ntc::HfK& o, uint32_t k, uint32_t* sketch, unsigned long long* f1,
 	o.init_f = init[2];
 	o.init_r = init[5];
 	o.pad_ = 0;
+	o.key_base = key_base;
+	o.pad2_ = 0;
 	o.sketch = sketch;
 	o.f1 = f1;
 	o.t1 = t1;
@@ -118,7 +131,7 @@ int hf_plan(int dev, uint64_t n_slots, uint32_t stride, const uint32_t* ks, uint
 	if (p.waves_per_cu == 0)
 		return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs more than 160 KiB of LDS per wave", stride, ks[0]);
 	p.smem = shared + p.wpb * (64u * (size_t)stride);
-	HIP_TRY(ntc::set_sketch_hf_smem_limit(p.smem));
+	if (p.smem > kMaxDynLds) return fail(NTC_ERR_ARG, "slot stride %u with k=%u needs %zu B of LDS per block", stride, ks[0], p.smem);
 	const unsigned per_cu = std::max(1u, p.waves_per_cu / p.wpb);
 	const uint64_t need = (n_slots + 64ull * p.wpb - 1) / (64ull * p.wpb);
 	p.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)di.cus * per_cu));
@@ -136,26 +149,21 @@ void hf_shape(uint32_t stride, const uint32_t* ks, uint32_t n_k, uint32_t gap, H
 	// blocks leaves part of the persistent grid waiting for a second round, which costs far more than a wave less.
 	const size_t granule = 1280, granules_per_cu = 128, static_lds = 1024 + 256 + 64;
 	unsigned best_waves = 0;
-	static const int force_wpb = std::getenv("NTC_WPB") ? std::atoi(std::getenv("NTC_WPB")) : 0; // tuning experiments only
 	auto consider = [&](unsigned w) {
 		const size_t alloc = (shared + w * per_wave + static_lds + granule - 1) / granule;
-		if (alloc > granules_per_cu) return;
+		if (alloc > granules_per_cu || shared + w * per_wave > kMaxDynLds) return;
 		const unsigned waves = std::min<unsigned>(16, (unsigned)(granules_per_cu / alloc) * w); // 128 VGPRs: 4 waves per SIMD
 		if (waves >= best_waves) { // ties: the larger block (fewer table copies)
 			best_waves = waves;
 			p.wpb = w;
 		}
 	};
-	if (force_wpb > 0) {
-		consider((unsigned)force_wpb);
-	} else {
-		// whole multiples of the 4 SIMDs keep them evenly loaded (measured: 6 or 13 waves per block cost 5-12 %,
-		// 3 blocks of 3 waves lose to 2 blocks of 4); smaller blocks only when not even 4 waves fit
-		for (unsigned w = 4; w <= 16; w += 4)
-			consider(w);
-		for (unsigned w = 3; best_waves == 0 && w >= 1; --w)
-			consider(w);
-	}
+	// whole multiples of the 4 SIMDs keep them evenly loaded (measured: 6 or 13 waves per block cost 5-12 %,
+	// 3 blocks of 3 waves lose to 2 blocks of 4); smaller blocks only when not even 4 waves fit
+	for (unsigned w = 4; w <= 16; w += 4)
+		consider(w);
+	for (unsigned w = 3; best_waves == 0 && w >= 1; --w)
+		consider(w);
 	p.waves_per_cu = best_waves;
 	shared_out = shared;
 }
@@ -174,25 +182,25 @@ uint32_t pick_stride(uint64_t maxlen, const std::vector<uint32_t>& klist, uint32
 	return b.waves_per_cu >= a.waves_per_cu && b.waves_per_cu > 0 ? s0 + 4 : s0;
 }
 
-// grid for the persistent-style hash kernel: enough blocks to fill the chip, not more than the work
-int hash_grid(int dev, uint64_t n_slots, uint32_t stride, int kind, uint32_t k, unsigned& grid, size_t& smem, uint32_t gap = 0)
+// grid for the simple (validation) kernel: enough blocks to fill the chip, not more than the work
+int hash_grid(int dev, uint64_t n_slots, uint32_t stride, unsigned& grid, size_t& smem)
 {
 	DevInfo di;
 	if (int rc = device_info(dev, di)) return rc;
-	smem = smem_for(stride, kind, k, gap);
-	const size_t total = smem + (kind == KIND_FAST ? (size_t)ntc::kTableBytes : (kind == KIND_HF ? 256 : 0));
-	if (total > 160 * 1024) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, total);
-	if (kind == KIND_HF)
-		HIP_TRY(ntc::set_sketch_hf_smem_limit(smem));
-	else if (kind == KIND_FAST)
-		HIP_TRY(ntc::set_sketch_fast_smem_limit(smem));
-	else
-		HIP_TRY(ntc::set_hash_smem_limit(smem));
-	unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / total));
+	smem = smem_simple(stride);
+	if (smem > kMaxDynLds) return fail(NTC_ERR_ARG, "slot stride %u needs %zu B of LDS per block (> 160 KiB)", stride, smem);
+	unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
 	uint64_t need = (n_slots + 64 * ntc::kWavesPerBlock - 1) / (64 * ntc::kWavesPerBlock);
 	uint64_t cap = (uint64_t)di.cus * per_cu;
 	grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(need, cap));
 	return 0;
+}
+
+uint32_t ceil_log2(uint64_t x)
+{
+	uint32_t b = 0;
+	while ((1ull << b) < x) ++b;
+	return b;
 }
 
 } // namespace
@@ -208,9 +216,22 @@ struct ntc_engine {
 	bool own_sketch = false, own_f1 = false;
 	uint32_t* d_phist = nullptr; // [nk][2][65536]
 	uint16_t* d_out16 = nullptr; // [2][1<<r_bits] scratch for finish
-	void* d_queue = nullptr;     // fast kernel: per-wave hit queues
-	size_t queue_cap = 0;
-	int kernel_kind = 2;         // KIND_HF unless NTC_FLAG_SIMPLE_KERNEL / NTC_FLAG_FAST_KERNEL
+	int kernel_kind = 2;         // KIND_HF unless NTC_FLAG_SIMPLE_KERNEL
+	// Hit log (ntc_apply.hip): K1 appends the counter index of every sampled k-mer instead of incrementing; the
+	// log is applied to d_sketch when it fills up and whenever the sketch itself is needed (finish, merge, ...).
+	uint32_t* d_log = nullptr;      // [log_regions][log_region_cap]
+	uint32_t* d_logfill = nullptr;  // [log_regions]
+	uint32_t log_regions = 0, log_region_cap = 0;
+	uint64_t log_cap = 0;           // entries
+	double log_est = 0.0;           // host-side upper estimate of the entries logged since the last apply
+	bool log_pending = false;
+	struct ApplyPlan {
+		uint32_t key_bits = 0, slice_bits = 0, b1 = 0, b2 = 0; // key = [b1 | b2 | slice_bits]
+		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
+	} ap;
+	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
+	double apply_ms = 0.0;
+	uint64_t applies = 0;
 	uint32_t hll_bits = 0;       // != 0: nthll engine (d_sketch holds uint32 M[1<<hll_bits])
 	uint32_t* d_hll_thr = nullptr;
 	uint64_t hll_reads_seen = 0;
@@ -237,7 +258,7 @@ struct ntc_engine {
 	std::mutex mu;
 	// profiling of the hash kernel (HIP events on the engine stream)
 	bool profiling = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, apply_pending;
 	double ms_total = 0.0;
 	uint64_t launches = 0;
 
@@ -258,6 +279,143 @@ int drain_events(ntc_engine* e)
 		(void)hipEventDestroy(pr.second);
 	}
 	e->pending.clear();
+	for (auto& pr : e->apply_pending) {
+		float ms = 0.f;
+		HIP_TRY(hipEventSynchronize(pr.second));
+		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+		e->apply_ms += ms;
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
+	}
+	e->apply_pending.clear();
+	return 0;
+}
+
+// Geometry of the hit log and of its partition passes for this engine's key space (keys are indices into the whole
+// sketch array: k index, sample and bucket).  Returns false when the keys do not fit (then ntComp's increments stay
+// direct atomics): more than 2^32 counters, or more than two 8-bit partition passes above a 2^15-counter slice.
+bool plan_log(ntc_engine* e, uint64_t want_entries)
+{
+	const uint64_t counters = e->klist.size() * e->plane_elems();
+	if (counters > (1ull << 32)) return false;
+	auto& ap = e->ap;
+	ap.key_bits = ceil_log2(counters);
+	ap.slice_bits = std::min<uint32_t>(15, ap.key_bits);
+	const uint32_t pb = ap.key_bits - ap.slice_bits;
+	if (pb > 16) return false;
+	ap.b1 = std::min<uint32_t>(8, pb);
+	ap.b2 = pb - ap.b1;
+	ap.n_slices = (uint32_t)((counters + (1ull << ap.slice_bits) - 1) >> ap.slice_bits);
+	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 28, std::max<uint64_t>(1ull << 18, 4 * counters));
+	cap = std::max<uint64_t>(cap, 1ull << 14);
+	e->log_region_cap = (uint32_t)std::max<uint64_t>(256, cap / 8192);
+	e->log_regions = (uint32_t)std::max<uint64_t>(1, cap / e->log_region_cap);
+	e->log_cap = (uint64_t)e->log_regions * e->log_region_cap;
+	// pass 1: g1 workgroups, each owns every g1-th region and writes 2^b1 private runs; a run holds its expected
+	// share of a FULL log + 25 % (+64); what does not fit is applied directly (exact), so the margin is about speed only
+	ap.g1 = std::min<uint32_t>(e->log_regions, 1024);
+	const uint64_t share1 = (uint64_t)((e->log_regions + ap.g1 - 1) / ap.g1) * e->log_region_cap;
+	ap.cap1 = (uint32_t)((share1 >> ap.b1) * 5 / 4 + 64);
+	// pass 2: bucket b of pass 1 is split again by `parts2` workgroups
+	ap.parts2 = 8;
+	const uint64_t share2 = ((e->log_cap >> ap.b1) * 5 / 4) / ap.parts2 + 1;
+	ap.cap2 = (uint32_t)((share2 >> ap.b2) * 13 / 10 + 64);
+	return true;
+}
+
+// Apply the pending hit log to the sketch (asynchronous on the engine's stream): partition, count, add, clear.
+int apply_log(ntc_engine* e)
+{
+	if (!e->d_log || !e->log_pending) return 0;
+	const auto& ap = e->ap;
+	const uint32_t nb1 = 1u << ap.b1, nb2 = 1u << ap.b2;
+	if (ap.b1 && !e->d_s1) {
+		const size_t runs1 = (size_t)ap.g1 * nb1;
+		if (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * 4) != hipSuccess || hipMalloc((void**)&e->d_c1, runs1 * 4) != hipSuccess)
+			return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of partition scratch on device", runs1 * ap.cap1 * 4);
+	}
+	if (ap.b2 && !e->d_s2) {
+		const size_t runs2 = (size_t)nb1 * ap.parts2 * nb2;
+		if (hipMalloc((void**)&e->d_s2, runs2 * ap.cap2 * 4) != hipSuccess || hipMalloc((void**)&e->d_c2, runs2 * 4) != hipSuccess)
+			return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of partition scratch on device", runs2 * ap.cap2 * 4);
+	}
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (e->profiling) {
+		HIP_TRY(hipEventCreate(&ev0));
+		HIP_TRY(hipEventCreate(&ev1));
+		HIP_TRY(hipEventRecord(ev0, e->stream));
+	}
+	ntc::CountArgs c;
+	std::memset(&c, 0, sizeof c);
+	c.slice_bits = ap.slice_bits;
+	c.n_slices = ap.n_slices;
+	c.sketch = e->d_sketch;
+	if (ap.b1 == 0) {
+		c.in = e->d_log;
+		c.in_cnt = e->d_logfill;
+		c.in_cap = e->log_region_cap;
+		c.n_in = e->log_regions;
+		c.mode = 0;
+	} else {
+		ntc::SplitArgs s1;
+		std::memset(&s1, 0, sizeof s1);
+		s1.in = e->d_log;
+		s1.in_cnt = e->d_logfill;
+		s1.in_cap = e->log_region_cap;
+		s1.n_in = e->log_regions;
+		s1.mode = 0;
+		s1.shift = ap.key_bits - ap.b1;
+		s1.bits = ap.b1;
+		s1.out = e->d_s1;
+		s1.out_cnt = e->d_c1;
+		s1.out_cap = ap.cap1;
+		s1.sketch = e->d_sketch;
+		HIP_TRY(ntc::launch_split(s1, ap.g1, e->stream));
+		if (ap.b2 == 0) {
+			c.in = e->d_s1;
+			c.in_cnt = e->d_c1;
+			c.in_cap = ap.cap1;
+			c.n_in = ap.g1 * nb1;
+			c.mode = 1;
+			c.nb1 = nb1;
+			c.nwg1 = ap.g1;
+		} else {
+			ntc::SplitArgs s2;
+			std::memset(&s2, 0, sizeof s2);
+			s2.in = e->d_s1;
+			s2.in_cnt = e->d_c1;
+			s2.in_cap = ap.cap1;
+			s2.n_in = ap.g1 * nb1;
+			s2.mode = 1;
+			s2.parts = ap.parts2;
+			s2.nb_in = nb1;
+			s2.shift = ap.slice_bits;
+			s2.bits = ap.b2;
+			s2.out = e->d_s2;
+			s2.out_cnt = e->d_c2;
+			s2.out_cap = ap.cap2;
+			s2.sketch = e->d_sketch;
+			HIP_TRY(ntc::launch_split(s2, nb1 * ap.parts2, e->stream));
+			c.in = e->d_s2;
+			c.in_cnt = e->d_c2;
+			c.in_cap = ap.cap2;
+			c.n_in = nb1 * ap.parts2 * nb2;
+			c.mode = 2;
+			c.parts = ap.parts2;
+			c.nb2 = nb2;
+		}
+	}
+	DevInfo di;
+	if (int rc = device_info(e->device, di)) return rc;
+	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, (unsigned)di.cus), e->stream));
+	HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
+	if (e->profiling) {
+		HIP_TRY(hipEventRecord(ev1, e->stream));
+		e->apply_pending.emplace_back(ev0, ev1);
+	}
+	e->log_pending = false;
+	e->log_est = 0.0;
+	e->applies += 1;
 	return 0;
 }
 
@@ -269,30 +427,15 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	unsigned grid = 0;
 	size_t smem = 0;
 	const int kind = e->kernel_kind;
-	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
-	if (kind != KIND_HF) // K1 plans its launch per k (hf_plan)
-		if (int rc = hash_grid(e->device, n_slots, stride, kind, kmax, grid, smem, e->gap)) return rc;
-	// every lane can queue at most one hit per window of its slot: `stride` rows always suffice
-	const uint32_t queue_rows = stride;
-	if (kind == KIND_FAST) {
-		const size_t need = (size_t)grid * ntc::kWavesPerBlock * queue_rows * 1024u;
-		if (need > e->queue_cap) {
-			HIP_TRY(hipStreamSynchronize(e->stream));
-			if (e->d_queue) (void)hipFree(e->d_queue);
-			e->d_queue = nullptr;
-			e->queue_cap = 0;
-			if (hipMalloc(&e->d_queue, need) != hipSuccess)
-				return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of hit queues on device", need);
-			e->queue_cap = need;
-		}
-	}
+	if (kind != KIND_HF) // K1 plans its launch per k group (hf_plan)
+		if (int rc = hash_grid(e->device, n_slots, stride, grid, smem)) return rc;
 	if (e->hll_bits) {
 		// nthll: refresh the "can still matter" threshold between sub-batches that double in size, so the
 		// expensive resolve stage only sees a vanishing fraction of the k-mers once the registers warm up
 		uint64_t done = 0;
 		while (done < n_slots) {
 			uint64_t n = std::max<uint64_t>(16384, e->hll_reads_seen);
-			n = std::min<uint64_t>((n + 1) & ~1ull, n_slots - done); // even: keeps 16-byte alignment of uniform slots
+			n = std::min<uint64_t>((n + 63) & ~63ull, n_slots - done); // whole waves: a sub-batch starts on a 16-byte aligned slot
 			HIP_TRY(ntc::launch_hll_threshold(e->d_sketch, 1u << e->hll_bits, e->d_hll_thr, e->stream));
 			ntc::HfArgs a;
 			std::memset(&a, 0, sizeof a);
@@ -351,6 +494,23 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			if (e->gap) ntc::build_gap_roll_table(e->klist[b], a.gap_first, e->gap, a.tabg);
 			for (size_t j = 0; j < n; ++j)
 				a.ks[j] = e->hfk[b + j];
+			if (e->d_log) {
+				// upper estimate of the sampled k-mers of this launch (both samples ~2^-sBits of the windows each, App. B of
+				// SURVEY.md) + what every wave may leave unused at the end of a region; apply first if the log could fill up
+				double est = 64.0 * hp.grid * hp.wpb;
+				for (size_t j = 0; j < n; ++j)
+					est += (double)n_slots * (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)e->klist[b + j] + 1) *
+					       std::ldexp(1.25, 1 - (int)e->s_bits);
+				if (e->log_pending && e->log_est + est > 0.7 * (double)e->log_cap)
+					if (int rc = apply_log(e)) return rc;
+				a.log = e->d_log;
+				a.log_fill = e->d_logfill;
+				a.log_regions = e->log_regions;
+				a.log_region_cap = e->log_region_cap;
+				e->log_est += est;
+				e->log_pending = true;
+			}
+			a.sketch0 = e->d_sketch;
 			hipEvent_t ev0 = nullptr, ev1 = nullptr;
 			if (e->profiling) {
 				HIP_TRY(hipEventCreate(&ev0));
@@ -389,17 +549,11 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			HIP_TRY(hipEventCreate(&ev1));
 			HIP_TRY(hipEventRecord(ev0, e->stream));
 		}
-		a.queue = e->d_queue;
-		a.queue_rows = queue_rows;
 		a.t1 = e->d_t1[ki];
 		a.gapt = e->d_gapt;
 		a.gap = e->gap;
 		a.gap_first = (a.k - e->gap) / 2;
-		const size_t smem_k = smem_for(stride, kind, a.k, e->gap);
-		if (kind == KIND_FAST)
-			HIP_TRY(ntc::launch_sketch_fast(a, grid, smem_k, e->stream));
-		else
-			HIP_TRY(ntc::launch_hash(0, a, grid, smem_k, e->stream));
+		HIP_TRY(ntc::launch_hash(0, a, grid, smem, e->stream));
 		if (e->profiling) {
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
@@ -429,8 +583,8 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		if (cfg->n_k != 1) return fail(NTC_ERR_ARG, "ntc_create: gap seed does not support multiple k");
 		if (cfg->gap % 2 != cfg->k[0] % 2 || cfg->gap >= cfg->k[0])
 			return fail(NTC_ERR_ARG, "ntc_create: gap size and kmer must have the same modulus");
-		if (cfg->flags & (NTC_FLAG_SIMPLE_KERNEL | NTC_FLAG_FAST_KERNEL))
-			return fail(NTC_ERR_ARG, "ntc_create: spaced seeds need the default (H-filter) kernel");
+		if (cfg->flags & NTC_FLAG_SIMPLE_KERNEL)
+			return fail(NTC_ERR_ARG, "ntc_create: spaced seeds need the production kernel");
 	}
 	if (cfg->r_bits < 8 || cfg->r_bits > 30) return fail(NTC_ERR_ARG, "ntc_create: r_bits %u outside 8..30", cfg->r_bits);
 	if (cfg->s_bits < 2 || cfg->s_bits > 24) return fail(NTC_ERR_ARG, "ntc_create: s_bits %u outside 2..24", cfg->s_bits);
@@ -439,6 +593,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		return fail(NTC_ERR_DEVICE, "ntc_create: no HIP device available (this library has no CPU fallback)");
 	if (cfg->device < 0 || cfg->device >= ndev) return fail(NTC_ERR_ARG, "ntc_create: device %d of %d", cfg->device, ndev);
 	HIP_TRY(hipSetDevice(cfg->device));
+	if (int rc = ensure_kernel_attrs(cfg->device)) return rc;
 	ntc_engine* e = new (std::nothrow) ntc_engine();
 	if (!e) return fail(NTC_ERR_MEMORY, "ntc_create: out of host memory");
 	e->device = cfg->device;
@@ -447,7 +602,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	e->gap = cfg->gap;
 	e->r_bits = cfg->r_bits;
 	e->s_bits = cfg->s_bits;
-	e->kernel_kind = (cfg->flags & NTC_FLAG_SIMPLE_KERNEL) ? KIND_SIMPLE : ((cfg->flags & NTC_FLAG_FAST_KERNEL) ? KIND_FAST : KIND_HF);
+	e->kernel_kind = (cfg->flags & NTC_FLAG_SIMPLE_KERNEL) ? KIND_SIMPLE : KIND_HF;
 	const size_t sk_bytes = e->klist.size() * e->plane_elems() * sizeof(uint32_t);
 	if (cfg->ext_sketch) {
 		e->d_sketch = (uint32_t*)cfg->ext_sketch;
@@ -490,9 +645,15 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the spaced-seed table on device");
 		}
 	}
+	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_DIRECT_ATOMICS) && plan_log(e, cfg->log_entries)) {
+		if (hipMalloc((void**)&e->d_log, e->log_cap * 4) != hipSuccess || hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) != hipSuccess) {
+			ntc_destroy(e);
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log on device", (unsigned long long)e->log_cap);
+		}
+	}
 	e->hfk.resize(e->klist.size());
 	for (size_t ki = 0; ki < e->klist.size(); ++ki)
-		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki]);
+		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki], (uint32_t)(ki * e->plane_elems()));
 	int rc = ntc_reset(e);
 	if (rc) {
 		ntc_destroy(e);
@@ -515,7 +676,12 @@ void ntc_destroy(ntc_engine* e)
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
-	if (e->d_queue) (void)hipFree(e->d_queue);
+	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2})
+		if (d) (void)hipFree(d);
+	for (auto& pr : e->apply_pending) {
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
+	}
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);
@@ -536,11 +702,16 @@ int ntc_reset(ntc_engine* e)
 	HIP_TRY(hipSetDevice(e->device));
 	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->hll_bits ? (sizeof(uint32_t) << e->hll_bits) : e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
 	e->hll_reads_seen = 0;
+	if (e->d_logfill) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
+	e->log_pending = false;
+	e->log_est = 0.0;
 	HIP_TRY(hipMemsetAsync(e->d_f1, 0, e->klist.size() * 8, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (int rc = drain_events(e)) return rc;
 	e->ms_total = 0.0;
 	e->launches = 0;
+	e->apply_ms = 0.0;
+	e->applies = 0;
 	return 0;
 }
 
@@ -707,12 +878,16 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 	// ---- enqueue: copy + kernels, in order on the engine's stream (asynchronous; ntc_sync / ntc_finish wait) ----
 	{
 		std::lock_guard<std::mutex> lk(e->mu);
-		HIP_TRY(hipMemcpyAsync(sl->d_stage, hs, (size_t)n_slots * stride, hipMemcpyHostToDevice, e->stream));
-		if (need_meta) HIP_TRY(hipMemcpyAsync(sl->d_meta, sl->h_meta, n_slots * 4, hipMemcpyHostToDevice, e->stream));
-		int rc = run_batch(e, sl->d_stage, need_meta ? sl->d_meta : nullptr, n_slots, (uint32_t)len0, stride);
-		if (rc) return rc;
-		HIP_TRY(hipEventRecord(sl->done, e->stream));
+		if (hipMemcpyAsync(sl->d_stage, hs, (size_t)n_slots * stride, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+		    (need_meta && hipMemcpyAsync(sl->d_meta, sl->h_meta, n_slots * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess)) {
+			(void)hipStreamSynchronize(e->stream); // nothing may still read the pinned pair when it is handed out again
+			return fail(NTC_ERR_DEVICE, "ntc_submit: host to device copy failed");
+		}
+		const int rc = run_batch(e, sl->d_stage, need_meta ? sl->d_meta : nullptr, n_slots, (uint32_t)len0, stride);
+		// the copies above are in flight whatever run_batch said: the pair may only be reused after them
 		sl->used = true;
+		if (hipEventRecord(sl->done, e->stream) != hipSuccess) (void)hipStreamSynchronize(e->stream);
+		if (rc) return rc;
 	}
 	return 0;
 }
@@ -734,6 +909,7 @@ int ntc_finish(ntc_engine* e, uint16_t* t_counter_out, uint32_t* p_hist_out, uin
 	HIP_TRY(hipSetDevice(e->device));
 	const size_t nk = e->klist.size();
 	const uint64_t per_sample = 1ull << e->r_bits;
+	if (int rc = apply_log(e)) return rc; // pending increments first: compEst reads the counters (ntcard.cpp:240-247)
 	if (t_counter_out && !e->d_out16) {
 		if (hipMalloc((void**)&e->d_out16, 2 * per_sample * sizeof(uint16_t)) != hipSuccess)
 			return fail(NTC_ERR_MEMORY, "ntc_finish: cannot allocate uint16 staging");
@@ -791,9 +967,22 @@ int ntc_merge_counters(ntc_engine* e, const uint16_t* t_counter, const uint64_t*
 	return 0;
 }
 
+int ntc_flush(ntc_engine* e)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_flush: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	return apply_log(e);
+}
+
 int ntc_device_state(ntc_engine* e, void** d_sketch_u32, uint64_t* n_counters, void** d_f1_u64)
 {
 	if (!e) return fail(NTC_ERR_ARG, "ntc_device_state: null engine");
+	{
+		std::lock_guard<std::mutex> lk(e->mu);
+		HIP_TRY(hipSetDevice(e->device));
+		if (int rc = apply_log(e)) return rc; // the caller is about to read or reduce the counters
+	}
 	if (d_sketch_u32) *d_sketch_u32 = e->d_sketch;
 	if (n_counters) *n_counters = e->klist.size() * e->plane_elems();
 	if (d_f1_u64) *d_f1_u64 = e->d_f1;
@@ -813,7 +1002,8 @@ int ntc_hash_dump_device(int32_t device, void* stream, const void* d_slots, uint
 	HIP_TRY(hipSetDevice(device));
 	unsigned grid = 0;
 	size_t smem = 0;
-	if (int rc = hash_grid(device, n_reads, stride, KIND_SIMPLE, k, grid, smem)) return rc;
+	if (int rc = ensure_kernel_attrs(device)) return rc;
+	if (int rc = hash_grid(device, n_reads, stride, grid, smem)) return rc;
 	ntc::HashArgs a;
 	std::memset(&a, 0, sizeof a);
 	a.slots = (const unsigned char*)d_slots;
@@ -855,6 +1045,7 @@ int ntc_hll_create(uint32_t k, uint32_t n_bits, int32_t device, void* stream, nt
 		return fail(NTC_ERR_DEVICE, "ntc_hll_create: no HIP device available (this library has no CPU fallback)");
 	if (device < 0 || device >= ndev) return fail(NTC_ERR_ARG, "ntc_hll_create: device %d of %d", device, ndev);
 	HIP_TRY(hipSetDevice(device));
+	if (int rc = ensure_kernel_attrs(device)) return rc;
 	ntc_engine* e = new (std::nothrow) ntc_engine();
 	if (!e) return fail(NTC_ERR_MEMORY, "ntc_hll_create: out of host memory");
 	e->device = device;
@@ -911,6 +1102,17 @@ int ntc_kernel_time(ntc_engine* e, double* ms_total, uint64_t* launches)
 	if (int rc = drain_events(e)) return rc;
 	if (ms_total) *ms_total = e->ms_total;
 	if (launches) *launches = e->launches;
+	return 0;
+}
+
+int ntc_apply_time(ntc_engine* e, double* ms_total, uint64_t* applies)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_apply_time: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	if (int rc = drain_events(e)) return rc;
+	if (ms_total) *ms_total = e->apply_ms;
+	if (applies) *applies = e->applies;
 	return 0;
 }
 

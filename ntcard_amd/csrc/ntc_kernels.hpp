@@ -24,8 +24,6 @@ struct HashArgs {
 	unsigned long long* f1;     // MODE 0: F1 of this k
 	uint64_t* dump;             // MODE 1: [n_slots][max_win]
 	uint32_t* dump_count;       // MODE 1: [n_slots]
-	void* queue;                // fast kernel: per-wave hit queues, [grid*4][queue_rows][64] x 16 B
-	uint32_t queue_rows;        // rows (hits per lane) each wave queue can hold
 	const void* t1;             // H-filter kernel: [ceil(k/2)][16] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seed pairs (device)
 	const void* gapt;           // H-filter kernel, spaced seed: [ceil(gap/2)][16] x {f.Hd, r.Hd, 0, 0} terms to XOR out
 	uint32_t gap, gap_first;    // number of don't-care positions and index of the first one (ntcard.cpp:407-413)
@@ -45,6 +43,8 @@ struct HfK {
 	uint32_t* sketch;           // uint32 [2][1<<r_bits] plane pair of this k (nthll: uint32 M[1<<hll_bits])
 	unsigned long long* f1;     // F1 of this k
 	const void* t1;             // [ceil(k/2)][16] x {fwd.lo, fwd.hi, rev.lo, rev.hi} pre-rotated seed pairs (device)
+	uint32_t key_base;          // index of this k's first counter in the engine's sketch array (hit-log keys are global indices)
+	uint32_t pad2_;
 	uint32_t tabh[kMainSlots][2]; // per (in,out) base pair: {Tf.Hd, Tr.Hd} step terms of the H halves
 };
 struct HfArgs {
@@ -56,16 +56,48 @@ struct HfArgs {
 	uint32_t n_k;               // 1..kMaxFusedK
 	uint32_t gap, gap_first;    // spaced seed: single k only
 	uint32_t hll_bits;          // nthll mode: single k only
+	uint32_t log_regions, log_region_cap; // hit log geometry (0 regions: ntComp's increment is a direct device atomic)
+	uint32_t* log;              // [log_regions][log_region_cap] counter indices of sampled k-mers, relative to sketch0
+	uint32_t* log_fill;         // [log_regions] entries used per region (persists across launches until the log is applied)
+	uint32_t* sketch0;          // the engine's whole sketch array (overflow fallback of the log)
 	const void* gapt;
 	const uint32_t* hll_thr;
 	uint32_t tabg[kMainSlots][2]; // spaced seed, rolling form: per (leaving, entering) base pair of the don't-care block
 	HfK ks[kMaxFusedK];
 };
 
+// ---- deferred sketch update (ntc_apply.hip) ----
+// A1/A2: radix partition of key runs.  Input run `seg` = in[seg * in_cap, +min(in_cnt[seg], in_cap)).
+//   mode 0: workgroup w reads runs w, w + grid, ...                      (first pass over the raw log regions)
+//   mode 1: workgroup w = b * parts + p reads runs (p + t * parts) * nb_in + b, t = 0, 1, ...   (bucket b of pass 1)
+// Output run (w, digit) = out[(w * 2^bits + digit) * out_cap, +out_cnt[w * 2^bits + digit]).
+struct SplitArgs {
+	const uint32_t* in;
+	const uint32_t* in_cnt;
+	uint32_t in_cap, n_in;
+	uint32_t mode, parts, nb_in;
+	uint32_t shift, bits;
+	uint32_t out_cap;
+	uint32_t* out;
+	uint32_t* out_cnt;
+	uint32_t* sketch; // uint32 [2][1 << r_bits] of this k: overflow fallback
+};
+// A3: slice s = keys [s << slice_bits, (s + 1) << slice_bits).  mode 0: raw regions (one slice), 1: after one
+// split pass (runs (w1, s), w1 < nwg1), 2: after two (runs ((b, p), d2), s = b * nb2 + d2, p < parts).
+struct CountArgs {
+	const uint32_t* in;
+	const uint32_t* in_cnt;
+	uint32_t in_cap, n_in;
+	uint32_t mode, nb1, nwg1, parts, nb2;
+	uint32_t slice_bits, n_slices;
+	uint32_t* sketch;
+};
+hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st);
+hipError_t launch_count(const CountArgs& a, unsigned grid, hipStream_t st);
+hipError_t set_apply_smem_limit();
+
 hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_hash_smem_limit(size_t smem);
-hipError_t launch_sketch_fast(const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
-hipError_t set_sketch_fast_smem_limit(size_t smem);
 hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st);
 hipError_t set_sketch_hf_smem_limit(size_t smem);
 bool sketch_hf_deep_prefetch(uint32_t stride);

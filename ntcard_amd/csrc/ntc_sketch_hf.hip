@@ -98,9 +98,6 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 	return code;
 }
 
-#ifndef NTC_EXP_NO_ATOMIC
-#define NTC_EXP_NO_ATOMIC 0
-#endif
 #ifndef NTC_EXP_ABL
 #define NTC_EXP_ABL 0 // ablations of the walk: 1 no record, 2 no table lookup, 3 no data reads
 #endif
@@ -183,6 +180,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	__syncthreads();
 	const unsigned char* tabHb = reinterpret_cast<const unsigned char*>(tabH[0]);
 	uint32_t* sketch_k = a.ks[0].sketch;
+	uint32_t key_base = a.ks[0].key_base;
 
 	// sample windows on the top bits (ntcard.cpp:135-138); VGPR-resident on purpose (SGPR sources halve the VALU rate)
 	uint32_t lo0 = 1u << (31 - a.s_bits);
@@ -196,6 +194,31 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 	const uint64_t n_wb = (a.n_slots + 63) / 64;
+	// Hit log: ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is not executed here.  The wave appends the counter
+	// index of every sampled k-mer to its private log regions gwave, gwave + W, ... (W = waves of this launch) with one
+	// coalesced store per resolve round; ntc_apply.hip adds them to the sketch later (counting commutes).  A wave
+	// that runs out of regions falls back to the direct atomic, which is exact as well.
+	const bool use_log = kMode != 2 && a.log_regions != 0;
+	const uint32_t log_w = gridDim.x * wpb;
+	uint32_t lreg = gwave, lfill = 0;
+	if (use_log && lreg < a.log_regions) lfill = __builtin_amdgcn_readfirstlane(a.log_fill[lreg]);
+	auto log_emit = [&](bool hit, uint32_t key) {
+		const uint64_t m = ballot(hit);
+		if (m == 0) return;
+		const uint32_t c = (uint32_t)__popcll(m);
+		while (lreg < a.log_regions && c > a.log_region_cap - lfill) { // region full: book its fill, take this wave's next one
+			if (lane == 0) a.log_fill[lreg] = lfill;
+			lreg += log_w;
+			lfill = lreg < a.log_regions ? __builtin_amdgcn_readfirstlane(a.log_fill[lreg]) : 0u;
+		}
+		if (lreg < a.log_regions) {
+			const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			if (hit) a.log[(uint64_t)lreg * a.log_region_cap + lfill + pos] = key;
+			lfill += c;
+		} else if (hit) {
+			atomicAdd(a.sketch0 + key, 1u);
+		}
+	};
 	uint64_t f1_acc[kMaxFusedK] = {0, 0, 0, 0};
 	uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
 
@@ -274,6 +297,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		t1 = t1_base + t1_off[ki];
 		tabHb = reinterpret_cast<const unsigned char*>(tabH[ki]);
 		sketch_k = a.ks[ki].sketch;
+		key_base = a.ks[ki].key_base;
 		shb = (0u - k) & 3u;
 		uint64_t f1_wave = 0;
 		int32_t endq = (int32_t)(len < wlim + k - 1 ? len : wlim + k - 1); // steps q in [0,endq)
@@ -353,11 +377,13 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 					rhi ^= t1v.w;
 				}
 			}
+			bool hit = false;
+			uint32_t key = 0;
 			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
 				const uint32_t hi = rev ? rhi : fhi;
 				const uint32_t lo = rev ? rlo : flo;
-				if (a.hll_bits != 0) {
+				if constexpr (kMode == 2) {
 					// nthll's ntComp (nthll.cpp:92-97): bucket = low bits, value = leading zeros of the rest
 					const uint32_t bmask = (1u << a.hll_bits) - 1u;
 					const uint32_t lo_rest = lo & ~bmask;
@@ -365,16 +391,19 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 						const uint32_t run0 = hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo_rest);
 						atomicMax(sketch_k + (lo & bmask), run0);
 					}
-					return;
+				} else {
+					// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+					const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+					const bool c0 = (hi >> (31 - s_bits)) == 1u;
+					hit = c0 | c1;
+					key = key_base + (lo & rmask) + (c1 ? rbuck : 0u);
 				}
-				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
-				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
-				const bool c0 = (hi >> (31 - s_bits)) == 1u;
-#if NTC_EXP_NO_ATOMIC
-				if ((c0 | c1) && lo == 0x12345678u && hi == 0x9abcdef0u) atomicAdd(sketch_k, 1u); // A/B experiment
-#else
-				if (c0 | c1) atomicAdd(sketch_k + (lo & rmask) + (c1 ? rbuck : 0u), 1u);
-#endif
+			}
+			if constexpr (kMode != 2) {
+				if (use_log)
+					log_emit(hit, key); // the increment itself happens later (ntc_apply.hip)
+				else if (hit)
+					atomicAdd(a.sketch0 + key, 1u);
 			}
 		};
 		// End of a 32-step block: queue the block's sampled steps as (lane, step) pairs.  The queue is ONE register
@@ -725,6 +754,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	}
 	for (uint32_t j = 0; j < n_k; ++j)
 		if (lane == 0 && f1_acc[j]) atomicAdd(a.ks[j].f1, (unsigned long long)f1_acc[j]);
+	if (use_log && lane == 0 && lreg < a.log_regions) a.log_fill[lreg] = lfill;
 }
 
 hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st)

@@ -14,7 +14,7 @@ from . import _abi
 from ._abi import NtcConfig, NtcError, check
 
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
-FLAG_FAST_KERNEL = 2  # NTC_FLAG_FAST_KERNEL: first tuned kernel (full hash in the loop)
+FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 
 
@@ -28,7 +28,7 @@ def _np_ptr(a):
 
 
 class Engine:
-    def __init__(self, klist, gap=0, r_bits=27, s_bits=7, device=0, stream=None, ext_sketch=None, ext_f1=None, flags=0):
+    def __init__(self, klist, gap=0, r_bits=27, s_bits=7, device=0, stream=None, ext_sketch=None, ext_f1=None, flags=0, log_entries=0):
         self._lib = _abi.lib()
         self.klist = [int(k) for k in klist]
         self.gap, self.r_bits, self.s_bits, self.device = int(gap), int(r_bits), int(s_bits), int(device)
@@ -42,6 +42,7 @@ class Engine:
         cfg.ext_sketch = C.c_void_p(ext_sketch.data_ptr()) if ext_sketch is not None else None
         cfg.ext_f1 = C.c_void_p(ext_f1.data_ptr()) if ext_f1 is not None else None
         cfg.flags = int(flags)
+        cfg.log_entries = int(log_entries)
         h = C.c_void_p()
         check(self._lib.ntc_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -88,6 +89,10 @@ class Engine:
     def sync(self):
         check(self._lib.ntc_sync(self._h))
 
+    def flush(self):
+        """apply the pending hit log to the device sketch (asynchronous on the engine's stream)"""
+        check(self._lib.ntc_flush(self._h))
+
     def finish(self, counters=False, p_hist=True):
         """-> (t_counter uint16[nk,2,2^r] | None, p_hist uint32[nk,2,65536] | None, f1 uint64[nk])"""
         nk = len(self.klist)
@@ -115,6 +120,11 @@ class Engine:
     def kernel_time(self):
         ms, n = C.c_double(), C.c_uint64()
         check(self._lib.ntc_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def apply_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        check(self._lib.ntc_apply_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
 

@@ -124,12 +124,13 @@ def test_sketch_device_batch_matches_oracle(nt, dist, klist, r_bits, s_bits):
 
 
 def test_simple_and_tuned_kernels_agree(nt):
-    """two independently written kernels (ntc_kernels.hip vs ntc_sketch_fast.hip) on dirty, ragged input"""
+    """independently written kernels (ntc_kernels.hip vs ntc_sketch_hf.hip) and both forms of the sketch update
+    (hit log + partitioned apply vs one device atomic per sampled k-mer) on dirty, ragged input"""
     rng = random.Random(4242)
     reads = [rseq(rng, rng.choice([40, 100, 149, 150, 150, 150, 151, 200]), pn=rng.choice([0, 0, 0.003, 0.05])) for _ in range(6000)]
     for klist, sb in (([32], 7), ([25, 61], 3)):
         res = []
-        for flags in (0, nt.FLAG_SIMPLE_KERNEL, nt.FLAG_FAST_KERNEL):
+        for flags in (0, nt.FLAG_SIMPLE_KERNEL, nt.FLAG_DIRECT_ATOMICS):
             with nt.Engine(klist, r_bits=19, s_bits=sb, flags=flags) as e:
                 e.submit_reads(reads)
                 res.append(e.finish(counters=True))
@@ -161,6 +162,45 @@ def test_host_submit_ragged_and_chunked(nt):
         tc, ph, f1 = e.finish(counters=True)
     oc, of1 = orc.sketch_reads(shorts, [20], 0, 16, 3)
     assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+
+
+@pytest.mark.parametrize("r_bits,klist,log_entries", [
+    (27, [32], 0),            # default geometry: two partition passes (8 + 5 bits) above 2^15-counter slices
+    (27, [32], 1 << 16),      # log much smaller than the batch: several applies + per-wave overflow to direct atomics
+    (20, [32, 40, 50], 0),    # one partition pass, key space not a power of two (3 planes)
+    (14, [20], 0),            # the whole sketch is one slice: no partition pass
+    (12, [15, 16, 17, 18, 19], 1 << 14),
+    (30, [32], 1 << 22),      # rBits = 30: two 8-bit passes
+])
+def test_hit_log_geometries_match_direct_atomics(nt, r_bits, klist, log_entries):
+    """ntComp's increment is deferred (hit log -> partition -> LDS histogram, ntc_apply.hip); every log geometry must
+    give exactly the counters of the literal one-atomic-per-hit form (ntcard.cpp:142-143), across several submits"""
+    n, L, stride = 60_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 77, 0, n, L, stride, 1, genome_len=200_000)
+    res = []
+    for flags, le in ((nt.FLAG_DIRECT_ATOMICS, 0), (0, log_entries)):
+        with nt.Engine(klist, r_bits=r_bits, s_bits=5, flags=flags, log_entries=le) as e:
+            e.submit_device(d.data_ptr(), 20_032, L, stride)
+            e.submit_device(d.data_ptr() + 20_032 * stride, n - 20_032, L, stride)
+            e.flush()
+            e.submit_device(d.data_ptr(), 6400, L, stride)
+            _, ph, f1 = e.finish()
+            sk, ncnt, _ = e.device_state()
+            torch.cuda.synchronize()
+            raw = torch.as_tensor(_DevArray(sk, ncnt), device="cuda").clone()
+            res.append((ph.copy(), f1.copy(), raw))
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][2], res[1][2])   # the uint32 counters themselves (before the uint16 wrap)
+    assert int(res[0][2].sum(dtype=torch.int64)) > 0
+
+
+class _DevArray:
+    """zero-copy view of a device int32 array for torch.as_tensor (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
 
 
 def test_golden_hist_from_reference(nt, golden_dir, tmp_path):
