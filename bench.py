@@ -46,6 +46,8 @@ def parse():
                     help="g: reads from a 100 Mbp random genome, 1%% subs, 0.05%% N; u: i.i.d. uniform ACGT")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
+    ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
     return ap.parse_args()
 
@@ -102,6 +104,8 @@ def main():
     import torch.distributed as dist
     import ntcard_amd as nt
     from ntcard_amd import parallel
+    if args.lib:
+        nt._abi.LIB_PATH = os.path.abspath(args.lib)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -145,7 +149,7 @@ def main():
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
     eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
-                    ext_sketch=sketch, ext_f1=f1_dev)
+                    ext_sketch=sketch, ext_f1=f1_dev, flags=nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,6 +159,8 @@ def main():
 
     for _ in range(W):
         eng.submit_device(wb.data_ptr(), R, L, stride)
+    if W > 0:
+        eng.flush()  # warm the deferred sketch update too (allocates its partition scratch)
     if use_dist and W > 0:  # warm the RCCL path too (same collectives as the timed merge)
         parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits,
                                            lambda c, h: nt.value_hist_device(c.data_ptr(), c.numel(), h.data_ptr(), device=local_rank, stream=stream), dst=0)
@@ -166,6 +172,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         eng.submit_device(batches[s % nb].data_ptr(), R, L, stride)
+    eng.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter
     ph_merged = None
     if use_dist:
         # the path's one exchange step: reduce-scatter of the sketches, per-rank value histograms of the summed slices,
@@ -182,6 +189,7 @@ def main():
     dt_max = float(tmax.item())
 
     ker_ms, launches = eng.kernel_time()
+    apply_ms, applies = eng.apply_time()
     if ph_merged is not None:
         eng.sync()
         ph, f1 = ph_merged.cpu().numpy().astype("uint32"), f1_dev.cpu().numpy().astype("uint64")
@@ -222,6 +230,8 @@ def main():
                          "kernel": "sketch_hf_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_launch_kmers},
+            # deferred sketch update (ntc_apply.hip), HIP-event timed like the hash kernel; inside the timed region
+            "sketch_apply": {"applies": applies, "total_ms": apply_ms, "ns_per_increment": apply_ms * 1e6 / max(hits, 1)},
             # the kernel is VALU-issue bound, so also price it against the vector ALUs.  ops_per_step is
             # read off the ISA of the steady-state walk (10 VALU per base-step + 8 per 4-step group); the whole kernel
             # issues ~19.4 VALU per base-step (PMC SQ_INSTS_VALU, profiles/), peak = 256 CUs x 128 lanes x 2.4 GHz.

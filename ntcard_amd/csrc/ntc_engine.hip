@@ -86,6 +86,7 @@ int ensure_kernel_attrs(int dev)
 	HIP_TRY(ntc::set_sketch_hf_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_hash_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_apply_smem_limit());
+	HIP_TRY(ntc::set_sketch_bs_smem_limit(kMaxDynLds));
 	done[dev] = 1;
 	return 0;
 }
@@ -230,6 +231,9 @@ struct ntc_engine {
 		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
 	} ap;
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
+	void* d_t4 = nullptr;           // K1b: closed-form table, 4 bases per entry (NULL: K1b not used by this engine)
+	uint32_t* d_redo = nullptr;     // K1b: [redo_cap] slot indices handed to K1 + the count word behind them
+	uint64_t redo_cap = 0;
 	double apply_ms = 0.0;
 	uint64_t applies = 0;
 	uint32_t hll_bits = 0;       // != 0: nthll engine (d_sketch holds uint32 M[1<<hll_bits])
@@ -459,11 +463,29 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		return 0;
 	}
 	if (kind == KIND_HF) {
+		hipEvent_t ev0 = nullptr, ev1 = nullptr;
+		if (e->profiling) {
+			HIP_TRY(hipEventCreate(&ev0));
+			HIP_TRY(hipEventCreate(&ev1));
+			HIP_TRY(hipEventRecord(ev0, e->stream));
+		}
+		if (e->d_log) {
+			// upper estimate of the sampled k-mers of this batch (both samples ~2^-sBits of the windows each, App. B of
+			// SURVEY.md) + what every wave may leave unused at the end of a region; apply first if the log could fill up
+			double est = 64.0 * 4096;
+			for (uint32_t k : e->klist)
+				est += (double)n_slots * (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+			if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
+				if (int rc = apply_log(e)) return rc;
+			e->log_est += est;
+			e->log_pending = true;
+		}
 		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
 		// a group whose closed-form tables would push the CU below 12 waves (and below what its members reach alone) is split in two
-		std::function<int(size_t, size_t)> launch_group = [&](size_t b, size_t n) -> int {
+		std::function<int(size_t, size_t, const unsigned char*, uint64_t, const uint32_t*, const uint32_t*)> launch_group =
+		    [&](size_t b, size_t n, const unsigned char* slots, uint64_t ns, const uint32_t* gather, const uint32_t* gather_count) -> int {
 			HfPlan hp;
-			if (int rc = hf_plan(e->device, n_slots, stride, &e->klist[b], (uint32_t)n, e->gap, hp)) {
+			if (int rc = hf_plan(e->device, ns, stride, &e->klist[b], (uint32_t)n, e->gap, hp)) {
 				if (n == 1) return rc;
 				hp.waves_per_cu = 0;
 			}
@@ -475,14 +497,14 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				worst_single = std::min(worst_single, one.waves_per_cu);
 			}
 			if (n > 1 && hp.waves_per_cu < 12 && hp.waves_per_cu < worst_single) {
-				if (int rc = launch_group(b, n / 2)) return rc;
-				return launch_group(b + n / 2, n - n / 2);
+				if (int rc = launch_group(b, n / 2, slots, ns, gather, gather_count)) return rc;
+				return launch_group(b + n / 2, n - n / 2, slots, ns, gather, gather_count);
 			}
 			ntc::HfArgs a;
 			std::memset(&a, 0, sizeof a);
-			a.slots = d_slots;
+			a.slots = slots;
 			a.meta = d_meta;
-			a.n_slots = n_slots;
+			a.n_slots = ns;
 			a.stride = stride;
 			a.read_len = read_len;
 			a.r_bits = e->r_bits;
@@ -491,41 +513,91 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.gap = e->gap;
 			a.gap_first = (e->klist[b] - e->gap) / 2;
 			a.gapt = e->d_gapt;
+			a.gather = gather;
+			a.gather_count = gather_count;
 			if (e->gap) ntc::build_gap_roll_table(e->klist[b], a.gap_first, e->gap, a.tabg);
 			for (size_t j = 0; j < n; ++j)
 				a.ks[j] = e->hfk[b + j];
 			if (e->d_log) {
-				// upper estimate of the sampled k-mers of this launch (both samples ~2^-sBits of the windows each, App. B of
-				// SURVEY.md) + what every wave may leave unused at the end of a region; apply first if the log could fill up
-				double est = 64.0 * hp.grid * hp.wpb;
-				for (size_t j = 0; j < n; ++j)
-					est += (double)n_slots * (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)e->klist[b + j] + 1) *
-					       std::ldexp(1.25, 1 - (int)e->s_bits);
-				if (e->log_pending && e->log_est + est > 0.7 * (double)e->log_cap)
-					if (int rc = apply_log(e)) return rc;
 				a.log = e->d_log;
 				a.log_fill = e->d_logfill;
 				a.log_regions = e->log_regions;
 				a.log_region_cap = e->log_region_cap;
-				e->log_est += est;
-				e->log_pending = true;
 			}
 			a.sketch0 = e->d_sketch;
-			hipEvent_t ev0 = nullptr, ev1 = nullptr;
-			if (e->profiling) {
-				HIP_TRY(hipEventCreate(&ev0));
-				HIP_TRY(hipEventCreate(&ev1));
-				HIP_TRY(hipEventRecord(ev0, e->stream));
-			}
 			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
-			if (e->profiling) {
-				HIP_TRY(hipEventRecord(ev1, e->stream));
-				e->pending.emplace_back(ev0, ev1);
-			}
 			return 0;
 		};
-		for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)
-			if (int rc = launch_group(b, std::min<size_t>(ntc::kMaxFusedK, e->klist.size() - b))) return rc;
+		// K1b (bit-sliced filter walk) takes the whole 2048-slot tiles of an equal-length batch when it is instantiated
+		// for this k; reads with a non-ACGTU byte come back on a device list and go through K1 in gather mode, and so
+		// does the tail of the batch.
+		uint64_t bs_slots = 0;
+		const uint32_t k0 = e->klist[0];
+		if (e->d_t4 && d_meta == nullptr && read_len >= k0 && stride >= 128 && stride <= 160 && read_len - k0 + 1 <= 255 &&
+		    ntc::sketch_bs_smem(k0, stride) <= kMaxDynLds && n_slots >= 2048) {
+			const uint64_t n_tiles = n_slots / 2048;
+			bs_slots = n_tiles * 2048;
+			if (bs_slots > e->redo_cap) {
+				HIP_TRY(hipStreamSynchronize(e->stream));
+				if (e->d_redo) (void)hipFree(e->d_redo);
+				e->d_redo = nullptr;
+				e->redo_cap = 0;
+				if (hipMalloc((void**)&e->d_redo, (bs_slots + 1) * 4) != hipSuccess)
+					return fail(NTC_ERR_MEMORY, "cannot allocate the %llu-entry redo list on device", (unsigned long long)bs_slots);
+				e->redo_cap = bs_slots;
+			}
+			uint32_t* redo_count = e->d_redo + e->redo_cap; // the word behind the list
+			HIP_TRY(hipMemsetAsync(redo_count, 0, 4, e->stream));
+			DevInfo di;
+			if (int rc = device_info(e->device, di)) return rc;
+			ntc::BsArgs ba;
+			std::memset(&ba, 0, sizeof ba);
+			ba.slots = d_slots;
+			ba.n_tiles = n_tiles;
+			ba.stride = stride;
+			ba.read_len = read_len;
+			ba.k = k0;
+			ba.r_bits = e->r_bits;
+			ba.s_bits = e->s_bits;
+			ba.nq = (read_len - k0 + 1 + 63) / 64;
+			ba.key_base = 0;
+			if (e->d_log) {
+				ba.log = e->d_log;
+				ba.log_fill = e->d_logfill;
+				ba.log_regions = e->log_regions;
+				ba.log_region_cap = e->log_region_cap;
+			}
+			ba.sketch0 = e->d_sketch;
+			ba.f1 = e->d_f1;
+			ba.t4 = e->d_t4;
+			ba.redo_list = e->d_redo;
+			ba.redo_count = redo_count;
+#ifdef NTC_BS_TIMERS
+			static uint64_t* dbg = nullptr;
+			if (!dbg) {
+				HIP_TRY(hipMalloc((void**)&dbg, 16 * 8));
+				HIP_TRY(hipMemset(dbg, 0, 16 * 8));
+				std::atexit([] {
+					uint64_t h[16];
+					if (hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+						fprintf(stderr, "K1b cycles (sum over waves): walker barrier %llu warm %llu (fetch %llu steps %llu) steady steps %llu drain %llu | stager barrier %llu dump+dirty %llu stage %llu\n",
+						        (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[4], (unsigned long long)h[5], (unsigned long long)h[2], (unsigned long long)h[3],
+						        (unsigned long long)h[8], (unsigned long long)h[9], (unsigned long long)h[10]);
+				});
+			}
+			ba.dbg = dbg;
+#endif
+			HIP_TRY(ntc::launch_sketch_bs(ba, (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)di.cus), e->stream));
+			if (int rc = launch_group(0, 1, d_slots, bs_slots, e->d_redo, redo_count)) return rc;
+		}
+		if (bs_slots < n_slots)
+			for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)
+				if (int rc = launch_group(b, std::min<size_t>(ntc::kMaxFusedK, e->klist.size() - b), d_slots + bs_slots * stride, n_slots - bs_slots, nullptr, nullptr))
+					return rc;
+		if (e->profiling) {
+			HIP_TRY(hipEventRecord(ev1, e->stream));
+			e->pending.emplace_back(ev0, ev1);
+		}
 		return 0;
 	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
@@ -651,6 +723,15 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log on device", (unsigned long long)e->log_cap);
 		}
 	}
+	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->klist.size() == 1 && e->gap == 0 &&
+	    ntc::sketch_bs_supports(e->klist[0], e->s_bits)) {
+		std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[0]) * 256 * 4);
+		ntc::build_t4(e->klist[0], t4.data());
+		if (hipMalloc(&e->d_t4, t4.size() * 4) != hipSuccess || hipMemcpy(e->d_t4, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+			ntc_destroy(e);
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the bit-sliced kernel on device");
+		}
+	}
 	e->hfk.resize(e->klist.size());
 	for (size_t ki = 0; ki < e->klist.size(); ++ki)
 		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki], (uint32_t)(ki * e->plane_elems()));
@@ -676,7 +757,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
-	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2})
+	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
 		(void)hipEventDestroy(pr.first);

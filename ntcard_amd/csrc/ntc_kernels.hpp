@@ -60,11 +60,36 @@ struct HfArgs {
 	uint32_t* log;              // [log_regions][log_region_cap] counter indices of sampled k-mers, relative to sketch0
 	uint32_t* log_fill;         // [log_regions] entries used per region (persists across launches until the log is applied)
 	uint32_t* sketch0;          // the engine's whole sketch array (overflow fallback of the log)
+	const uint32_t* gather;     // != NULL: the batch is the listed slots, gather[i] = slot index, i < *gather_count
+	const uint32_t* gather_count; // (reads the bit-sliced kernel K1b handed back: a non-ACGTU byte somewhere in the read)
 	const void* gapt;
 	const uint32_t* hll_thr;
 	uint32_t tabg[kMainSlots][2]; // spaced seed, rolling form: per (leaving, entering) base pair of the don't-care block
 	HfK ks[kMaxFusedK];
 };
+
+// K1b (sketch_bs_kernel, ntc_sketch_bs.hip): bit-sliced filter walk over whole tiles of 2048 equal-length slots
+struct BsArgs {
+	const unsigned char* slots; // tile t = slots [2048 t, 2048 (t + 1))
+	uint64_t n_tiles;
+	uint32_t stride, read_len;
+	uint32_t k, r_bits, s_bits;
+	uint32_t nq;                // 16-window blocks per wave segment: 4 waves x 16 nq windows >= read_len - k + 1
+	uint32_t key_base;
+	uint32_t log_regions, log_region_cap;
+	uint32_t* log;
+	uint32_t* log_fill;
+	uint32_t* sketch0;
+	unsigned long long* f1;
+	const void* t4;             // [k/4][256] x {fwd.lo, fwd.hi, rev.lo, rev.hi}: closed form, 4 bases per entry (code2 order)
+	uint32_t* redo_list;        // slot indices of the reads left to the lane-per-read kernel
+	uint32_t* redo_count;
+	uint64_t* dbg;              // instrumentation builds only (NTC_BS_TIMERS)
+};
+hipError_t launch_sketch_bs(const BsArgs& a, unsigned grid, hipStream_t st);
+hipError_t set_sketch_bs_smem_limit(size_t smem);
+size_t sketch_bs_smem(uint32_t k, uint32_t stride);
+bool sketch_bs_supports(uint32_t k, uint32_t s_bits);
 
 // ---- deferred sketch update (ntc_apply.hip) ----
 // A1/A2: radix partition of key runs.  Input run `seg` = in[seg * in_cap, +min(in_cnt[seg], in_cap)).

@@ -193,7 +193,9 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	const uint32_t rbuck = 1u << a.r_bits;
 
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
-	const uint64_t n_wb = (a.n_slots + 63) / 64;
+	// gather mode: the batch is a device-side list of slot indices (its length is only known on the device)
+	const uint64_t n_slots = a.gather ? (uint64_t)__builtin_amdgcn_readfirstlane(*a.gather_count) : a.n_slots;
+	const uint64_t n_wb = (n_slots + 63) / 64;
 	// Hit log: ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is not executed here.  The wave appends the counter
 	// index of every sampled k-mer to its private log regions gwave, gwave + W, ... (W = waves of this launch) with one
 	// coalesced store per resolve round; ntc_apply.hip adds them to the sketch later (counting commutes).  A wave
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	// ---- global -> LDS staging with register prefetch of the next batch (see ntc_sketch_fast.hip) ----
 	const uint32_t full_bytes = 64u * stride;
 	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
-	const bool can_prefetch = nchunk <= (uint32_t)kPref;
+	const bool can_prefetch = nchunk <= (uint32_t)kPref && a.gather == nullptr;
 	const uint64_t wb_step = (uint64_t)gridDim.x * wpb;
 	uint4 pref[kPref];
 	auto load_round = [&](uint64_t wb_, uint32_t c0) {
@@ -250,12 +252,12 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			}
 		}
 	};
-	auto is_full = [&](uint64_t wb_) { return wb_ * 64 + 64 <= a.n_slots; };
+	auto is_full = [&](uint64_t wb_) { return wb_ * 64 + 64 <= n_slots; };
 	if (can_prefetch && gwave < n_wb && is_full(gwave)) load_round(gwave, 0);
 
 	for (uint64_t wb = gwave; wb < n_wb; wb += wb_step) {
 		const uint64_t slot0 = wb * 64;
-		const uint32_t nvalid = (uint32_t)((a.n_slots - slot0) < 64 ? (a.n_slots - slot0) : 64);
+		const uint32_t nvalid = (uint32_t)((n_slots - slot0) < 64 ? (n_slots - slot0) : 64);
 		uint32_t badacc = 0;
 		// Wave priorities follow the age of the work: staging (waits on memory anyway) 0, the walk 1, the walk after
 		// its first compaction 2, compaction + resolve 3.  A batch that has been started gets finished ahead of
@@ -264,7 +266,28 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		// Slots too long for the register prefetch keep the staging at the walk's level (it would starve otherwise).
 		if (can_prefetch) __builtin_amdgcn_s_setprio(0); // without the register prefetch the staging waits for its own loads: keep its rank
 		__builtin_amdgcn_wave_barrier();
-		if (nvalid == 64 && can_prefetch) {
+		if (a.gather != nullptr) {
+			// row i of the wave's LDS block <- slot gather[slot0 + i]: lane i fetches index i, every lane then copies
+			// dwords d = lane, lane + 64, ... of the 64 x stride/4 block (row = d / (stride/4) by multiply-high)
+			const uint32_t s4 = stride >> 2, magic = 0xffffffffu / s4 + 1u;
+			const uint32_t my_idx = (uint32_t)lane < nvalid ? a.gather[slot0 + lane] : 0u;
+			const uint32_t total = nvalid * s4;
+			for (uint32_t d0 = 0; d0 < total; d0 += 64u * 8u) {
+				uint32_t v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					const uint32_t d = d0 + (uint32_t)u * 64u + (uint32_t)lane;
+					const uint32_t row = __umulhi(d, magic), col = d - row * s4;
+					const uint32_t idx = (uint32_t)__shfl((int)my_idx, (int)(row & 63u));
+					v[u] = d < total ? reinterpret_cast<const uint32_t*>(a.slots + (uint64_t)idx * stride)[col] : 0x41414141u;
+				}
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					const uint32_t d = d0 + (uint32_t)u * 64u + (uint32_t)lane;
+					if (d < total) reinterpret_cast<uint32_t*>(wdata)[d] = decode4(v[u], badacc);
+				}
+			}
+		} else if (nvalid == 64 && can_prefetch) {
 			store_round(0, badacc);
 			if (wb + wb_step < n_wb && is_full(wb + wb_step)) load_round(wb + wb_step, 0);
 		} else if (nvalid == 64) {

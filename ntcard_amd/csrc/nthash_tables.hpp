@@ -116,6 +116,31 @@ inline void build_t2(unsigned k, uint32_t* out /* t2_pairs(k)*16*4 dwords */, un
 			}
 }
 
+// Closed-form table of K1b's resolve stage, FOUR bases per entry, indexed by a packed byte of 2-bit codes in
+// code2 order (code2 = (ascii >> 1) & 3: A=0 C=1 T/U=2 G=3; base t of the group in bits 2t+1:2t):
+// entry (g, v) = XOR over t < 4, i = 4 g + t < k of  srol^(k-1-i)(seed(c_t))  and  srol^i(comp(c_t))   (nthash.hpp:220-239)
+inline unsigned t4_groups(unsigned k) { return (k + 3) / 4; }
+inline void build_t4(unsigned k, uint32_t* out /* t4_groups(k)*256*4 dwords */)
+{
+	static const unsigned code_of_code2[4] = { 0, 1, 3, 2 }; // code2 -> the A C G T numbering of seed_of()
+	for (unsigned g = 0; g < t4_groups(k); ++g)
+		for (unsigned v = 0; v < 256; ++v) {
+			uint64_t f = 0, r = 0;
+			for (unsigned t = 0; t < 4; ++t) {
+				const unsigned i = 4 * g + t;
+				if (i >= k) break;
+				const unsigned c = code_of_code2[(v >> (2 * t)) & 3u];
+				f ^= srol(seed_of(c), k - 1 - i);
+				r ^= srol(comp_of(c), i);
+			}
+			uint32_t* e = out + ((size_t)g * 256 + v) * 4;
+			e[0] = (uint32_t)f;
+			e[1] = (uint32_t)(f >> 32);
+			e[2] = (uint32_t)r;
+			e[3] = (uint32_t)(r >> 32);
+		}
+}
+
 // Spaced-seed filter table: for the p-th PAIR of don't-care positions (i, i+1), entry (a, b) holds the H halves
 // (Hd layout) of  srol^(k-1-i)(seed(a)) ^ srol^(k-2-i)(seed(b))  and  srol^i(comp(a)) ^ srol^(i+1)(comp(b)),
 // i.e. what NTMSM64 XORs out of fh / rh (nthash.hpp:641-646).  16-byte stride: {f.Hd, r.Hd, 0, 0}.

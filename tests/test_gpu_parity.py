@@ -196,6 +196,48 @@ def test_hit_log_geometries_match_direct_atomics(nt, r_bits, klist, log_entries)
     assert int(res[0][2].sum(dtype=torch.int64)) > 0
 
 
+@pytest.mark.parametrize("L,stride,s_bits,pn", [
+    (150, 152, 7, 0.0005), (150, 152, 11, 0.0), (150, 160, 7, 0.01), (128, 128, 7, 0.0), (156, 156, 8, 0.002),
+    (32, 128, 7, 0.0), (33, 132, 7, 0.001), (95, 140, 7, 0.0), (96, 144, 9, 0.0), (97, 148, 7, 0.0005), (159, 160, 7, 0.0),
+])
+def test_bit_sliced_kernel_matches_oracle(nt, L, stride, s_bits, pn):
+    """K1b (ntc_sketch_bs.hip): whole 2048-slot tiles of equal-length k=32 batches take the bit-sliced filter walk,
+    reads with a non-ACGTU byte come back through K1's gather mode, the tail of the batch through K1.  Window counts
+    around the 16-window blocks and the 4-way segment split, slot strides 128..160, lower case / U, all-N reads."""
+    rng = random.Random(L * 31 + stride)
+    n = 2048 * 3 + 777
+    reads = [rseq(rng, L, pn=pn, plow=0.05) for _ in range(n)]
+    reads[5] = b"N" * L
+    reads[2048 + 9] = (b"acgu" * 64)[:L]
+    reads[4096] = (b"ACGT" * 64)[:L - 1] + b"n"
+    buf, _ = to_slots(reads, stride=stride)
+    buf[buf == 10] = ord("A")  # padding bytes are base letters (ntc_submit_device's contract for the fast path)
+    d = torch.from_numpy(buf).cuda()
+    with nt.Engine([32], r_bits=20, s_bits=s_bits) as e:
+        e.submit_device(d.data_ptr(), n, L, stride)
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads(reads, [32], 0, 20, s_bits)
+    assert np.array_equal(f1, of1)
+    assert np.array_equal(tc, oc)
+
+
+def test_bit_sliced_kernel_agrees_with_lane_kernel_at_size(nt):
+    """2 M genome-like reads (1 % substitutions, 0.05 % N): K1b + redo list vs K1 alone, counters compared on the device"""
+    n, L, stride = 2_000_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 5, 0, n, L, stride, 1, genome_len=3_000_000)
+    res = []
+    for flags in (0, nt.FLAG_LANE_KERNEL):
+        with nt.Engine([32], r_bits=24, s_bits=7, flags=flags) as e:
+            e.submit_device(d.data_ptr(), n, L, stride)
+            _, ph, f1 = e.finish()
+            sk, ncnt, _ = e.device_state()
+            torch.cuda.synchronize()
+            res.append((ph.copy(), f1.copy(), torch.as_tensor(_DevArray(sk, ncnt), device="cuda").clone()))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][2], res[1][2])
+
+
 class _DevArray:
     """zero-copy view of a device int32 array for torch.as_tensor (__cuda_array_interface__)"""
 
