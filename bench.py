@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
+    ap.add_argument("--bitslice", action="store_true", help="use the experimental bit-sliced kernel K1b (k = 32, equal-length reads)")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
     return ap.parse_args()
@@ -149,7 +150,7 @@ def main():
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
     eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
-                    ext_sketch=sketch, ext_f1=f1_dev, flags=nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
+                    ext_sketch=sketch, ext_f1=f1_dev, flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0))
 
     def barrier():
         torch.cuda.synchronize()

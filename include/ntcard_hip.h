@@ -64,8 +64,8 @@ typedef struct {
 
 #define NTC_FLAG_NONE 0u
 #define NTC_FLAG_SIMPLE_KERNEL 1u  /* run the simple validation kernel instead of the production ones */
-#define NTC_FLAG_LANE_KERNEL 4u     /* never use the bit-sliced kernel K1b: every batch goes through the lane-per-read
-                                      kernel K1 (cross-check and A/B runs)                                        */
+#define NTC_FLAG_BITSLICE_KERNEL 4u /* use the experimental bit-sliced kernel K1b for the whole 2048-read tiles of
+                                      equal-length k = 32 batches (exact, but not yet faster than K1) */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 

@@ -723,7 +723,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log on device", (unsigned long long)e->log_cap);
 		}
 	}
-	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->klist.size() == 1 && e->gap == 0 &&
+	if (e->kernel_kind == KIND_HF && (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) && e->klist.size() == 1 && e->gap == 0 &&
 	    ntc::sketch_bs_supports(e->klist[0], e->s_bits)) {
 		std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[0]) * 256 * 4);
 		ntc::build_t4(e->klist[0], t4.data());

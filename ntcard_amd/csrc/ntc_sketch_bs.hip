@@ -19,10 +19,9 @@
 //   * the four walkers walk the SAME tile, each one quarter of the window positions (segment = 16*nq windows,
 //     preceded by the k-1 window-filling steps); a lane's 32 reads are 64*i + lane, i = 0..31; per 16-base chunk
 //     the lane fetches its 32 packed words from LDS and transposes the 32x32 bit matrix into 32 bit planes;
-//   * a walker only produces hit planes (one bit per read and window); every 8 steps it hands them to the helper on
-//     its SIMD through a double-buffered LDS area.  The helper turns them into (read, window) pairs (DPP prefix sum,
-//     LDS queue), resolves them 64 at a time with a 4-bases-per-lookup closed-form table and sends the counter index
-//     to the hit log (ntc_apply.hip);
+//   * every 16 steps the walker turns its hit planes (one bit per read and window) into (read, window) pairs (DPP
+//     prefix sum, LDS queue), resolves them 64 at a time with a 4-bases-per-lookup closed-form table and sends the
+//     counter index to the hit log (ntc_apply.hip);
 //   * a read with any non-ACGTU byte is NOT handled here: it is left out of F1 and of the sketch and its slot
 //     index is appended to a device list that the lane-per-read kernel processes right after (gather mode), which
 //     keeps ntHashIterator's N semantics (ntHashIterator.hpp:59-86) in one place.
@@ -111,8 +110,6 @@ __device__ __forceinline__ void pin31(uint32_t (&X)[31])
 constexpr int kTileReads = 2048;
 constexpr int kGroupLoads = 10;  // loads per staging group
 constexpr int kGroups = 8;       // 80 loads of 1 KiB per helper and tile: strides up to 160 B
-constexpr int kHalf = 8;         // steps per hit-plane hand-off (half a 16-window block)
-constexpr uint32_t kHitBufs = 3;     // hit-plane buffers per walker: it may run two half-blocks ahead of its helper
 constexpr uint32_t kQueueCap = 1024; // sampled (read, window) pairs a helper can hold in LDS
 
 // inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS round trip)
@@ -139,165 +136,41 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const bool walker = wave < 4;
-	const uint32_t part = (uint32_t)wave & 3u; // walker: segment of the window positions; helper: quarter of the tile + this walker's hits
+	const uint32_t part = (uint32_t)wave & 3u; // walker: segment of the window positions; helper: quarter of the tile
 	const uint32_t stride = a.stride, s4 = stride >> 2;
 	const uint32_t tile_dw = 128u * stride; // packed dwords per tile (one per 16 raw bytes)
 	const uint32_t qd = 32u * stride;       // chunks (= packed dwords) per helper quarter
 	const uint32_t cbm_words = tile_dw >> 5;
-	// LDS: [packed tile + 64 dwords][closed-form table][2 chunk-dirty bitmaps][read-dirty bitmap][flags][4 x 3 hit buffers][4 queues]
+	// LDS: [packed tile + 64 dwords][closed-form table][2 chunk-dirty bitmaps][read-dirty bitmap][4 hit buffers][4 queues]
 	uint32_t* const tile = reinterpret_cast<uint32_t*>(smem);
 	unsigned char* const t4 = smem + (size_t)(tile_dw + 64u) * 4u;
 	const uint32_t t4_bytes = (uint32_t)(K / 4) * 4096u;
 	uint32_t* const cbm0 = reinterpret_cast<uint32_t*>(t4 + t4_bytes);
 	uint32_t* const cbm1 = cbm0 + cbm_words;
 	uint32_t* const rdirty = cbm1 + cbm_words; // 64 words
-	volatile uint32_t* const ready = rdirty + 64;     // [4] half-blocks produced by walker `part`
-	volatile uint32_t* const consumed = rdirty + 68;  // [4] half-blocks taken over by helper `part`
-	uint32_t* const hitbuf = rdirty + 80 + part * (kHitBufs * (kHalf + 1) * 64u); // 3 buffers x (8 steps + the first window) x 64 lanes
-	uint32_t* const queue = rdirty + 80 + 4u * (kHitBufs * (kHalf + 1) * 64u) + part * kQueueCap;
+	uint32_t* const hitbuf = rdirty + 64 + part * (17u * 64u); // 16 steps + the first window, x 64 lanes
+	uint32_t* const queue = rdirty + 64 + 4u * (17u * 64u) + part * kQueueCap;
 	{
 		const uint4* src = reinterpret_cast<const uint4*>(a.t4);
 		for (uint32_t i = tid; i < t4_bytes / 16u; i += 512u)
 			reinterpret_cast<uint4*>(t4)[i] = src[i];
-		for (uint32_t i = tid; i < 2u * cbm_words + 80u; i += 512u)
+		for (uint32_t i = tid; i < 2u * cbm_words + 64u; i += 512u)
 			cbm0[i] = 0;
 		if (tid < 64) tile[tile_dw + tid] = 0;
 	}
-	__syncthreads(); // tables, zeroed bitmaps and flags are in place
+	__syncthreads(); // tables and zeroed bitmaps are in place
 	const uint32_t W = a.read_len - (uint32_t)K + 1u; // windows per read
-	const uint32_t Q = 16u * a.nq;                    // windows per walker segment
-	const uint32_t sb = part * Q;                     // first window (= first base) of segment `part`
-	const uint32_t hpt = 2u * a.nq;                   // half-blocks per tile
 #ifdef NTC_BS_TIMERS
 	uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
 	if (!walker) {
-		// ================= HELPER: stages quarter `part` of the next tile, resolves the hits of walker `part` =================
+		// ======================= HELPER: stages quarter `part` of the next tile while the current one is walked =======================
 		const uint32_t magic = 0xffffffffu / stride + 1u; // x / stride = umulhi(x, magic) for x < 2^19
-		const uint32_t rmask = (1u << a.r_bits) - 1u, rbuck = 1u << a.r_bits, s_bits = a.s_bits;
-		// ---- hit log (see ntc_sketch_hf.hip): this wave's regions are gwave, gwave + log_w, ... ----
-		const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + part);
-		const uint32_t log_w = gridDim.x * 4u;
-		const bool use_log = a.log_regions != 0;
-		uint32_t lreg = gwave, lfill = 0;
-		if (use_log && lreg < a.log_regions) lfill = __builtin_amdgcn_readfirstlane(a.log_fill[lreg]);
-		auto log_emit = [&](bool hit, uint32_t key) {
-			const uint64_t m = ballot(hit);
-			if (m == 0) return;
-			const uint32_t c = (uint32_t)__popcll(m);
-			while (lreg < a.log_regions && c > a.log_region_cap - lfill) {
-				if (lane == 0) a.log_fill[lreg] = lfill;
-				lreg += log_w;
-				lfill = lreg < a.log_regions ? __builtin_amdgcn_readfirstlane(a.log_fill[lreg]) : 0u;
-			}
-			if (lreg < a.log_regions) {
-				const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-				if (hit) a.log[(uint64_t)lreg * a.log_region_cap + lfill + pos] = key;
-				lfill += c;
-			} else if (hit) {
-				atomicAdd(a.sketch0 + key, 1u);
-			}
-		};
-		// ---- resolve: 64 (read, window) pairs -> full canonical hash from the packed bases -> ntComp -> log ----
-		auto resolve_round = [&](uint32_t e, uint32_t count) {
-			const bool act = (uint32_t)lane < count;
-			const uint32_t r = act ? e >> 8 : 0u, win = act ? e & 0xffu : 0u;
-			const uint32_t B = r * stride + win;          // tile byte offset of the window's first base
-			const uint32_t sh = (B & 15u) * 2u;           // bit offset inside the packed dword
-			const uint32_t* dp = tile + (B >> 4);
-			const uint32_t rd = rdirty[r >> 5];
-			uint32_t d[KB + 1]; // KB + 1 aligned dwords cover the window's 2 K bits at any shift
-#pragma unroll
-			for (int i = 0; i < KB + 1; ++i)
-				d[i] = dp[i];
-			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
-#pragma unroll
-			for (int i = 0; i < KB; ++i) {
-				const uint32_t w = alignbit(d[i + 1], d[i], sh); // 16 bases of the window
-#pragma unroll
-				for (int g = 0; g < 4; ++g) {
-					const uint32_t idx = (w >> (8 * g)) & 0xffu;
-					const v4u32 t = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)(i * 4 + g) * 4096u + idx * 16u);
-					flo ^= t.x;
-					fhi ^= t.y;
-					rlo ^= t.z;
-					rhi ^= t.w;
-				}
-			}
-			const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
-			const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
-			// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
-			const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
-			const bool c0 = (hi >> (31 - s_bits)) == 1u;
-			const bool clean = ((rd >> (r & 31u)) & 1u) == 0u; // dirty reads are handed to the lane-per-read kernel as a whole
-			const bool hit = act & clean & (c0 | c1);
-			const uint32_t key = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
-			if (use_log)
-				log_emit(hit, key);
-			else if (hit)
-				atomicAdd(a.sketch0 + key, 1u);
-		};
-		// ---- LDS queue of sampled (read, window) pairs: [qhead, qhead + qfill) mod kQueueCap ----
-		uint32_t qhead = 0, qfill = 0;
-		auto drain_queue = [&](uint32_t keep) { // resolve until at most `keep` pairs are left (keep < 64: the last round is partial)
-			while (qfill > keep) {
-				const uint32_t n = qfill < 64u ? qfill : 64u;
-				const uint32_t e = queue[(qhead + (uint32_t)lane) & (kQueueCap - 1u)];
-				resolve_round(e, n);
-				qhead = (qhead + n) & (kQueueCap - 1u);
-				qfill -= n;
-			}
-		};
-		auto append = [&](uint32_t cur, uint32_t win) { // cur: bit i set <=> read 64 i + lane sampled at window `win`
-			for (uint32_t sl = 0; sl < 4u; ++sl) { // a byte slice adds at most 512 pairs: the queue always has room after a drain
-				uint32_t bits = cur & (0xffu << (8u * sl));
-				if (ballot(bits != 0u) == 0) continue;
-				const uint32_t cnt = (uint32_t)__popc(bits);
-				const uint32_t incl = wave_scan(cnt);
-				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-				if (qfill + total > kQueueCap) drain_queue(63u);
-				uint32_t pos = qhead + qfill + incl - cnt;
-				while (bits != 0u) {
-					const uint32_t bit = (uint32_t)__builtin_ctz(bits);
-					bits &= bits - 1u;
-					queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
-				}
-				qfill += total;
-			}
-		};
-		// Take over half-blocks of hit planes from the walker until `limit` have been taken in total; blocking or only
-		// what is ready.  Their sampled pairs are queued and resolved in full rounds.
-		uint32_t hb = 0; // half-blocks taken over so far (all tiles)
-		auto take_upto = [&](uint32_t limit, uint32_t tile_first_hb, bool blocking) {
-			while (hb < limit) {
-				if (ready[part] <= hb) {
-					if (!blocking) break;
-					__builtin_amdgcn_s_sleep(2);
-					continue;
-				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				const uint32_t hbt = hb - tile_first_hb; // index inside the tile
-				const uint32_t* buf = hitbuf + (hb % kHitBufs) * ((kHalf + 1) * 64u);
-#pragma unroll 1
-				for (uint32_t q = 0; q < (uint32_t)kHalf + 1u; ++q) {
-					// slot 8: the window the last window-filling step completed (first half-block of a tile only);
-					// slots 0..7: local window 8 hbt + q + 1 (window Q belongs to the next walker)
-					const uint32_t lw = q == (uint32_t)kHalf ? 0u : kHalf * hbt + q + 1u;
-					if ((q == (uint32_t)kHalf && hbt != 0u) || lw >= Q || sb + lw >= W) continue;
-					append(buf[q * 64u + (uint32_t)lane], sb + lw);
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				++hb;
-				if (lane == 0) consumed[part] = hb; // every plane has been read: the walker may reuse the buffer
-				drain_queue(63u);
-			}
-		};
-
 		uint32_t park[kGroups * kGroupLoads];
 		const uint32_t nl = __builtin_amdgcn_readfirstlane(stride >> 1); // 1 KiB loads per quarter (qd / 64)
 		uint64_t f1_acc = 0;
-		uint32_t par = 1, tile_hb0 = 0; // the tile staged during an iteration lands in bitmap par ^ 1
+		uint32_t par = 1; // the tile staged during an iteration lands in bitmap par ^ 1
 		// iteration -1 has no current tile: it only stages the workgroup's first one
 		for (int64_t ts = (int64_t)blockIdx.x - (int64_t)gridDim.x; ts < (int64_t)a.n_tiles; ts += gridDim.x, par ^= 1u) {
 			const bool has_cur = ts >= 0;
@@ -355,10 +228,9 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 			}
 			BS_T(ts2);
 			if (has_next) {
-				// staging of the next tile: 8 groups of 10 loads; while a group is in flight the helper looks after the hit
-				// planes its walker has finished meanwhile, then packs the group
+				// staging of the next tile: 8 groups of 10 loads, group g + 1 in flight while group g is packed
 				const unsigned char* src = a.slots + tn * ((uint64_t)kTileReads * stride) + (uint64_t)part * 16u * qd;
-				uint4 raw[kGroupLoads];
+				uint4 raw[2][kGroupLoads];
 				uint32_t vlane = (uint32_t)lane;
 				auto issue = [&](auto gc) {
 					constexpr int g = decltype(gc)::value;
@@ -367,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 						const uint32_t i = (uint32_t)(g * kGroupLoads + c) * 64u + vlane;
 						// strides >= 128 B: the first 64 loads always exist (one address register serves them all); a later
 						// load past the quarter re-reads its last chunk (no branch)
-						raw[c] = *reinterpret_cast<const uint4*>(src + 16u * (g * kGroupLoads + c < 64 || i < qd ? i : qd - 1u));
+						raw[g & 1][c] = *reinterpret_cast<const uint4*>(src + 16u * (g * kGroupLoads + c < 64 || i < qd ? i : qd - 1u));
 					}
 				};
 				auto pack = [&](auto gc) {
@@ -376,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 #pragma unroll
 					for (int c = 0; c < kGroupLoads; ++c) {
 						uint32_t dirty;
-						park[g * kGroupLoads + c] = pack16(raw[c], dirty);
+						park[g * kGroupLoads + c] = pack16(raw[g & 1][c], dirty);
 						dm = (dm << 1) | dirty;
 					}
 					while (dm != 0u) { // rare: note the chunk; the read(s) it belongs to are sorted out at the tile switch
@@ -386,34 +258,28 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 						const uint32_t gi = part * qd + i;
 						if (i < qd) atomicOr(&cbm_nxt[gi >> 5], 1u << (gi & 31u));
 					}
-					// one group in flight at a time (each costs 40 VGPRs): the next group's addresses "depend" on this group's packed words
+					// keep the pipeline two groups deep, not deeper (every group in flight costs 40 VGPRs): the addresses of
+					// group g + 2 "depend" on this group's packed words
 					uint32_t* q = park + g * kGroupLoads;
 					uint32_t vl = vlane;
 					asm volatile("" : "+v"(vl) : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]), "v"(q[8]), "v"(q[9]));
 					vlane = vl;
 				};
 				using std::integral_constant;
-				issue(integral_constant<int, 0>{}); pack(integral_constant<int, 0>{});
-				issue(integral_constant<int, 1>{}); if (has_cur) take_upto(tile_hb0 + hpt, tile_hb0, false); pack(integral_constant<int, 1>{});
-				issue(integral_constant<int, 2>{}); pack(integral_constant<int, 2>{});
-				issue(integral_constant<int, 3>{}); if (has_cur) take_upto(tile_hb0 + hpt, tile_hb0, false); pack(integral_constant<int, 3>{});
-				issue(integral_constant<int, 4>{}); pack(integral_constant<int, 4>{});
-				issue(integral_constant<int, 5>{}); if (has_cur) take_upto(tile_hb0 + hpt, tile_hb0, false); pack(integral_constant<int, 5>{});
-				issue(integral_constant<int, 6>{}); pack(integral_constant<int, 6>{});
-				issue(integral_constant<int, 7>{}); if (has_cur) take_upto(tile_hb0 + hpt, tile_hb0, false); pack(integral_constant<int, 7>{});
+				issue(integral_constant<int, 0>{});
+				issue(integral_constant<int, 1>{}); pack(integral_constant<int, 0>{});
+				issue(integral_constant<int, 2>{}); pack(integral_constant<int, 1>{});
+				issue(integral_constant<int, 3>{}); pack(integral_constant<int, 2>{});
+				issue(integral_constant<int, 4>{}); pack(integral_constant<int, 3>{});
+				issue(integral_constant<int, 5>{}); pack(integral_constant<int, 4>{});
+				issue(integral_constant<int, 6>{}); pack(integral_constant<int, 5>{});
+				issue(integral_constant<int, 7>{}); pack(integral_constant<int, 6>{});
+				pack(integral_constant<int, 7>{});
 			}
 			BS_T(ts3);
 			BS_ACC(2, ts2, ts3);
-			if (has_cur) {
-				take_upto(tile_hb0 + hpt, tile_hb0, true); // the rest of this tile's hit planes, as the walker delivers them
-				drain_queue(0u); // the image changes at the tile switch: nothing of this tile may stay queued
-				tile_hb0 += hpt;
-			}
-			BS_T(ts4);
-			BS_ACC(3, ts3, ts4);
 		}
 		if (part == 0 && lane == 0 && f1_acc) atomicAdd(a.f1, (unsigned long long)f1_acc);
-		if (use_log && lane == 0 && lreg < a.log_regions) a.log_fill[lreg] = lfill;
 #ifdef NTC_BS_TIMERS
 		if (lane == 0 && a.dbg)
 			for (int i = 0; i < 4; ++i)
@@ -423,20 +289,145 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 	}
 
 	// =========================== WALKER: windows [sb, sb + Q) of every read of every tile ===========================
+	const uint32_t Q = 16u * a.nq; // windows per walker segment
+	const uint32_t sb = part * Q;  // first window (= first base) of segment `part`
+	const uint32_t rmask = (1u << a.r_bits) - 1u, rbuck = 1u << a.r_bits, s_bits = a.s_bits;
+	// ---- hit log (see ntc_sketch_hf.hip): this wave's regions are gwave, gwave + log_w, ... ----
+	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + part);
+	const uint32_t log_w = gridDim.x * 4u;
+	const bool use_log = a.log_regions != 0;
+	uint32_t lreg = gwave, lfill = 0;
+	if (use_log && lreg < a.log_regions) lfill = __builtin_amdgcn_readfirstlane(a.log_fill[lreg]);
+	auto log_emit = [&](bool hit, uint32_t key) {
+		const uint64_t m = ballot(hit);
+		if (m == 0) return;
+		const uint32_t c = (uint32_t)__popcll(m);
+		while (lreg < a.log_regions && c > a.log_region_cap - lfill) {
+			if (lane == 0) a.log_fill[lreg] = lfill;
+			lreg += log_w;
+			lfill = lreg < a.log_regions ? __builtin_amdgcn_readfirstlane(a.log_fill[lreg]) : 0u;
+		}
+		if (lreg < a.log_regions) {
+			const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			if (hit) a.log[(uint64_t)lreg * a.log_region_cap + lfill + pos] = key;
+			lfill += c;
+		} else if (hit) {
+			atomicAdd(a.sketch0 + key, 1u);
+		}
+	};
+	// ---- resolve: 64 (read, window) pairs -> full canonical hash from the packed bases -> ntComp -> log ----
+	auto resolve_round = [&](uint32_t e, uint32_t count) {
+		const bool act = (uint32_t)lane < count;
+		const uint32_t r = act ? e >> 8 : 0u, win = act ? e & 0xffu : 0u;
+		const uint32_t B = r * stride + win;          // tile byte offset of the window's first base
+		const uint32_t sh = (B & 15u) * 2u;           // bit offset inside the packed dword
+		const uint32_t* dp = tile + (B >> 4);
+		const uint32_t rd = rdirty[r >> 5];
+		uint32_t d[KB + 1]; // KB + 1 aligned dwords cover the window's 2 K bits at any shift
+#pragma unroll
+		for (int i = 0; i < KB + 1; ++i)
+			d[i] = dp[i];
+		// every table address first, then all K / 4 lookups in flight together, then the XORs (see fetch_planes)
+		uint32_t toff[K / 4];
+#pragma unroll
+		for (int i = 0; i < KB; ++i) {
+			const uint32_t w = alignbit(d[i + 1], d[i], sh); // 16 bases of the window
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+				toff[i * 4 + g] = (uint32_t)(i * 4 + g) * 4096u + ((w >> (8 * g)) & 0xffu) * 16u;
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		v4u32 tv[K / 4];
+#pragma unroll
+		for (int j = 0; j < K / 4; ++j)
+			tv[j] = *reinterpret_cast<const v4u32*>(t4 + toff[j]);
+		__builtin_amdgcn_sched_barrier(0);
+		uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+#pragma unroll
+		for (int j = 0; j < K / 4; ++j) {
+			flo ^= tv[j].x;
+			fhi ^= tv[j].y;
+			rlo ^= tv[j].z;
+			rhi ^= tv[j].w;
+		}
+		const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
+		const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
+		// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+		const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+		const bool c0 = (hi >> (31 - s_bits)) == 1u;
+		const bool clean = ((rd >> (r & 31u)) & 1u) == 0u; // dirty reads are handed to the lane-per-read kernel as a whole
+		const bool hit = act & clean & (c0 | c1);
+		const uint32_t key = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
+		if (use_log)
+			log_emit(hit, key);
+		else if (hit)
+			atomicAdd(a.sketch0 + key, 1u);
+	};
+	// ---- LDS queue of sampled (read, window) pairs: [qhead, qhead + qfill) mod kQueueCap ----
+	uint32_t qhead = 0, qfill = 0;
+	auto drain_queue = [&](uint32_t keep) { // resolve until at most `keep` pairs are left (keep < 64: the last round is partial)
+		while (qfill > keep) {
+			const uint32_t n = qfill < 64u ? qfill : 64u;
+			const uint32_t e = queue[(qhead + (uint32_t)lane) & (kQueueCap - 1u)];
+			resolve_round(e, n);
+			qhead = (qhead + n) & (kQueueCap - 1u);
+			qfill -= n;
+		}
+	};
+	auto append = [&](uint32_t cur, uint32_t win) { // cur: bit i set <=> read 64 i + lane sampled at window `win`
+		if (ballot(cur != 0u) == 0) return;
+		const uint32_t cnt = (uint32_t)__popc(cur);
+		const uint32_t incl = wave_scan(cnt);
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		if (total <= kQueueCap - 64u) {
+			if (qfill + total > kQueueCap) drain_queue(63u);
+			uint32_t pos = qhead + qfill + incl - cnt;
+			while (cur != 0u) {
+				const uint32_t bit = (uint32_t)__builtin_ctz(cur);
+				cur &= cur - 1u;
+				queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
+			}
+			qfill += total;
+			return;
+		}
+		for (uint32_t sl = 0; sl < 4u; ++sl) { // more sampled reads than the queue holds: a byte slice adds at most 512 pairs
+			uint32_t bits = cur & (0xffu << (8u * sl));
+			const uint32_t c8 = (uint32_t)__popc(bits);
+			const uint32_t in8 = wave_scan(c8);
+			const uint32_t tot8 = (uint32_t)__builtin_amdgcn_readlane((int)in8, 63);
+			if (qfill + tot8 > kQueueCap) drain_queue(63u);
+			uint32_t pos = qhead + qfill + in8 - c8;
+			while (bits != 0u) {
+				const uint32_t bit = (uint32_t)__builtin_ctz(bits);
+				bits &= bits - 1u;
+				queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
+			}
+			qfill += tot8;
+		}
+	};
 	const uint32_t abase = (uint32_t)lane * s4; // packed BYTE offset of read `lane`; reads 64 i + lane follow every 16 * s4 dwords
 	auto fetch_planes = [&](uint32_t (&P)[32], uint32_t pos) { // planes of bases [pos, pos + 16) of the lane's 32 reads
 		const uint32_t byte0 = abase + (pos >> 2);
 		const uint32_t sh = (byte0 & 3u) * 8u + (pos & 3u) * 2u;
 		const uint32_t* p = tile + (byte0 >> 2);
+		// all loads of a half first, then their uses: left alone, the scheduler (minimising live ranges) waits for every
+		// single LDS load, and with one wave per SIMD nothing hides those round trips
 #pragma unroll
-		for (int i = 0; i < 32; ++i) {
-			const uint32_t d0 = p[(uint32_t)i * 16u * s4], d1 = p[(uint32_t)i * 16u * s4 + 1u];
-			P[i] = alignbit(d1, d0, sh);
-			if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0); // 8 pairs in flight at a time, not 32
+		for (int hf = 0; hf < 2; ++hf) {
+			uint32_t d0[16], d1[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				d0[i] = p[(uint32_t)(hf * 16 + i) * 16u * s4];
+				d1[i] = p[(uint32_t)(hf * 16 + i) * 16u * s4 + 1u];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				P[hf * 16 + i] = alignbit(d1[i], d0[i], sh);
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		transpose32(P); // P[2 q + b] = bit b of the code of base pos + q, one bit per read
 	};
-	uint32_t gb = 0; // half-blocks handed over so far (all tiles)
 	for (uint64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
 		BS_T(tw0);
 		__syncthreads(); // B1
@@ -448,20 +439,20 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 #pragma unroll
 		for (int j = 0; j < 31; ++j)
 			F[j] = R[j] = 0;
+		uint32_t H[KB][32]; // bit planes of the last KB chunks (H[0]: the bases that leave the window in the next block)
 		auto test = [&]() -> uint32_t {
 			if constexpr (SB == 7) return bs_test_s7(F, R);
 			else return bs_test_s8(F, R);
 		};
-#pragma unroll 1
-		for (uint32_t b = 0; b < (uint32_t)KB; ++b) { // window filling: no outgoing base; the last step completes window sb
-			uint32_t I[32];
+#pragma unroll
+		for (int b = 0; b < KB; ++b) { // window filling: no outgoing base; the last step completes window sb
 			BS_T(tf0);
-			fetch_planes(I, sb + 16u * b);
+			fetch_planes(H[b], sb + 16u * (uint32_t)b);
 			BS_T(tf1);
 			BS_ACC(4, tf0, tf1);
 #pragma unroll
 			for (int q = 0; q < 16; ++q) {
-				if constexpr (K == 32) bs_step_warm_k32(F, R, I[2 * q], I[2 * q + 1]);
+				if constexpr (K == 32) bs_step_warm_k32(F, R, H[b][2 * q], H[b][2 * q + 1]);
 			}
 #ifdef NTC_BS_TIMERS
 			pin31(F);
@@ -470,38 +461,79 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 			BS_T(tf2);
 			BS_ACC(5, tf1, tf2);
 		}
-		const uint32_t hp_first = test();
+		hitbuf[16 * 64 + lane] = test(); // window sb itself: drained with the first block
 		BS_T(tw2);
 		BS_ACC(1, tw1, tw2);
 #pragma unroll 1
-		for (uint32_t bq = 0; bq < a.nq; ++bq) { // steady state: 16 windows per block, handed over in two halves
+		for (uint32_t bq = 0; bq < a.nq; ++bq) { // steady state: 16 windows per block
 			BS_T(tw3);
-			// incoming bases [sb + K + 16 bq, +16) and the bases that leave the window, K positions earlier (fetched and
-			// transposed again: keeping KB chunks of planes alive costs 32 KB registers the walker does not have)
-			uint32_t I[32], O[32];
+			uint32_t I[32];
 			fetch_planes(I, sb + 16u * ((uint32_t)KB + bq));
-			fetch_planes(O, sb + 16u * bq);
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				while (consumed[part] + kHitBufs <= gb) // the buffer this half-block goes to still holds planes the helper has not read
-					__builtin_amdgcn_s_sleep(1);
-				uint32_t* buf = hitbuf + (gb % kHitBufs) * ((kHalf + 1) * 64u);
-#pragma unroll
-				for (int q = h * kHalf; q < (h + 1) * kHalf; ++q) {
-					if constexpr (K == 32) bs_step_main_k32(F, R, I[2 * q], I[2 * q + 1], O[2 * q], O[2 * q + 1]);
-					buf[(q - h * kHalf) * 64 + lane] = test();
-				}
-				buf[kHalf * 64 + lane] = hp_first; // only read for the tile's first half-block
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				++gb;
-				if (lane == 0) ready[part] = gb;
+			for (int q = 0; q < 16; ++q) {
+				if constexpr (K == 32) bs_step_main_k32(F, R, I[2 * q], I[2 * q + 1], H[0][2 * q], H[0][2 * q + 1]);
+				hitbuf[q * 64 + lane] = test();
 			}
+			// the chunk that just came in leaves the window KB blocks from now
+#pragma unroll
+			for (int hh = 0; hh + 1 < KB; ++hh)
+#pragma unroll
+				for (int i = 0; i < 32; ++i)
+					H[hh][i] = H[hh + 1][i];
+#pragma unroll
+			for (int i = 0; i < 32; ++i)
+				H[KB - 1][i] = I[i];
 			pin31(F);
 			pin31(R);
 			BS_T(tw4);
 			BS_ACC(2, tw3, tw4);
+			// drain the block's sampled windows: slot 16 = window sb (first block only), slot q = local window 16 bq + q + 1
+			// (window Q belongs to the next walker).  ONE prefix sum per block places every lane's pairs in the queue.
+			{
+				uint32_t hp[17];
+#pragma unroll
+				for (int q = 0; q < 17; ++q)
+					hp[q] = hitbuf[q * 64 + lane];
+				__builtin_amdgcn_sched_barrier(0);
+				uint32_t cnt = 0;
+#pragma unroll
+				for (int q = 0; q < 17; ++q) {
+					const uint32_t lw = q == 16 ? 0u : 16u * bq + (uint32_t)q + 1u;
+					const bool valid = (q != 16 || bq == 0u) && lw < Q && sb + lw < W; // wave-uniform
+					hp[q] = valid ? hp[q] : 0u;
+					cnt += (uint32_t)__popc(hp[q]);
+				}
+				const uint32_t incl = wave_scan(cnt);
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				if (total <= kQueueCap - 64u) {
+					if (qfill + total > kQueueCap) drain_queue(63u);
+					uint32_t pos = qhead + qfill + incl - cnt;
+#pragma unroll
+					for (int q = 0; q < 17; ++q) {
+						const uint32_t win = sb + (q == 16 ? 0u : 16u * bq + (uint32_t)q + 1u);
+						uint32_t bits = hp[q];
+						while (bits != 0u) {
+							const uint32_t bit = (uint32_t)__builtin_ctz(bits);
+							bits &= bits - 1u;
+							queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
+						}
+					}
+					qfill += total;
+				} else { // more sampled windows than the queue holds (repeats): plane by plane
+#pragma unroll 1
+					for (uint32_t q = 0; q < 17u; ++q) {
+						const uint32_t lw = q == 16u ? 0u : 16u * bq + q + 1u;
+						if ((q != 16u || bq == 0u) && lw < Q && sb + lw < W) append(hitbuf[q * 64u + (uint32_t)lane], sb + lw);
+					}
+				}
+			}
+			drain_queue(63u);
+			BS_T(tw5);
+			BS_ACC(3, tw4, tw5);
 		}
+		drain_queue(0u); // the image changes at the tile switch: nothing of this tile may stay queued
 	}
+	if (use_log && lane == 0 && lreg < a.log_regions) a.log_fill[lreg] = lfill;
 #ifdef NTC_BS_TIMERS
 	if (lane == 0 && a.dbg)
 		for (int i = 0; i < 6; ++i)
@@ -523,7 +555,7 @@ bool sketch_bs_supports(uint32_t k, uint32_t s_bits) { return k == 32 && s_bits 
 size_t sketch_bs_smem(uint32_t k, uint32_t stride)
 {
 	const size_t tile_dw = 128u * (size_t)stride;
-	return (tile_dw + 64) * 4 + (size_t)(k / 4) * 4096 + 2 * (tile_dw / 32) * 4 + 80 * 4 + 4 * 3 * 9 * 64 * 4 + 4 * 1024 * 4;
+	return (tile_dw + 64) * 4 + (size_t)(k / 4) * 4096 + 2 * (tile_dw / 32) * 4 + 64 * 4 + 4 * 17 * 64 * 4 + 4 * 1024 * 4;
 }
 
 hipError_t launch_sketch_bs(const BsArgs& a, unsigned grid, hipStream_t st)

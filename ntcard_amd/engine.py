@@ -14,7 +14,7 @@ from . import _abi
 from ._abi import NtcConfig, NtcError, check
 
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
-FLAG_LANE_KERNEL = 4  # NTC_FLAG_LANE_KERNEL: never use the bit-sliced kernel K1b
+FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: experimental bit-sliced kernel K1b for equal-length k = 32 batches
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 

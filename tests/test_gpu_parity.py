@@ -213,7 +213,7 @@ def test_bit_sliced_kernel_matches_oracle(nt, L, stride, s_bits, pn):
     buf, _ = to_slots(reads, stride=stride)
     buf[buf == 10] = ord("A")  # padding bytes are base letters (ntc_submit_device's contract for the fast path)
     d = torch.from_numpy(buf).cuda()
-    with nt.Engine([32], r_bits=20, s_bits=s_bits) as e:
+    with nt.Engine([32], r_bits=20, s_bits=s_bits, flags=nt.FLAG_BITSLICE_KERNEL) as e:
         e.submit_device(d.data_ptr(), n, L, stride)
         tc, ph, f1 = e.finish(counters=True)
     oc, of1 = orc.sketch_reads(reads, [32], 0, 20, s_bits)
@@ -227,7 +227,7 @@ def test_bit_sliced_kernel_agrees_with_lane_kernel_at_size(nt):
     d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
     nt.gen_reads_device(d.data_ptr(), 5, 0, n, L, stride, 1, genome_len=3_000_000)
     res = []
-    for flags in (0, nt.FLAG_LANE_KERNEL):
+    for flags in (nt.FLAG_BITSLICE_KERNEL, 0):
         with nt.Engine([32], r_bits=24, s_bits=7, flags=flags) as e:
             e.submit_device(d.data_ptr(), n, L, stride)
             _, ph, f1 = e.finish()
