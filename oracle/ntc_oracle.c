@@ -265,6 +265,115 @@ static void one_read(uint16_t *counters, const char *seq, size_t len, const uint
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Timed form of ntRead for plain k-mers (the cpu_baseline leg of bench.py): the same walk as one_read with
+ * what the reference precomputes precomputed here as well — per byte value the seed, the complement seed
+ * and their srol^k images for this k (nthash.hpp:66-183 are such tables; ours are derived with orc_srol,
+ * not copied) — and the +-1 split rotates written out as a plain 64-bit rotate plus the swap of the two
+ * bits that crossed the 33/31 boundary (nthash.hpp:186-217).  Checked against one_read by the tests.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t s[256], sk[256], c[256], ck[256]; /* seed, srol^k(seed), complement seed, srol^k(complement seed) */
+} orc_ktab;
+
+static void build_ktab(orc_ktab *t, unsigned k)
+{
+    for (unsigned b = 0; b < 256; ++b) {
+        t->s[b] = orc_seed((uint8_t)b);
+        t->c[b] = t->s[b] ? orc_seed_comp((uint8_t)b) : 0;
+        t->sk[b] = orc_srol(t->s[b], k);
+        t->ck[b] = orc_srol(t->c[b], k);
+    }
+}
+
+static inline uint64_t srol1_fast(uint64_t x)
+{
+    uint64_t y = (x << 1) | (x >> 63);          /* bit 63 -> 0 and bit 32 -> 33: both on the wrong side */
+    uint64_t d = ((y >> 33) ^ y) & 1u;
+    return y ^ (d | (d << 33));
+}
+
+static inline uint64_t sror1_fast(uint64_t x)
+{
+    uint64_t y = (x >> 1) | (x << 63);          /* bit 0 -> 63 and bit 33 -> 32 */
+    uint64_t d = ((y >> 32) ^ (y >> 63)) & 1u;
+    return y ^ ((d << 32) | (d << 63));
+}
+
+static void one_read_fast(uint16_t *plane, const orc_ktab *t, const char *seq, size_t len, unsigned k,
+                          uint32_t r_bits, uint32_t s_bits, uint64_t *f1_local)
+{
+    if (k == 0 || (size_t)k > len) return;
+    const uint64_t r_buck = 1ULL << r_bits, r_mask = r_buck - 1, s_mask = (1ULL << (s_bits - 1)) - 1;
+    const size_t last = len - k;
+    const uint8_t *u = (const uint8_t *)seq;
+    size_t pos = 0;
+    uint64_t fh = 0, rh = 0, n = 0;
+    int have = 0;
+    while (pos <= last) {
+        if (!have) { /* NTMC64 base, nthash.hpp:467-492 */
+            int bad = -1;
+            for (int i = (int)k - 1; i >= 0; --i)
+                if (t->s[u[pos + i]] == 0) {
+                    bad = i;
+                    break;
+                }
+            if (bad >= 0) {
+                pos += (size_t)bad + 1;
+                continue;
+            }
+            fh = rh = 0;
+            for (unsigned i = 0; i < k; ++i) {
+                fh = srol1_fast(fh) ^ t->s[u[pos + i]];
+                rh = srol1_fast(rh) ^ t->c[u[pos + k - 1 - i]];
+            }
+            have = 1;
+        }
+        const uint64_t h = rh < fh ? rh : fh;
+        if ((h >> (63 - s_bits)) == 1) { /* ntComp, ntcard.cpp:132-145; the two patterns exclude each other for sBits >= 2 */
+            __atomic_fetch_add(&plane[h & r_mask], (uint16_t)1, __ATOMIC_RELAXED);
+        } else if ((h >> (64 - s_bits)) == s_mask) {
+            __atomic_fetch_add(&plane[r_buck + (h & r_mask)], (uint16_t)1, __ATOMIC_RELAXED);
+        }
+        ++n;
+        ++pos;
+        if (pos > last) break;
+        const uint8_t in = u[pos + k - 1], out = u[pos - 1];
+        if (t->s[in] == 0) {
+            pos += k;
+            have = 0;
+        } else { /* NTF64 / NTR64, nthash.hpp:242-257 */
+            fh = srol1_fast(fh) ^ t->s[in] ^ t->sk[out];
+            rh = sror1_fast(rh ^ t->ck[in] ^ t->c[out]);
+        }
+    }
+    *f1_local += n;
+}
+
+/* one thread per shard of the batch (the reference: one thread per input file, ntcard.cpp:445-446) */
+void orc_sketch_update_sharded(uint16_t *counters, const char *bases, const uint64_t *offsets,
+                               uint64_t n_reads, const uint32_t *klist, uint32_t n_k,
+                               uint32_t r_bits, uint32_t s_bits, uint64_t *f1, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    orc_ktab *tabs = (orc_ktab *)malloc(sizeof(orc_ktab) * n_k);
+    for (uint32_t ki = 0; ki < n_k; ++ki) build_ktab(&tabs[ki], klist[ki]);
+    const uint64_t r_buck = 1ULL << r_bits;
+#pragma omp parallel for schedule(static, 1) num_threads(n_threads)
+    for (int sh = 0; sh < n_threads; ++sh) {
+        uint64_t local[64];
+        memset(local, 0, sizeof local);
+        const uint64_t lo = n_reads * (uint64_t)sh / (uint64_t)n_threads, hi = n_reads * (uint64_t)(sh + 1) / (uint64_t)n_threads;
+        for (uint64_t i = lo; i < hi; ++i)
+            for (uint32_t ki = 0; ki < n_k; ++ki) /* ntRead's loop over kList, ntcard.cpp:147-158 */
+                one_read_fast(counters + (size_t)ki * 2 * r_buck, &tabs[ki], bases + offsets[i], (size_t)(offsets[i + 1] - offsets[i]),
+                              klist[ki], r_bits, s_bits, &local[ki]);
+        for (uint32_t ki = 0; ki < n_k; ++ki)
+            __atomic_fetch_add(&f1[ki], local[ki], __ATOMIC_RELAXED);
+    }
+    free(tabs);
+}
+
 void orc_sketch_update(uint16_t *counters, const char *bases, const uint64_t *offsets,
                        uint64_t n_reads, const uint32_t *klist, uint32_t n_k, uint32_t gap,
                        uint32_t r_bits, uint32_t s_bits, uint64_t *f1, int n_threads)

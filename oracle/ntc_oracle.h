@@ -81,6 +81,12 @@ double orc_hll_estimate(const uint8_t *regs, uint32_t n_bits);
 
 /* ---- synthetic read generator (spec: DESIGN.md "Synthetic workloads"; no reference analogue) */
 /* dist 0 = uniform i.i.d. ACGT; dist 1 = reads from an implicit random genome, 1 % subs, 0.05 % N */
+/* ntRead for plain k-mers with per-k precomputed seed tables, one thread per shard of the batch (the reference's
+ * threading shape, ntcard.cpp:445-446): the timed cpu_baseline form; same results as orc_sketch_update(gap = 0). */
+void orc_sketch_update_sharded(uint16_t *counters, const char *bases, const uint64_t *offsets,
+                               uint64_t n_reads, const uint32_t *klist, uint32_t n_k,
+                               uint32_t r_bits, uint32_t s_bits, uint64_t *f1, int n_threads);
+
 void orc_gen_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                    uint32_t stride, uint32_t dist, uint64_t genome_len, uint8_t *out);
 

@@ -54,6 +54,8 @@ def lib():
     L.orc_sample_of.argtypes = [u64, C.c_uint]
     L.orc_sketch_update.restype = None
     L.orc_sketch_update.argtypes = [p, p, p, u64, p, u32, u32, u32, u32, p, C.c_int]
+    L.orc_sketch_update_sharded.restype = None
+    L.orc_sketch_update_sharded.argtypes = [p, p, p, u64, p, u32, u32, u32, p, C.c_int]
     L.orc_value_hist.restype = None
     L.orc_value_hist.argtypes = [p, u32, p]
     L.orc_comp_est_p.restype = None
@@ -125,6 +127,18 @@ def sketch_update(counters, bases, offsets, klist, gap, r_bits, s_bits, f1=None,
     assert counters.dtype == np.uint16 and counters.flags.c_contiguous
     L.orc_sketch_update(_ptr(counters), _ptr(bases), _ptr(offsets), len(offsets) - 1, _ptr(kl),
                         len(kl), gap, r_bits, s_bits, _ptr(f1), threads)
+    return f1
+
+
+def sketch_update_sharded(counters, bases, offsets, klist, r_bits, s_bits, f1=None, threads=1):
+    """plain k-mers, per-k precomputed tables, one thread per shard (the timed cpu_baseline form); same results"""
+    L = lib()
+    kl = np.asarray(klist, dtype=np.uint32)
+    if f1 is None:
+        f1 = np.zeros(len(kl), dtype=np.uint64)
+    assert counters.dtype == np.uint16 and counters.flags.c_contiguous
+    L.orc_sketch_update_sharded(_ptr(counters), _ptr(bases), _ptr(offsets), len(offsets) - 1, _ptr(kl),
+                                len(kl), r_bits, s_bits, _ptr(f1), threads)
     return f1
 
 
