@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--dist", choices=["g", "u"], default="g",
                     help="g: reads from a 100 Mbp random genome, 1%% subs, 0.05%% N; u: i.i.d. uniform ACGT")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config: 2 (default) 100 M reads k=32 sBits=7; 3: 1 B reads in total, sBits=11, read-index ranges split "
+                         "over the ranks (strong scaling); 4: k=32,64,96,128 in one run; 5: spaced seed k=12 g=2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
     ap.add_argument("--bitslice", action="store_true", help="use the experimental bit-sliced kernel K1b (k = 32, equal-length reads)")
@@ -117,6 +120,16 @@ def pmc_traffic(args, reads_per_launch):
 
 def main():
     args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    strong_total = None
+    if args.config == 3:  # 1 B reads in total over the ranks, sBits = 11 (the >= 50 GB branch of ntcard.cpp:427-431)
+        args.s_bits = 11
+        strong_total = 1_000_000_000
+        args.steps = max(1, strong_total // (world_env * args.reads_per_step))
+    elif args.config == 4:
+        args.klist = "32,64,96,128"
+    elif args.config == 5:
+        args.k, args.gap = 12, 2
     import torch
     import torch.distributed as dist
     import ntcard_amd as nt
@@ -151,6 +164,8 @@ def main():
     # ---- resident inputs: K step batches (+1 warmup batch), generated on the device (K0) ----
     reads_per_rank = R * K
     first, _ = parallel.read_range(rank, world, reads_per_rank)
+    if strong_total is not None:  # config 3: contiguous read-index ranges of ONE 1 B-read stream (parallel.split_reads)
+        first, reads_per_rank = parallel.split_reads(K * R * world, world)[rank]
     # at most `nb` distinct batches stay resident (all K when they fit in half of the free HBM); a larger K cycles over them
     free_b, _ = torch.cuda.mem_get_info(dev)
     nb = max(1, min(K, int(free_b * 0.5) // (R * stride + 16)))
@@ -232,7 +247,7 @@ def main():
             "warmup": W,
             "ms_per_step": dt_max * 1e3 / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong_total is not None else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",

@@ -123,6 +123,14 @@ int ntc_value_hist_device(int32_t device, void *stream, const void *d_counters_u
  * mod 2^16 (ntcard.cpp:142-143), so runs split across processes, nodes or days merge exactly.               */
 int ntc_merge_counters(ntc_engine *e, const uint16_t *t_counter, const uint64_t *f1);
 
+/* Multi-GPU merge inside ONE host process: engines[0..n) are engines with the same configuration,
+ * normally one per GPU of the node, each fed with its own share of the reads.  After the call engine 0 holds the
+ * element-wise SUM of all sketches and F1 values (MAX of the registers for nthll engines) — the state the
+ * reference's threads build in their one shared t_Counter / totalKmers (ntcard.cpp:142-143,464-466; nthll.cpp:
+ * 238-243) — and the other engines are reset to zero.  Devices are connected with RCCL (ncclCommInitAll + one grouped
+ * ncclReduce over xGMI; librccl is loaded on first use); engines that share a device are folded with a kernel.   */
+int ntc_merge_devices(ntc_engine *const *engines, int32_t n_engines);
+
 /* Device pointers of the live sketch / F1 (for a host framework's collective); flushes the hit log first */
 int ntc_device_state(ntc_engine *e, void **d_sketch_u32, uint64_t *n_counters, void **d_f1_u64);
 

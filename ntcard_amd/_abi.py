@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
     "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
-    "ntc_kernel_time", "ntc_apply_time", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
+    "ntc_kernel_time", "ntc_apply_time", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
 ]
 
 
@@ -71,6 +71,7 @@ def lib():
     L.ntc_sync.argtypes = [p]
     L.ntc_finish.argtypes = [p, p, p, p]
     L.ntc_merge_counters.argtypes = [p, p, p]
+    L.ntc_merge_devices.argtypes = [C.POINTER(p), i32]
     L.ntc_value_hist_device.argtypes = [i32, p, p, u64, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]

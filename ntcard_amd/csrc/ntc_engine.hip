@@ -5,6 +5,8 @@
 // (ntcard.cpp:147-171), ntc_finish = the state compEst reads (ntcard.cpp:237-247) + F1
 // (ntcard.cpp:464-466).  No CPU fallback exists: every entry point needs a live HIP device.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: the library is loaded on demand (ntc_merge_devices)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1054,6 +1056,124 @@ int ntc_flush(ntc_engine* e)
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
 	return apply_log(e);
+}
+
+// ---- multi-GPU merge in ONE host process -------------------------------------------------------
+// The reference's threads all increment one shared t_Counter (ntcard.cpp:142-143,445) and add their k-mer counts into
+// one totalKmers (ntcard.cpp:464-466); with one private sketch per GPU the same state is the element-wise SUM of the
+// sketches (MAX for nthll's registers, nthll.cpp:238-243).  RCCL does it over xGMI: one communicator per device
+// (ncclCommInitAll), one grouped ncclReduce to the root.  librccl is loaded the first time this is needed, so that
+// single-GPU users do not pay for it at start-up.
+namespace {
+struct Rccl {
+	void* lib = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+int load_rccl(Rccl& r)
+{
+	static std::mutex mu;
+	static Rccl cached;
+	std::lock_guard<std::mutex> lk(mu);
+	if (!cached.lib) {
+		void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) return fail(NTC_ERR_DEVICE, "ntc_merge_devices: cannot load librccl (%s)", dlerror());
+		Rccl t;
+		t.lib = h;
+		t.CommInitAll = (decltype(t.CommInitAll))dlsym(h, "ncclCommInitAll");
+		t.CommDestroy = (decltype(t.CommDestroy))dlsym(h, "ncclCommDestroy");
+		t.GroupStart = (decltype(t.GroupStart))dlsym(h, "ncclGroupStart");
+		t.GroupEnd = (decltype(t.GroupEnd))dlsym(h, "ncclGroupEnd");
+		t.Reduce = (decltype(t.Reduce))dlsym(h, "ncclReduce");
+		t.GetErrorString = (decltype(t.GetErrorString))dlsym(h, "ncclGetErrorString");
+		if (!t.CommInitAll || !t.CommDestroy || !t.GroupStart || !t.GroupEnd || !t.Reduce || !t.GetErrorString)
+			return fail(NTC_ERR_DEVICE, "ntc_merge_devices: librccl lacks a required entry point");
+		cached = t;
+	}
+	r = cached;
+	return 0;
+}
+} // namespace
+
+int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
+{
+	if (!engines || n_engines < 1) return fail(NTC_ERR_ARG, "ntc_merge_devices: need at least one engine");
+	ntc_engine* root = engines[0];
+	if (!root) return fail(NTC_ERR_ARG, "ntc_merge_devices: null engine");
+	const uint64_t counters = root->hll_bits ? (1ull << root->hll_bits) : root->klist.size() * root->plane_elems();
+	for (int32_t i = 0; i < n_engines; ++i) {
+		ntc_engine* e = engines[i];
+		if (!e || e->klist != root->klist || e->gap != root->gap || e->r_bits != root->r_bits || e->s_bits != root->s_bits || e->hll_bits != root->hll_bits)
+			return fail(NTC_ERR_ARG, "ntc_merge_devices: engine %d is not configured like engine 0", i);
+		for (int32_t j = 0; j < i; ++j)
+			if (engines[j] == e) return fail(NTC_ERR_ARG, "ntc_merge_devices: engine %d listed twice", i);
+	}
+	// 1. pending increments first, everything quiescent
+	for (int32_t i = 0; i < n_engines; ++i) {
+		std::lock_guard<std::mutex> lk(engines[i]->mu);
+		HIP_TRY(hipSetDevice(engines[i]->device));
+		if (int rc = apply_log(engines[i])) return rc;
+		HIP_TRY(hipStreamSynchronize(engines[i]->stream));
+	}
+	// 2. engines that share a device are folded locally (RCCL wants one rank per device); `lead` = first engine per device
+	std::vector<ntc_engine*> lead;
+	for (int32_t i = 0; i < n_engines; ++i) {
+		ntc_engine* e = engines[i];
+		ntc_engine* l = nullptr;
+		for (ntc_engine* c : lead)
+			if (c->device == e->device) l = c;
+		if (!l) {
+			lead.push_back(e);
+			continue;
+		}
+		HIP_TRY(hipSetDevice(e->device));
+		HIP_TRY(ntc::launch_fold_u32(l->d_sketch, e->d_sketch, counters, root->hll_bits != 0, l->stream));
+		HIP_TRY(ntc::launch_fold_u64((unsigned long long*)l->d_f1, (unsigned long long*)e->d_f1, e->klist.size(), l->stream));
+		HIP_TRY(hipStreamSynchronize(l->stream));
+	}
+	// 3. one rank per device: grouped reduce to the root's device
+	if (lead.size() > 1) {
+		Rccl nc;
+		if (int rc = load_rccl(nc)) return rc;
+		std::vector<int> devs;
+		for (ntc_engine* e : lead)
+			devs.push_back(e->device);
+		std::vector<ncclComm_t> comms(lead.size());
+		ncclResult_t r = nc.CommInitAll(comms.data(), (int)lead.size(), devs.data());
+		if (r != ncclSuccess) return fail(NTC_ERR_DEVICE, "ncclCommInitAll failed: %s", nc.GetErrorString(r));
+		auto run = [&]() -> ncclResult_t {
+			ncclResult_t rr = nc.GroupStart();
+			if (rr != ncclSuccess) return rr;
+			for (size_t i = 0; i < lead.size(); ++i) {
+				ntc_engine* e = lead[i];
+				(void)hipSetDevice(e->device);
+				rr = nc.Reduce(e->d_sketch, e->d_sketch, counters, ncclUint32, root->hll_bits ? ncclMax : ncclSum, 0, comms[i], e->stream);
+				if (rr != ncclSuccess) return rr;
+				rr = nc.Reduce(e->d_f1, e->d_f1, e->klist.size(), ncclUint64, ncclSum, 0, comms[i], e->stream);
+				if (rr != ncclSuccess) return rr;
+			}
+			return nc.GroupEnd();
+		};
+		r = run();
+		for (size_t i = 0; i < lead.size(); ++i) {
+			(void)hipSetDevice(lead[i]->device);
+			(void)hipStreamSynchronize(lead[i]->stream);
+		}
+		for (ncclComm_t c : comms)
+			(void)nc.CommDestroy(c);
+		if (r != ncclSuccess) return fail(NTC_ERR_DEVICE, "RCCL reduce failed: %s", nc.GetErrorString(r));
+	}
+	// 4. everything now lives in engine 0: the others start from zero again (the sum stays what it was)
+	for (int32_t i = 1; i < n_engines; ++i)
+		if (int rc = ntc_reset(engines[i])) return rc;
+	HIP_TRY(hipSetDevice(root->device));
+	return 0;
 }
 
 int ntc_device_state(ntc_engine* e, void** d_sketch_u32, uint64_t* n_counters, void** d_f1_u64)

@@ -420,6 +420,29 @@ __global__ __launch_bounds__(256) void add_counters_kernel(uint32_t* __restrict_
 	}
 }
 
+__global__ __launch_bounds__(256) void fold_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n, int take_max)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t a = dst[i], b = src[i];
+		dst[i] = take_max ? (a > b ? a : b) : a + b;
+	}
+}
+__global__ void fold_u64_kernel(unsigned long long* dst, const unsigned long long* src, uint64_t n)
+{
+	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x)
+		dst[i] += src[i];
+}
+hipError_t launch_fold_u32(uint32_t* dst, const uint32_t* src, uint64_t n, bool take_max, hipStream_t st)
+{
+	hipLaunchKernelGGL(fold_u32_kernel, dim3(4096), dim3(256), 0, st, dst, src, n, take_max ? 1 : 0);
+	return hipGetLastError();
+}
+hipError_t launch_fold_u64(unsigned long long* dst, const unsigned long long* src, uint64_t n, hipStream_t st)
+{
+	hipLaunchKernelGGL(fold_u64_kernel, dim3(1), dim3(64), 0, st, dst, src, n);
+	return hipGetLastError();
+}
+
 hipError_t launch_add_counters(uint32_t* sketch, const uint16_t* add16, uint64_t n, hipStream_t st)
 {
 	hipLaunchKernelGGL(add_counters_kernel, dim3(4096), dim3(256), 0, st, sketch, add16, n);

@@ -224,13 +224,10 @@ int main(int argc, char** argv)
 	const size_t nk = opt.klist.size();
 	std::vector<uint32_t> p(nk * 2 * 65536);
 	std::vector<uint64_t> f1(nk);
-	if (engines.size() > 1) { // fold the other devices' sketches into the first (ntc_merge_counters: exact, mod 2^16)
-		std::vector<uint16_t> image(nk * 2 * ((size_t)1 << opt.r_bits));
-		for (size_t d = 1; d < engines.size(); ++d) {
-			if (ntc_finish(engines[d], image.data(), nullptr, f1.data()) != 0) die_engine();
-			if (ntc_merge_counters(eng, image.data(), f1.data()) != 0) die_engine();
+	if (engines.size() > 1) { // one sketch per GPU -> their sum on the first one (RCCL reduce over xGMI inside the library)
+		if (ntc_merge_devices(engines.data(), (int32_t)engines.size()) != 0) die_engine();
+		for (size_t d = 1; d < engines.size(); ++d)
 			ntc_destroy(engines[d]);
-		}
 	}
 	if (ntc_finish(eng, nullptr, p.data(), f1.data()) != 0) die_engine();
 	std::vector<double> f(opt.cov_max + 1);

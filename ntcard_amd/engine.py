@@ -153,6 +153,12 @@ def hll_estimate(regs, n_bits=16):
     return est.value
 
 
+def merge_devices(engines):
+    """RCCL (xGMI) sum of the engines' sketches and F1 into engines[0]; the others are reset (ntc_merge_devices)"""
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    check(_abi.lib().ntc_merge_devices(arr, len(engines)))
+
+
 # -- stateless entry points ---------------------------------------------------------------------
 def estimate(p_hist_k, r_bits, s_bits, cov_max=1000):
     """compEst for one k from p[2][65536] -> (F0, f[0..cov_max])"""

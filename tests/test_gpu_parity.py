@@ -420,6 +420,53 @@ def test_full_size_properties(nt):
     assert h1 + h2 == hits
 
 
+def test_native_merge_devices_matches_single_engine(nt):
+    """ntc_merge_devices (C ABI, one host process): reads sharded over min(2, device_count) devices x 2 engines each,
+    merged by a kernel fold (same device) + one grouped RCCL reduce (distinct devices) == one engine over all reads:
+    identical t_Counter, value histogram, F1 and therefore .hist (config 3 at test size, sBits = 11)"""
+    ndev = min(2, torch.cuda.device_count())
+    n, L, stride = 48_000, 150, 152
+    per = n // (2 * ndev)
+    want = None
+    bufs = []
+    for dev in range(ndev):
+        with torch.cuda.device(dev):
+            d = torch.empty(n * stride + 16, dtype=torch.uint8, device=f"cuda:{dev}")
+            nt.gen_reads_device(d.data_ptr(), 21, 0, n, L, stride, 1, genome_len=500_000, device=dev)
+            bufs.append(d)
+    with nt.Engine([32, 45], r_bits=22, s_bits=11, device=0) as e:
+        e.submit_device(bufs[0].data_ptr(), n, L, stride)
+        want = e.finish(counters=True)
+    engines = [nt.Engine([32, 45], r_bits=22, s_bits=11, device=dev) for dev in range(ndev) for _ in range(2)]
+    try:
+        for j, e in enumerate(engines):
+            dev = j // 2
+            e.submit_device(bufs[dev].data_ptr() + j * per * stride, per if j < len(engines) - 1 else n - j * per, L, stride)
+        nt.merge_devices(engines)
+        got = engines[0].finish(counters=True)
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        for e in engines[1:]:
+            _, ph, f1 = e.finish()
+            assert int(f1.sum()) == 0 and int(ph[:, :, 1:].sum()) == 0  # the merged-in engines start from zero again
+    finally:
+        for e in engines:
+            e.close()
+    # nthll registers merge with max
+    hs = [nt.HllEngine(32, 16, device=0) for _ in range(2)]
+    try:
+        hs[0].submit_device(bufs[0].data_ptr(), n // 2, L, stride)
+        hs[1].submit_device(bufs[0].data_ptr() + (n // 2) * stride, n - n // 2, L, stride)
+        nt.merge_devices(hs)
+        regs, f1 = hs[0].finish()
+    finally:
+        for h in hs:
+            h.close()
+    with nt.HllEngine(32, 16, device=0) as h:
+        h.submit_device(bufs[0].data_ptr(), n, L, stride)
+        regs1, f11 = h.finish()
+    assert f1 == f11 and np.array_equal(regs, regs1)
+
+
 def test_value_hist_device_matches_numpy(nt):
     rng = np.random.default_rng(3)
     c = rng.integers(0, 70000, size=1 << 20, dtype=np.uint32)
