@@ -142,6 +142,12 @@ int ntc_device_state(ntc_engine *e, void **d_sketch_u32, uint64_t *n_counters, v
 int ntc_hash_dump_device(int32_t device, void *stream, const void *d_slots, uint64_t n_reads,
                          uint32_t read_len, uint32_t stride, uint32_t k, uint32_t gap,
                          uint32_t max_win, void *d_hash_out, void *d_count_out);
+/* The same dump produced by a validation build of the PRODUCTION kernel K1 (its filter lets every window through, so
+ * every 64-bit value comes out of K1's closed-form resolve stage; spaced seeds included: ntcard.cpp:160-171,
+ * stHashIterator.hpp:60-87, nthash.hpp:641-646).  ntc_hash_dump_device forwards here when gap != 0.  Synchronous. */
+int ntc_hash_dump_k1_device(int32_t device, void *stream, const void *d_slots, uint64_t n_reads,
+                            uint32_t read_len, uint32_t stride, uint32_t k, uint32_t gap,
+                            uint32_t max_win, void *d_hash_out, void *d_count_out);
 
 /* Synthetic workload generator (K0), bit-identical to oracle/orc_gen_reads; DESIGN.md
  * "Synthetic workloads".  Fills d_slots[n_reads*stride].                                         */

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libntcard_hip.so")
 ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
     "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
-    "ntc_hash_dump_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
+    "ntc_hash_dump_device", "ntc_hash_dump_k1_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
     "ntc_kernel_time", "ntc_apply_time", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
 ]
 
@@ -75,6 +75,7 @@ def lib():
     L.ntc_value_hist_device.argtypes = [i32, p, p, u64, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
+    L.ntc_hash_dump_k1_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_gen_reads_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u32, u64]
     L.ntc_estimate.argtypes = [p, u32, u32, u32, C.POINTER(C.c_double), p]
     L.ntc_write_hist.argtypes = [C.c_char_p, u64, C.c_double, p, u32]

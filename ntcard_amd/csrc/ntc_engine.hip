@@ -1137,8 +1137,9 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 		HIP_TRY(ntc::launch_fold_u64((unsigned long long*)l->d_f1, (unsigned long long*)e->d_f1, e->klist.size(), l->stream));
 		HIP_TRY(hipStreamSynchronize(l->stream));
 	}
-	// 3. one rank per device: grouped reduce to the root's device
-	if (lead.size() > 1) {
+	// 3. one rank per device: grouped reduce to the root's device (with a single device the one-rank reduce is a no-op
+	//    that still walks the whole RCCL path: communicator, group, reduce)
+	if (n_engines > 1) {
 		Rccl nc;
 		if (int rc = load_rccl(nc)) return rc;
 		std::vector<int> devs;
@@ -1196,7 +1197,8 @@ int ntc_hash_dump_device(int32_t device, void* stream, const void* d_slots, uint
 {
 	if (!d_slots || !d_hash_out || !d_count_out) return fail(NTC_ERR_ARG, "ntc_hash_dump_device: null buffer");
 	if (k < 1 || k > kMaxK) return fail(NTC_ERR_ARG, "ntc_hash_dump_device: k=%u outside 1..%u", k, kMaxK);
-	if (gap != 0) return fail(NTC_ERR_ARG, "ntc_hash_dump_device: gap seeds are not implemented in this build");
+	if (gap != 0) // the simple kernel has no spaced-seed form: the production kernel's validation build does it
+		return ntc_hash_dump_k1_device(device, stream, d_slots, n_reads, read_len, stride, k, gap, max_win, d_hash_out, d_count_out);
 	if ((stride & 3u) || stride < read_len || ((uintptr_t)d_slots & 15u))
 		return fail(NTC_ERR_ARG, "ntc_hash_dump_device: need 16-byte aligned slots, stride %% 4 == 0, stride >= read_len");
 	if (n_reads == 0) return 0;
@@ -1220,6 +1222,73 @@ int ntc_hash_dump_device(int32_t device, void* stream, const void* d_slots, uint
 	ntc::build_tables(k, a.tab);
 	HIP_TRY(ntc::launch_hash(1, a, grid, smem, (hipStream_t)stream));
 	return 0;
+}
+
+int ntc_hash_dump_k1_device(int32_t device, void* stream, const void* d_slots, uint64_t n_reads, uint32_t read_len,
+                            uint32_t stride, uint32_t k, uint32_t gap, uint32_t max_win, void* d_hash_out, void* d_count_out)
+{
+	if (!d_slots || !d_hash_out || !d_count_out) return fail(NTC_ERR_ARG, "ntc_hash_dump_k1_device: null buffer");
+	if (k < 1 || k > kMaxK) return fail(NTC_ERR_ARG, "ntc_hash_dump_k1_device: k=%u outside 1..%u", k, kMaxK);
+	if (gap != 0 && (gap % 2 != k % 2 || gap >= k)) return fail(NTC_ERR_ARG, "ntc_hash_dump_k1_device: gap size and kmer must have the same modulus");
+	if ((stride & 3u) || stride < read_len || ((uintptr_t)d_slots & 15u))
+		return fail(NTC_ERR_ARG, "ntc_hash_dump_k1_device: need 16-byte aligned slots, stride %% 4 == 0, stride >= read_len");
+	if (n_reads == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	if (int rc = ensure_kernel_attrs(device)) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	const uint32_t n_win = read_len >= k ? read_len - k + 1 : 1;
+	const uint32_t gap_first = (k - gap) / 2;
+	std::vector<uint32_t> t1((size_t)ntc::t2_pairs(k) * 64), gt((size_t)((gap + 1) / 2) * 64);
+	ntc::build_t2(k, t1.data(), gap_first, gap);
+	if (gap) ntc::build_gap_table(k, gap_first, gap, gt.data());
+	void *d_t1 = nullptr, *d_gt = nullptr;
+	uint64_t* d_full = nullptr;
+	uint32_t* d_valid = nullptr;
+	unsigned long long* d_f1 = nullptr;
+	const size_t vbytes = (size_t)n_reads * ((n_win + 31) / 32) * 4;
+	auto cleanup = [&]() {
+		for (void* p : {d_t1, d_gt, (void*)d_full, (void*)d_valid, (void*)d_f1})
+			if (p) (void)hipFree(p);
+	};
+	if (hipMalloc(&d_t1, t1.size() * 4) != hipSuccess || (gap && hipMalloc(&d_gt, gt.size() * 4) != hipSuccess) ||
+	    hipMalloc((void**)&d_full, (size_t)n_reads * n_win * 8) != hipSuccess || hipMalloc((void**)&d_valid, vbytes) != hipSuccess ||
+	    hipMalloc((void**)&d_f1, 8) != hipSuccess) {
+		cleanup();
+		return fail(NTC_ERR_MEMORY, "ntc_hash_dump_k1_device: device allocation failed");
+	}
+	int rc = 0;
+	auto run = [&]() -> int {
+		HIP_TRY(hipMemcpyAsync(d_t1, t1.data(), t1.size() * 4, hipMemcpyHostToDevice, st));
+		if (gap) HIP_TRY(hipMemcpyAsync(d_gt, gt.data(), gt.size() * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemsetAsync(d_valid, 0, vbytes, st));
+		HIP_TRY(hipMemsetAsync(d_f1, 0, 8, st));
+		ntc::HfArgs a;
+		std::memset(&a, 0, sizeof a);
+		a.slots = (const unsigned char*)d_slots;
+		a.n_slots = n_reads;
+		a.stride = stride;
+		a.read_len = read_len;
+		a.r_bits = 27;
+		a.s_bits = 7;
+		a.n_k = 1;
+		a.gap = gap;
+		a.gap_first = gap_first;
+		a.gapt = d_gt;
+		if (gap) ntc::build_gap_roll_table(k, gap_first, gap, a.tabg);
+		fill_hfk(a.ks[0], k, nullptr, d_f1, d_t1);
+		a.dump = d_full;
+		a.dump_valid = d_valid;
+		a.dump_win = n_win;
+		HfPlan hp;
+		if (int r = hf_plan(device, n_reads, stride, &k, 1, gap, hp)) return r;
+		HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, st));
+		HIP_TRY(ntc::launch_compact_dump(d_full, d_valid, n_reads, n_win, max_win, (uint64_t*)d_hash_out, (uint32_t*)d_count_out, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		return 0;
+	};
+	rc = run();
+	cleanup();
+	return rc;
 }
 
 int ntc_gen_reads_device(int32_t device, void* stream, void* d_slots, uint64_t seed, uint64_t first_read,

@@ -60,6 +60,9 @@ struct HfArgs {
 	uint32_t* log;              // [log_regions][log_region_cap] counter indices of sampled k-mers, relative to sketch0
 	uint32_t* log_fill;         // [log_regions] entries used per region (persists across launches until the log is applied)
 	uint32_t* sketch0;          // the engine's whole sketch array (overflow fallback of the log)
+	uint64_t* dump;             // validation build of K1 (kDump): [n_slots][dump_win] canonical hash of the window starting at each position
+	uint32_t* dump_valid;       //   [n_slots][ceil(dump_win / 32)] bit set where a hash was written (window without a non-ACGTU byte)
+	uint32_t dump_win, pad3_;
 	const uint32_t* gather;     // != NULL: the batch is the listed slots, gather[i] = slot index, i < *gather_count
 	const uint32_t* gather_count; // (reads the bit-sliced kernel K1b handed back: a non-ACGTU byte somewhere in the read)
 	const void* gapt;
@@ -124,6 +127,7 @@ hipError_t set_apply_smem_limit();
 hipError_t launch_hash(int mode, const HashArgs& a, unsigned grid, size_t smem, hipStream_t st);
 hipError_t set_hash_smem_limit(size_t smem);
 hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st);
+hipError_t launch_compact_dump(const uint64_t* full, const uint32_t* valid, uint64_t n_reads, uint32_t n_win, uint32_t max_win, uint64_t* out, uint32_t* count, hipStream_t st);
 hipError_t set_sketch_hf_smem_limit(size_t smem);
 bool sketch_hf_deep_prefetch(uint32_t stride);
 hipError_t launch_hll_threshold(const uint32_t* regs, uint32_t n_regs, uint32_t* thr, hipStream_t st);

@@ -118,7 +118,10 @@ __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_bal
 // free of the other modes' state (the spaced-seed walks cost the plain kernel 5 spilled VGPRs otherwise)
 // kPref: 1 KiB chunks of the NEXT batch a wave keeps in flight in registers (10 covers slots of up to 160 B at 16 waves
 // per CU; 16 covers 256 B slots, whose LDS footprint allows 12 waves at most, hence the smaller launch bound)
-template <bool kMulti, int kMode, int kPref>
+// kDump: validation build (ntc_hash_dump_k1_device): the filter lets EVERY window through, so the resolve stage
+// re-derives the full canonical hash of every window with the production code path, and writes it out instead of
+// sampling it (what ntHashIterator / stHashIterator enumerate, ntHashIterator.hpp:59-86, stHashIterator.hpp:60-87)
+template <bool kMulti, int kMode, int kPref, bool kDump = false>
 __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(const HfArgs a)
 {
 	const uint32_t n_k = kMulti ? a.n_k : 1u;
@@ -406,7 +409,14 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
 				const uint32_t hi = rev ? rhi : fhi;
 				const uint32_t lo = rev ? rlo : flo;
-				if constexpr (kMode == 2) {
+				if constexpr (kDump) {
+					const uint32_t win = q + 1u - k; // window start
+					const uint64_t row = slot0 + src_lane;
+					if (win < a.dump_win) {
+						a.dump[row * a.dump_win + win] = ((uint64_t)hi << 32) | lo;
+						atomicOr(a.dump_valid + row * ((a.dump_win + 31u) >> 5) + (win >> 5), 1u << (win & 31u));
+					}
+				} else if constexpr (kMode == 2) {
 					// nthll's ntComp (nthll.cpp:92-97): bucket = low bits, value = leading zeros of the rest
 					const uint32_t bmask = (1u << a.hll_bits) - 1u;
 					const uint32_t lo_rest = lo & ~bmask;
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 					key = key_base + (lo & rmask) + (c1 ? rbuck : 0u);
 				}
 			}
-			if constexpr (kMode != 2) {
+			if constexpr (kMode != 2 && !kDump) {
 				if (use_log)
 					log_emit(hit, key); // the increment itself happens later (ntc_apply.hip)
 				else if (hit)
@@ -555,7 +565,9 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 						}
 					}
 					const uint32_t mn = fs < rs ? fs : rs; // top bits of min(fh,rh) (of the spaced-seed values when gapped)
-					if (hll.value)
+					if (kDump)
+						m = ballot(true);
+					else if (hll.value)
 						m = ballot(mn < hll_thr); // nthll: only a hash with enough leading zeros can raise a register
 					else
 						m = ballot(mn < lo0) | ballot((int32_t)mn >= lo1); // two v_cmp + s_or_b64 (mn carries the flipped bit)
@@ -784,7 +796,11 @@ hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_b
 {
 	const dim3 g(grid), b(64u * waves_per_block);
 	const bool deep = sketch_hf_deep_prefetch(a.stride) && waves_per_block <= 12; // plain k-mer mode only
-	if (a.hll_bits != 0)
+	if (a.dump != nullptr && a.gap != 0)
+		hipLaunchKernelGGL((sketch_hf_kernel<false, 1, 10, true>), g, b, smem, st, a);
+	else if (a.dump != nullptr)
+		hipLaunchKernelGGL((sketch_hf_kernel<false, 0, 10, true>), g, b, smem, st, a);
+	else if (a.hll_bits != 0)
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 2, 10>), g, b, smem, st, a);
 	else if (a.gap != 0)
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 1, 10>), g, b, smem, st, a);
@@ -799,6 +815,28 @@ hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_b
 	return hipGetLastError();
 }
 
+// validation: per read, the hashes of the valid windows in window order (the layout ntc_hash_dump_device documents)
+__global__ __launch_bounds__(256) void compact_dump_kernel(const uint64_t* __restrict__ full, const uint32_t* __restrict__ valid, uint64_t n_reads,
+                                                           uint32_t n_win, uint32_t max_win, uint64_t* __restrict__ out, uint32_t* __restrict__ count)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint32_t vw = (n_win + 31u) >> 5;
+	uint32_t n = 0;
+	for (uint32_t w = 0; w < n_win; ++w)
+		if ((valid[r * vw + (w >> 5)] >> (w & 31u)) & 1u) {
+			if (n < max_win) out[r * max_win + n] = full[r * n_win + w];
+			++n;
+		}
+	count[r] = n;
+}
+hipError_t launch_compact_dump(const uint64_t* full, const uint32_t* valid, uint64_t n_reads, uint32_t n_win, uint32_t max_win, uint64_t* out,
+                               uint32_t* count, hipStream_t st)
+{
+	hipLaunchKernelGGL(compact_dump_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, full, valid, n_reads, n_win, max_win, out, count);
+	return hipGetLastError();
+}
+
 // slots of 164..256 B: a 16-chunk register prefetch covers them (the 10-chunk one would fall back to blocking loads)
 bool sketch_hf_deep_prefetch(uint32_t stride) { return 64u * stride > 10u * 1024u && 64u * stride <= 16u * 1024u; }
 
@@ -806,7 +844,8 @@ hipError_t set_sketch_hf_smem_limit(size_t smem)
 {
 	const void* fns[] = { reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 10>),
 		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 16>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 16>),
-		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 2, 10>) };
+		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 2, 10>),
+		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10, true>) };
 	for (const void* f : fns) {
 		const hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (rc != hipSuccess) return rc;

@@ -187,6 +187,8 @@ def value_hist_device(d_counters_ptr, n, d_hist_ptr, device=0, stream=None):
                                            C.c_void_p(d_hist_ptr)))
 
 
-def hash_dump_device(d_slots_ptr, n_reads, read_len, stride, k, gap, max_win, d_hash_ptr, d_count_ptr, device=0, stream=None):
-    check(_abi.lib().ntc_hash_dump_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_slots_ptr), n_reads,
+def hash_dump_device(d_slots_ptr, n_reads, read_len, stride, k, gap, max_win, d_hash_ptr, d_count_ptr, device=0, stream=None, k1=False):
+    """every canonical (spaced-seed when gap != 0) hash of every clean window; k1=True: out of the production kernel K1"""
+    fn = _abi.lib().ntc_hash_dump_k1_device if k1 else _abi.lib().ntc_hash_dump_device
+    check(fn(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_slots_ptr), n_reads,
                                           read_len, stride, k, gap, max_win, C.c_void_p(d_hash_ptr), C.c_void_p(d_count_ptr)))

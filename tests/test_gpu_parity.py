@@ -88,6 +88,39 @@ def test_hash_dump_matches_oracle(nt, L):
             assert np.array_equal(hh[i, : len(oh)], oh), (L, k, i)
 
 
+def test_golden_hash_vectors_through_production_kernel(nt, golden_dir):
+    """hash_vectors.json holds what the REFERENCE's ntHashIterator / stHashIterator enumerate (ntHashIterator.hpp:59-86,
+    stHashIterator.hpp:60-87, nthash.hpp:641-646; made by tools/make_golden.py with oracle/_ref/ref_tool) for 16
+    sequences of length 0..1000.  The validation build of the production kernel K1 (every window passes the filter,
+    so every value comes out of its closed-form resolve stage) must reproduce every 64-bit value, spaced seeds
+    included; the simple kernel K1d is checked on the plain vectors as well."""
+    with open(os.path.join(golden_dir, "hash_vectors.json")) as f:
+        vec = json.load(f)
+    seqs = [s.encode() for s in vec["seqs"]]
+
+    def dump(seq, k, gap, k1):
+        L = len(seq)
+        buf, stride = to_slots([seq], stride=max(4, (L + 3) & ~3))
+        buf[buf == 10] = ord("A")
+        d = torch.from_numpy(buf).cuda()
+        maxw = max(L - k + 1, 1)
+        dh = torch.zeros(maxw, dtype=torch.int64, device="cuda")
+        dc = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        nt.hash_dump_device(d.data_ptr(), 1, L, stride, k, gap, maxw, dh.data_ptr(), dc.data_ptr(), k1=k1)
+        torch.cuda.synchronize()
+        n = int(dc[0])
+        return ["%016x" % int(x) for x in dh.cpu().numpy().view(np.uint64)[:n]]
+
+    for ent in vec["sthash"]:
+        for s, hs in zip(seqs, ent["hash"]):
+            assert dump(s, ent["k"], ent["gap"], True) == hs, (ent["k"], ent["gap"], len(s))
+            assert dump(s, ent["k"], ent["gap"], False) == hs  # the plain entry point forwards spaced seeds to K1
+    for ent in vec["nthash"]:
+        for s, hs in zip(seqs, ent["hash"]):
+            assert dump(s, ent["k"], 0, True) == hs, (ent["k"], len(s))
+            assert dump(s, ent["k"], 0, False) == hs, (ent["k"], len(s))
+
+
 def test_known_answer_on_device(nt):
     # vendor/ntHash/unittest/UnitTests.cpp:39,45 — the reference's own invariant value
     buf, stride = to_slots([b"ACGTACACTGGACTGAGTCT"])
