@@ -50,6 +50,7 @@ def parse():
                          "over the ranks (strong scaling); 4: k=32,64,96,128 in one run; 5: spaced seed k=12 g=2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
+    ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
     ap.add_argument("--bitslice", action="store_true", help="use the experimental bit-sliced kernel K1b (k = 32, equal-length reads)")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
@@ -104,16 +105,29 @@ def cpu_baseline(args, nt_stride):
                       f"the build container), {dt:.2f} s timed"}
 
 
+def traffic_key(args, reads_per_launch):
+    k = ",".join(map(str, klist_of(args)))
+    return (f"dist={args.dist},L={args.read_len},k={k},gap={args.gap},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
+            + (",bitslice" if args.bitslice else "") + (",direct-atomics" if args.direct_atomics else "")
+            + (",always-log" if args.always_log else ""))
+
+
+def pmc_valu(args, reads_per_launch):
+    """VALU wave-instructions per launch of the hash kernel(s) from the same committed PMC passes (SQ_INSTS_VALU), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as f:
+            return json.load(f)[traffic_key(args, reads_per_launch)].get("valu_insts_per_launch")
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_traffic(args, reads_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_pmc.json); counters cannot
     be read from inside the process, so this is the measured value for the matching workload or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as f:
             table = json.load(f)
-        if args.klist or args.gap:
-            return None
-        key = f"dist={args.dist},L={args.read_len},k={args.k},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
-        return table[key]["traffic_bytes"]
+        return table[traffic_key(args, reads_per_launch)]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -181,7 +195,8 @@ def main():
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
     eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
-                    ext_sketch=sketch, ext_f1=f1_dev, flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0))
+                    ext_sketch=sketch, ext_f1=f1_dev, flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
+                    | (nt.FLAG_ALWAYS_LOG if args.always_log else 0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -222,6 +237,7 @@ def main():
 
     ker_ms, launches = eng.kernel_time()
     apply_ms, applies = eng.apply_time()
+    update_mode = eng.update_mode()
     if ph_merged is not None:
         eng.sync()
         ph, f1 = ph_merged.cpu().numpy().astype("uint32"), f1_dev.cpu().numpy().astype("uint64")
@@ -233,10 +249,12 @@ def main():
         import numpy as np
         hits = int(sum((ph[ki].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum() for ki in range(nk)))
         # --- roofline of the dominant kernel (nthash_kernel<0>), per launch, this rank ---
-        per_launch_kmers = total_kmers / max(world, 1) / max(launches, 1)
-        per_launch_hits = hits / max(world, 1) / max(launches, 1)
+        # one "launch" = the hash kernel(s) of one step (K1, or K1b + its redo pass; the first step of an adaptive engine is
+        # cut in two): HIP-event time of all of them / K
+        per_launch_kmers = total_kmers / max(world, 1) / max(K, 1)
+        per_launch_hits = hits / max(world, 1) / max(K, 1)
         alg_bytes = R * (L + 4) + 4.0 * per_launch_hits  # bases+offset read once, 2 B r/w per sampled hit
-        avg_ms = ker_ms / max(launches, 1)
+        avg_ms = ker_ms / max(K, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "k-mers/s hashed+sketched (whole node) at k=32, 150 bp reads",
@@ -255,7 +273,7 @@ def main():
                                    f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
                                    f"{K} steps x {R} reads per GPU" + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
                                    + (", RCCL reduce-scatter of the sketches + value histograms to rank 0 inside the timed region" if world > 1 else ""),
-                       "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
+                       "traffic_key": traffic_key(args, R), "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
                        "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),
@@ -263,13 +281,13 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_launch_kmers},
             # deferred sketch update (ntc_apply.hip), HIP-event timed like the hash kernel; inside the timed region
-            "sketch_apply": {"applies": applies, "total_ms": apply_ms, "ns_per_increment": apply_ms * 1e6 / max(hits, 1)},
-            # the kernel is VALU-issue bound, so also price it against the vector ALUs.  ops_per_step is
-            # read off the ISA of the steady-state walk (10 VALU per base-step + 8 per 4-step group); the whole kernel
-            # issues ~19.4 VALU per base-step (PMC SQ_INSTS_VALU, profiles/), peak = 256 CUs x 128 lanes x 2.4 GHz.
-            "valu": {"ops_per_step_walk": 12.0, "lane_ops_per_s": R * L * 12.0 / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
-                     "peak_lane_ops_per_s": 256 * 128 * 2.4e9,
-                     "frac_walk": (R * L * 12.0 / (avg_ms * 1e-3)) / (256 * 128 * 2.4e9) if avg_ms > 0 else 0.0},
+            "sketch_apply": {"mode_at_end": "direct atomics" if update_mode else "hit log", "applies": applies, "total_ms": apply_ms, "ns_per_increment": apply_ms * 1e6 / max(hits, 1)},
+            # the kernel is VALU-issue bound, so it is also priced against the vector ALUs: wave-instructions
+            # per launch from the committed PMC pass of this workload (SQ_INSTS_VALU, profiles/traffic_pmc.json; null when
+            # this workload was not profiled), per 64-lane base step; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 clk per wave64 op.
+            "valu": (lambda v: {"wave_insts_per_launch": v, "per_wave_step": (v / (R * L / 64.0)) if v else None,
+                                "wave_insts_per_s": (v / (avg_ms * 1e-3)) if v and avg_ms > 0 else None,
+                                "peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 2})(pmc_valu(args, R)),
             "f1_total": total_kmers,
             "sampled_increments": hits,
         }

@@ -55,8 +55,8 @@ typedef struct {
                                   (lets a host framework own/merge the buffer, e.g. RCCL reduce) */
     void *ext_f1;              /* optional caller-owned DEVICE uint64_t [n_k]; NULL -> engine    */
     uint32_t flags;            /* NTC_FLAG_*                                                      */
-    uint64_t log_entries;      /* capacity of the hit log in 4-byte entries, 0 = default (2^28 at
-                                  rBits = 27).  ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is
+    uint64_t log_entries;      /* capacity of the hit log in 4-byte entries, 0 = default (one per
+                                  counter: 2^28 at rBits = 27 and one k).  ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is
                                   deferred: the kernels log the counter index of every sampled k-mer
                                   and the log is applied to the sketch when it fills up and whenever
                                   the counters are needed (ntc_finish, ntc_flush, ...)              */
@@ -66,6 +66,8 @@ typedef struct {
 #define NTC_FLAG_SIMPLE_KERNEL 1u  /* run the simple validation kernel instead of the production ones */
 #define NTC_FLAG_BITSLICE_KERNEL 4u /* use the experimental bit-sliced kernel K1b for the whole 2048-read tiles of
                                       equal-length k = 32 batches (exact, but not yet faster than K1) */
+#define NTC_FLAG_ALWAYS_LOG 8u      /* keep logging whatever the data looks like (by default the engine switches to direct
+                                      atomics when an apply finds few distinct counters per increment: repeats)       */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 
@@ -181,6 +183,9 @@ int ntc_kernel_time(ntc_engine *e, double *ms_total, uint64_t *launches);
 /* same for the deferred sketch update (partition + count passes): milliseconds and number of applies */
 int ntc_apply_time(ntc_engine *e, double *ms_total, uint64_t *applies);
 int ntc_set_profiling(ntc_engine *e, int enable);
+/* how ntComp's increment is currently carried out on the device: 0 = hit log + partitioned apply, 1 = direct atomics
+ * (NTC_FLAG_DIRECT_ATOMICS, or chosen by the engine after an apply found mostly repeated counters); waits for the stream */
+int ntc_update_mode(ntc_engine *e, uint32_t *mode_out);
 
 #ifdef __cplusplus
 }

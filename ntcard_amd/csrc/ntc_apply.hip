@@ -10,7 +10,7 @@
 //   A1/A2  split_kernel   radix partition of the log by the top bits of the key (one or two passes, <= 256 ways
 //                         each; per-workgroup private output runs, so no global cursor atomics)
 //   A3     count_kernel   one workgroup per slice of 2^15 counters: histogram of the slice's keys in LDS
-//                         (ds_add, single writer per slice), then one coalesced `sketch[i] += n` sweep.
+//                         (ds_add on 16-bit fields, single writer per slice), then one coalesced `sketch[i] += n` sweep.
 //
 // Every run has a fixed capacity; a key that does not fit falls back to `atomicAdd(sketch + key, 1)`, which is
 // exact too (just slower), so skewed inputs (one k-mer repeated millions of times) stay correct.
@@ -23,7 +23,9 @@ namespace ntc {
 
 namespace {
 
-constexpr uint32_t kSplitRound = 2048; // keys per workgroup round (8 per thread)
+constexpr uint32_t kSplitThreads = 256;
+constexpr uint32_t kSplitKeys = 8;                              // keys per thread and round
+constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;      // 8192 keys per workgroup round: runs of ~32 keys (128 B) per digit
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -38,13 +40,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 } // namespace
 
 // A1/A2: partition the keys of this workgroup's input runs by digit = (key >> shift) & (2^bits - 1).
-__global__ __launch_bounds__(256) void split_kernel(const SplitArgs a)
+__global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 {
 	__shared__ uint32_t hist[256], excl[256], gcur[256], rankc[256];
 	__shared__ uint32_t sorted[kSplitRound];
 	const uint32_t tid = threadIdx.x, w = blockIdx.x;
 	const uint32_t nb = 1u << a.bits, dmask = nb - 1u;
-	gcur[tid] = 0;
+	if (tid < 256) gcur[tid] = 0;
 	uint32_t seg, step;
 	if (a.mode == 0) {
 		seg = w;
@@ -61,13 +63,15 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs a)
 		const uint32_t* src = a.in + (uint64_t)seg * a.in_cap;
 		for (uint32_t base = 0; base < n; base += kSplitRound) {
 			const uint32_t m = n - base < kSplitRound ? n - base : kSplitRound;
-			hist[tid] = 0;
-			rankc[tid] = 0;
+			if (tid < 256) {
+				hist[tid] = 0;
+				rankc[tid] = 0;
+			}
 			__syncthreads();
-			uint32_t key[8];
+			uint32_t key[kSplitKeys];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const uint32_t i = (uint32_t)j * 256u + tid;
+			for (int j = 0; j < (int)kSplitKeys; ++j) {
+				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
 				key[j] = 0;
 				if (i < m) {
 					key[j] = src[base + i];
@@ -86,15 +90,15 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs a)
 			}
 			__syncthreads();
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const uint32_t i = (uint32_t)j * 256u + tid;
+			for (int j = 0; j < (int)kSplitKeys; ++j) {
+				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
 				if (i < m) {
 					const uint32_t d = (key[j] >> a.shift) & dmask;
 					sorted[excl[d] + atomicAdd(&rankc[d], 1u)] = key[j];
 				}
 			}
 			__syncthreads();
-			for (uint32_t i = tid; i < m; i += 256u) {
+			for (uint32_t i = tid; i < m; i += kSplitThreads) {
 				const uint32_t kk = sorted[i];
 				const uint32_t d = (kk >> a.shift) & dmask;
 				const uint32_t off = gcur[d] + (i - excl[d]);
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs a)
 					atomicAdd(a.sketch + kk, 1u); // run is full: apply directly (exact, slower)
 			}
 			__syncthreads();
-			gcur[tid] += hist[tid]; // the same thread zeroes hist[tid] at the top of the next round
+			if (tid < 256) gcur[tid] += hist[tid]; // the same thread zeroes hist[tid] at the top of the next round
 		}
 	}
 	__syncthreads();
@@ -112,16 +116,15 @@ __global__ __launch_bounds__(256) void split_kernel(const SplitArgs a)
 }
 
 // A3: one workgroup per slice of 2^slice_bits counters (<= 2^15): LDS histogram of the slice's keys, then
-// sketch[slice] += histogram.  The slice has exactly one writer, so the sweep needs no atomics.
+// sketch[slice] += histogram.  The slice has exactly one writer, so the sweep needs no atomics.  The LDS counts are
+// 16 bits wide, two per dword (64 KiB per slice: two workgroups per CU overlap their phases); a pass takes at most
+// 65535 keys, so no count can carry into its neighbour, and a slice with more keys is done in several passes.
 __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 {
-	extern __shared__ __align__(16) uint32_t cnt[]; // [1 << slice_bits]
+	extern __shared__ __align__(16) uint32_t cnt[]; // [(1 << slice_bits) / 2]
 	const uint32_t tid = threadIdx.x, nt = blockDim.x;
-	const uint32_t n_cnt = 1u << a.slice_bits, cmask = n_cnt - 1u;
+	const uint32_t n_cnt = 1u << a.slice_bits, cmask = n_cnt - 1u, n_words = n_cnt >> 1;
 	for (uint32_t slice = blockIdx.x; slice < a.n_slices; slice += gridDim.x) {
-		for (uint32_t i = tid; i < n_cnt / 4; i += nt)
-			reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
-		__syncthreads();
 		uint32_t seg_add, seg_mul, seg_cnt;
 		if (a.mode == 0) { // raw log regions, single slice
 			seg_add = 0;
@@ -137,51 +140,156 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 			seg_mul = a.nb2;
 			seg_cnt = a.parts;
 		}
-		uint32_t any = 0;
-		for (uint32_t t = 0; t < seg_cnt; ++t) {
-			const uint32_t seg = t * seg_mul + seg_add;
-			uint32_t n = a.in_cnt[seg];
-			n = n < a.in_cap ? n : a.in_cap;
-			any |= n;
-			const uint32_t* src = a.in + (uint64_t)seg * a.in_cap;
-			for (uint32_t i = tid; i < n; i += nt)
-				atomicAdd(&cnt[src[i] & cmask], 1u);
-		}
-		__syncthreads();
-		if (any != 0) { // wave-uniform (every thread saw the same counts)
-			uint32_t* dst = a.sketch + ((uint64_t)slice << a.slice_bits);
-			for (uint32_t i = tid; i < n_cnt / 4; i += nt) {
-				const uint4 c = reinterpret_cast<const uint4*>(cnt)[i];
-				if ((c.x | c.y | c.z | c.w) != 0u) {
-					uint4 s = reinterpret_cast<uint4*>(dst)[i];
-					s.x += c.x;
-					s.y += c.y;
-					s.z += c.z;
-					s.w += c.w;
-					reinterpret_cast<uint4*>(dst)[i] = s;
+		uint32_t* dst = a.sketch + ((uint64_t)slice << a.slice_bits);
+		uint32_t t = 0;
+		while (t < seg_cnt && a.in_cnt[t * seg_mul + seg_add] == 0u) // leading empty runs (an empty log costs no LDS traffic at all)
+			++t;
+		while (t < seg_cnt) {
+			for (uint32_t i = tid; i < n_words / 4; i += nt)
+				reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+			__syncthreads();
+			uint32_t taken = 0; // keys of this pass (the same for every thread)
+			for (; t < seg_cnt; ++t) {
+				const uint32_t seg = t * seg_mul + seg_add;
+				uint32_t n = a.in_cnt[seg];
+				n = n < a.in_cap ? n : a.in_cap;
+				if (taken + n > 65535u) break; // the next run would allow a 16-bit count to wrap into its neighbour
+				taken += n;
+				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap;
+				for (uint32_t i = tid; i < n; i += nt) {
+					const uint32_t kk = src[i] & cmask;
+					atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
 				}
 			}
+			__syncthreads();
+			if (taken != 0) {
+				for (uint32_t i = tid; i < n_words / 2; i += nt) { // 2 dwords of LDS = 4 counters = one uint4 of the sketch
+					const uint2 c = reinterpret_cast<const uint2*>(cnt)[i];
+					if ((c.x | c.y) != 0u) {
+						uint4 s = reinterpret_cast<uint4*>(dst)[i];
+						s.x += c.x & 0xffffu;
+						s.y += c.x >> 16;
+						s.z += c.y & 0xffffu;
+						s.w += c.y >> 16;
+						reinterpret_cast<uint4*>(dst)[i] = s;
+					}
+				}
+			}
+			__syncthreads();
 		}
-		__syncthreads();
 	}
+}
+
+// Log or direct atomics?  A direct atomic per sampled k-mer is cheap when the counters it hits stay in the Infinity
+// Cache, i.e. when the k-mers of a batch repeat (deep coverage of a small genome); for mostly distinct k-mers it costs a
+// 128-byte HBM round trip each and the log + partition wins.  The probe looks at a sample of what the
+// first batch logged: keys go into a small open hash table, a key that finds itself there is a repeat.
+__global__ __launch_bounds__(256) void log_probe_kernel(const uint32_t* __restrict__ log, const uint32_t* __restrict__ fill, uint32_t region_cap,
+                                                        uint32_t n_regions, uint32_t per_region, uint32_t* __restrict__ table, uint32_t table_mask,
+                                                        unsigned long long* __restrict__ stats)
+{
+	uint32_t seen = 0, rep = 0;
+	for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+		uint32_t n = fill[r];
+		n = n < region_cap ? n : region_cap;
+		n = n < per_region ? n : per_region;
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+			const uint32_t key = log[(uint64_t)r * region_cap + i];
+			const uint32_t slot = (key * 0x9e3779b1u) >> 8 & table_mask;
+			const uint32_t old = atomicCAS(&table[slot], 0u, key + 1u);
+			++seen;
+			rep += old == key + 1u;
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		seen += __shfl_xor(seen, o);
+		rep += __shfl_xor(rep, o);
+	}
+	if ((threadIdx.x & 63u) == 0u && seen) {
+		atomicAdd(stats, (unsigned long long)seen);
+		atomicAdd(stats + 1, (unsigned long long)rep);
+	}
+}
+
+__global__ void log_decide_kernel(unsigned long long* stats, uint32_t* mode, unsigned long long min_keys)
+{
+	// uniform k-mers: ~0.05 % of a 256 K sample repeat; 15 x coverage of a 100 Mbp genome per batch: ~5 %
+	if (stats[0] >= min_keys && *mode == 0u) *mode = stats[1] * 100ull > stats[0] ? 1u : 0u;
+	stats[0] = 0;
+	stats[1] = 0;
+}
+
+hipError_t launch_log_probe(const uint32_t* log, const uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t per_region, uint32_t* table,
+                            uint32_t table_slots, unsigned long long* stats, uint32_t* mode, hipStream_t st)
+{
+	hipError_t rc = hipMemsetAsync(table, 0, (size_t)table_slots * 4, st);
+	if (rc != hipSuccess) return rc;
+	hipLaunchKernelGGL(log_probe_kernel, dim3(n_regions < 1024u ? n_regions : 1024u), dim3(256), 0, st, log, fill, region_cap, n_regions, per_region, table,
+	                   table_slots - 1u, stats);
+	hipLaunchKernelGGL(log_decide_kernel, dim3(1), dim3(1), 0, st, stats, mode, (unsigned long long)(1u << 16));
+	return hipGetLastError();
+}
+
+
+// A log that holds little (the head batch the mode was decided on, a tail at finish, everything after the switch to
+// direct atomics) is applied with plain atomics: the partition passes and the sweep over every slice have a fixed cost of
+// ~0.4 ms at rBits = 27.  The host does not know how much was logged (the mode lives on the device), so the first
+// kernel adds up the region fills and the second acts on the sum; the regions it applies are marked empty.
+__global__ __launch_bounds__(1024) void log_total_kernel(const uint32_t* __restrict__ fill, uint32_t n_regions, uint32_t* __restrict__ total)
+{
+	__shared__ uint32_t part[16];
+	uint32_t s = 0;
+	for (uint32_t r = threadIdx.x; r < n_regions; r += blockDim.x)
+		s += fill[r] >> 4; // in units of 16 entries: cannot overflow
+	for (int o = 32; o > 0; o >>= 1)
+		s += __shfl_xor(s, o);
+	if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t t = 0;
+		for (uint32_t w = 0; w < blockDim.x / 64; ++w)
+			t += part[w];
+		*total = t;
+	}
+}
+__global__ __launch_bounds__(256) void log_atomics_kernel(const uint32_t* __restrict__ log, uint32_t* __restrict__ fill, uint32_t region_cap,
+                                                          uint32_t n_regions, const uint32_t* __restrict__ total16, uint32_t max16, uint32_t* __restrict__ sketch)
+{
+	if (*total16 > max16) return; // plenty: the partition passes take it
+	for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+		uint32_t n = fill[r];
+		n = n < region_cap ? n : region_cap;
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+			atomicAdd(sketch + log[(uint64_t)r * region_cap + i], 1u);
+		__syncthreads();
+		if (threadIdx.x == 0) fill[r] = 0;
+	}
+}
+
+hipError_t launch_log_atomics(const uint32_t* log, uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t* total16, uint32_t* sketch, hipStream_t st)
+{
+	hipLaunchKernelGGL(log_total_kernel, dim3(1), dim3(1024), 0, st, fill, n_regions, total16);
+	hipLaunchKernelGGL(log_atomics_kernel, dim3(n_regions < 4096u ? n_regions : 4096u), dim3(256), 0, st, log, fill, region_cap, n_regions, total16,
+	                   (4u << 20) >> 4, sketch);
+	return hipGetLastError();
 }
 
 hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st)
 {
-	hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(kSplitThreads), 0, st, a);
 	return hipGetLastError();
 }
 
 hipError_t launch_count(const CountArgs& a, unsigned grid, hipStream_t st)
 {
-	const size_t smem = sizeof(uint32_t) << a.slice_bits;
+	const size_t smem = (sizeof(uint32_t) << a.slice_bits) / 2;
 	hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(1024), smem, st, a);
 	return hipGetLastError();
 }
 
 hipError_t set_apply_smem_limit()
 {
-	return hipFuncSetAttribute(reinterpret_cast<const void*>(&count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(&count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
 } // namespace ntc

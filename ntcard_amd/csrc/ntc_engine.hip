@@ -228,6 +228,12 @@ struct ntc_engine {
 	uint64_t log_cap = 0;           // entries
 	double log_est = 0.0;           // host-side upper estimate of the entries logged since the last apply
 	bool log_pending = false;
+	// log or direct atomics: decided ON THE DEVICE from a sample of what the first sizeable batch after a reset logged
+	// (repeated keys -> the counters stay cached -> direct atomics are cheaper; ntc_apply.hip, log_probe_kernel)
+	uint32_t* d_logmode = nullptr;          // 0 = log, 1 = direct atomics
+	unsigned long long* d_logstats = nullptr; // {keys sampled, repeats among them}
+	uint32_t* d_probe = nullptr;            // 2^20-slot hash table of the probe
+	bool adaptive = true, probed = false;
 	struct ApplyPlan {
 		uint32_t key_bits = 0, slice_bits = 0, b1 = 0, b2 = 0; // key = [b1 | b2 | slice_bits]
 		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
@@ -309,12 +315,12 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	ap.slice_bits = std::min<uint32_t>(15, ap.key_bits);
 	const uint32_t pb = ap.key_bits - ap.slice_bits;
 	if (pb > 16) return false;
-	ap.b1 = std::min<uint32_t>(8, pb);
+	ap.b1 = pb <= 8 ? pb : (pb + 1) / 2; // two passes: balanced fan-out (longer runs per digit coalesce better than 256-way + 32-way)
 	ap.b2 = pb - ap.b1;
 	ap.n_slices = (uint32_t)((counters + (1ull << ap.slice_bits) - 1) >> ap.slice_bits);
-	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 28, std::max<uint64_t>(1ull << 18, 4 * counters));
+	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(1ull << 18, counters));
 	cap = std::max<uint64_t>(cap, 1ull << 14);
-	e->log_region_cap = (uint32_t)std::max<uint64_t>(256, cap / 8192);
+	e->log_region_cap = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, cap / 8192)); // <= 65535: one run fits a 16-bit count pass
 	e->log_regions = (uint32_t)std::max<uint64_t>(1, cap / e->log_region_cap);
 	e->log_cap = (uint64_t)e->log_regions * e->log_region_cap;
 	// pass 1: g1 workgroups, each owns every g1-th region and writes 2^b1 private runs; a run holds its expected
@@ -351,6 +357,8 @@ int apply_log(ntc_engine* e)
 		HIP_TRY(hipEventCreate(&ev1));
 		HIP_TRY(hipEventRecord(ev0, e->stream));
 	}
+	// little in the log (decided on the device: fewer than 4 M entries): plain atomics, and the passes below find it empty
+	HIP_TRY(ntc::launch_log_atomics(e->d_log, e->d_logfill, e->log_region_cap, e->log_regions, (uint32_t*)(e->d_logstats + 2), e->d_sketch, e->stream));
 	ntc::CountArgs c;
 	std::memset(&c, 0, sizeof c);
 	c.slice_bits = ap.slice_bits;
@@ -413,7 +421,7 @@ int apply_log(ntc_engine* e)
 	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
-	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, (unsigned)di.cus), e->stream));
+	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, 2u * (unsigned)di.cus), e->stream));
 	HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
 	if (e->profiling) {
 		HIP_TRY(hipEventRecord(ev1, e->stream));
@@ -465,12 +473,15 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		return 0;
 	}
 	if (kind == KIND_HF) {
-		hipEvent_t ev0 = nullptr, ev1 = nullptr;
-		if (e->profiling) {
-			HIP_TRY(hipEventCreate(&ev0));
-			HIP_TRY(hipEventCreate(&ev1));
-			HIP_TRY(hipEventRecord(ev0, e->stream));
+		// The first sizeable equal-length batch after a reset is cut in two: a small head goes first, the probe samples what
+		// it logged and decides log vs direct atomics on the device, and the bulk of the batch already runs in that mode.
+		constexpr uint64_t kProbeHead = 2048ull * 320ull;
+		if (e->d_log && e->adaptive && !e->probed && d_meta == nullptr && n_slots >= 4 * kProbeHead) {
+			if (int rc = run_batch(e, d_slots, nullptr, kProbeHead, read_len, stride)) return rc;
+			return run_batch(e, d_slots + kProbeHead * stride, nullptr, n_slots - kProbeHead, read_len, stride);
 		}
+		hipEvent_t ev0 = nullptr, ev1 = nullptr;
+		double batch_est = 0.0;
 		if (e->d_log) {
 			// upper estimate of the sampled k-mers of this batch (both samples ~2^-sBits of the windows each, App. B of
 			// SURVEY.md) + what every wave may leave unused at the end of a region; apply first if the log could fill up
@@ -481,6 +492,12 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				if (int rc = apply_log(e)) return rc;
 			e->log_est += est;
 			e->log_pending = true;
+			batch_est = est;
+		}
+		if (e->profiling) { // the hash kernels of this batch only: an apply has its own pair of events
+			HIP_TRY(hipEventCreate(&ev0));
+			HIP_TRY(hipEventCreate(&ev1));
+			HIP_TRY(hipEventRecord(ev0, e->stream));
 		}
 		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
 		// a group whose closed-form tables would push the CU below 12 waves (and below what its members reach alone) is split in two
@@ -525,6 +542,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				a.log_fill = e->d_logfill;
 				a.log_regions = e->log_regions;
 				a.log_region_cap = e->log_region_cap;
+				a.log_mode = e->d_logmode;
 			}
 			a.sketch0 = e->d_sketch;
 			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
@@ -568,6 +586,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				ba.log_fill = e->d_logfill;
 				ba.log_regions = e->log_regions;
 				ba.log_region_cap = e->log_region_cap;
+				ba.log_mode = e->d_logmode;
 			}
 			ba.sketch0 = e->d_sketch;
 			ba.f1 = e->d_f1;
@@ -599,6 +618,11 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		if (e->profiling) {
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
+		}
+		if (e->d_log && e->adaptive && !e->probed && batch_est >= (double)(1u << 20)) { // first sizeable batch: sample its log, decide log vs atomics
+			e->probed = true;
+			HIP_TRY(ntc::launch_log_probe(e->d_log, e->d_logfill, e->log_region_cap, std::min<uint32_t>(e->log_regions, 1024), 256, e->d_probe, 1u << 20,
+			                              e->d_logstats, e->d_logmode, e->stream));
 		}
 		return 0;
 	}
@@ -719,8 +743,10 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the spaced-seed table on device");
 		}
 	}
+	e->adaptive = !(cfg->flags & NTC_FLAG_ALWAYS_LOG);
 	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_DIRECT_ATOMICS) && plan_log(e, cfg->log_entries)) {
-		if (hipMalloc((void**)&e->d_log, e->log_cap * 4) != hipSuccess || hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) != hipSuccess) {
+		if (hipMalloc((void**)&e->d_log, e->log_cap * 4) != hipSuccess || hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) != hipSuccess ||
+		    hipMalloc((void**)&e->d_logmode, 4) != hipSuccess || hipMalloc((void**)&e->d_logstats, 24) != hipSuccess || hipMalloc((void**)&e->d_probe, 4u << 20) != hipSuccess) {
 			ntc_destroy(e);
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log on device", (unsigned long long)e->log_cap);
 		}
@@ -759,7 +785,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
-	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo})
+	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
 		(void)hipEventDestroy(pr.first);
@@ -786,6 +812,11 @@ int ntc_reset(ntc_engine* e)
 	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->hll_bits ? (sizeof(uint32_t) << e->hll_bits) : e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
 	e->hll_reads_seen = 0;
 	if (e->d_logfill) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
+	if (e->d_logmode) {
+		HIP_TRY(hipMemsetAsync(e->d_logmode, 0, 4, e->stream));
+		HIP_TRY(hipMemsetAsync(e->d_logstats, 0, 24, e->stream));
+	}
+	e->probed = false;
 	e->log_pending = false;
 	e->log_est = 0.0;
 	HIP_TRY(hipMemsetAsync(e->d_f1, 0, e->klist.size() * 8, e->stream));
@@ -1383,6 +1414,19 @@ int ntc_apply_time(ntc_engine* e, double* ms_total, uint64_t* applies)
 	if (int rc = drain_events(e)) return rc;
 	if (ms_total) *ms_total = e->apply_ms;
 	if (applies) *applies = e->applies;
+	return 0;
+}
+
+int ntc_update_mode(ntc_engine* e, uint32_t* mode_out)
+{
+	if (!e || !mode_out) return fail(NTC_ERR_ARG, "ntc_update_mode: null argument");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	*mode_out = 1; // engines without a log increment directly
+	if (e->d_logmode) {
+		HIP_TRY(hipMemcpyAsync(mode_out, e->d_logmode, 4, hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+	}
 	return 0;
 }
 

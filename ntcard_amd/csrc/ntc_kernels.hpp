@@ -60,6 +60,7 @@ struct HfArgs {
 	uint32_t* log;              // [log_regions][log_region_cap] counter indices of sampled k-mers, relative to sketch0
 	uint32_t* log_fill;         // [log_regions] entries used per region (persists across launches until the log is applied)
 	uint32_t* sketch0;          // the engine's whole sketch array (overflow fallback of the log)
+	const uint32_t* log_mode;   // device word: 0 = append to the log, 1 = direct atomics (set by the apply pass, see ntc_apply.hip)
 	uint64_t* dump;             // validation build of K1 (kDump): [n_slots][dump_win] canonical hash of the window starting at each position
 	uint32_t* dump_valid;       //   [n_slots][ceil(dump_win / 32)] bit set where a hash was written (window without a non-ACGTU byte)
 	uint32_t dump_win, pad3_;
@@ -83,6 +84,7 @@ struct BsArgs {
 	uint32_t* log;
 	uint32_t* log_fill;
 	uint32_t* sketch0;
+	const uint32_t* log_mode;
 	unsigned long long* f1;
 	const void* t4;             // [k/4][256] x {fwd.lo, fwd.hi, rev.lo, rev.hi}: closed form, 4 bases per entry (code2 order)
 	uint32_t* redo_list;        // slot indices of the reads left to the lane-per-read kernel
@@ -120,6 +122,10 @@ struct CountArgs {
 	uint32_t slice_bits, n_slices;
 	uint32_t* sketch;
 };
+hipError_t launch_log_atomics(const uint32_t* log, uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t* total16, uint32_t* sketch, hipStream_t st);
+// sample of the first batch's log -> *mode (0 keep logging, 1 direct atomics: the sampled keys repeat); ntc_apply.hip
+hipError_t launch_log_probe(const uint32_t* log, const uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t per_region, uint32_t* table,
+                            uint32_t table_slots, unsigned long long* stats, uint32_t* mode, hipStream_t st);
 hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st);
 hipError_t launch_count(const CountArgs& a, unsigned grid, hipStream_t st);
 hipError_t set_apply_smem_limit();

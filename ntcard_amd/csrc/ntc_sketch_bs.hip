@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 	// ---- hit log (see ntc_sketch_hf.hip): this wave's regions are gwave, gwave + log_w, ... ----
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + part);
 	const uint32_t log_w = gridDim.x * 4u;
-	const bool use_log = a.log_regions != 0;
+	const bool use_log = a.log_regions != 0 && (a.log_mode == nullptr || __builtin_amdgcn_readfirstlane(*a.log_mode) == 0u);
 	uint32_t lreg = gwave, lfill = 0;
 	if (use_log && lreg < a.log_regions) lfill = __builtin_amdgcn_readfirstlane(a.log_fill[lreg]);
 	auto log_emit = [&](bool hit, uint32_t key) {

@@ -15,6 +15,7 @@ from ._abi import NtcConfig, NtcError, check
 
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
 FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: experimental bit-sliced kernel K1b for equal-length k = 32 batches
+FLAG_ALWAYS_LOG = 8  # NTC_FLAG_ALWAYS_LOG: never switch from the hit log to direct atomics
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 
@@ -122,6 +123,12 @@ class Engine:
         ms, n = C.c_double(), C.c_uint64()
         check(self._lib.ntc_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def update_mode(self):
+        """0: hit log + partitioned apply, 1: direct atomics (waits for the stream)"""
+        m = C.c_uint32()
+        check(self._lib.ntc_update_mode(self._h, C.byref(m)))
+        return m.value
 
     def apply_time(self):
         ms, n = C.c_double(), C.c_uint64()

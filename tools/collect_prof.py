@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""tools/collect_prof.py <tag> <round> [bench args...] — turn gpurun_out/prof_<tag>/ (written by tools/prof.sh on the
+GPU box) into the tracked evidence: profiles/<round>_<tag>/{kernel_stats.csv, summary.txt, bench.json} and an entry of
+profiles/traffic_pmc.json keyed by the workload (what bench.py reports as roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag, rnd = sys.argv[1], sys.argv[2]
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles", f"{rnd}_{tag}")
+    os.makedirs(dst, exist_ok=True)
+    ks = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)
+    lines = []
+    if ks:
+        shutil.copy(ks[0], os.path.join(dst, "kernel_stats.csv"))
+        lines.append("== kernel stats (rocprofv3 --kernel-trace --stats)")
+        lines += [",".join(r)[:220] for i, r in enumerate(csv.reader(open(ks[0]))) if i < 10]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    hash_kernels = {}
+    for k, v in agg.items():
+        if any(t in k for t in ("sketch_", "split_kernel", "count_kernel", "finalize")):
+            lines.append(f"== counters, mean per dispatch (separate --pmc passes): {k}")
+            for c, vals in sorted(v.items()):
+                lines.append("  %-28s %18.1f  n=%d" % (c, sum(vals) / len(vals), len(vals)))
+            if "sketch_" in k:
+                hash_kernels[k] = {c: sum(vals) / len(vals) for c, vals in v.items()}
+    bj = os.path.join(src, "bench.json")
+    bench = None
+    if os.path.exists(bj):
+        shutil.copy(bj, os.path.join(dst, "bench.json"))
+        try:
+            bench = json.loads(open(bj).read().strip().splitlines()[-1])
+        except ValueError:
+            bench = None
+    open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
+    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) summed over the hash kernels of one step (K1 / K1b + its redo pass)
+    if bench and hash_kernels:
+        fetch = sum(v.get("FETCH_SIZE", 0.0) for v in hash_kernels.values())
+        write = sum(v.get("WRITE_SIZE", 0.0) for v in hash_kernels.values())
+        key = bench["config"]["traffic_key"]
+        tj = os.path.join(ROOT, "profiles", "traffic_pmc.json")
+        table = json.load(open(tj))
+        table[key] = {"fetch_kb": fetch, "write_kb": write, "traffic_bytes": int((2 * fetch + write) * 1024),
+                      "source": f"profiles/{rnd}_{tag}/summary.txt",
+                      "valu_insts_per_launch": sum(v.get("SQ_INSTS_VALU", 0.0) for v in hash_kernels.values())}
+        json.dump(table, open(tj, "w"), indent=1)
+        print("traffic entry", key, table[key])
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main()
