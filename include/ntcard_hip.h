@@ -90,6 +90,11 @@ int ntc_reset(ntc_engine *e);                    /* re-zero sketch and F1 */
  * only the enqueue is serialised).                                                             */
 int ntc_submit(ntc_engine *e, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 
+/* The same for reads that are SPANS of one host buffer: read i = buf[starts[i], starts[i] + lens[i]).  This is what a
+ * block-based record splitter produces (the sequence lines of a FASTQ block, field 10 of SAM lines): the bytes are
+ * copied exactly once, from the file block into the pinned staging buffer.  Same threading and ownership rules.  */
+int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, const uint32_t *lens, uint64_t n_reads);
+
 /* Same for a batch that is already DEVICE-resident in the engine's slot layout: read i occupies
  * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Padding bytes
  * (read_len..stride) are never hashed; filling them with a base letter ('A') keeps the kernel on

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libntcard_hip.so")
 # every symbol include/ntcard_hip.h declares
 ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
-    "ntc_submit", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
+    "ntc_submit", "ntc_submit_spans", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_hash_dump_k1_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
     "ntc_kernel_time", "ntc_apply_time", "ntc_update_mode", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
 ]
@@ -67,6 +67,7 @@ def lib():
     L.ntc_destroy.restype = None
     L.ntc_reset.argtypes = [p]
     L.ntc_submit.argtypes = [p, p, p, u64]
+    L.ntc_submit_spans.argtypes = [p, p, p, p, u64]
     L.ntc_submit_device.argtypes = [p, p, u64, u32, u32]
     L.ntc_sync.argtypes = [p]
     L.ntc_finish.argtypes = [p, p, p, p]

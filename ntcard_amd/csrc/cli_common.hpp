@@ -5,10 +5,12 @@
 #pragma once
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <future>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -110,6 +112,19 @@ public:
 		}
 	}
 
+	// raw bytes for the block-based splitter: what is left of the line buffer first, then straight from the file
+	size_t read_raw(char* dst, size_t cap)
+	{
+		if (!fp_ || cap == 0) return 0;
+		if (pos_ < len_) {
+			const size_t n = std::min(cap, len_ - pos_);
+			std::memcpy(dst, &buf_[pos_], n);
+			pos_ += n;
+			return n;
+		}
+		return std::fread(dst, 1, cap, fp_);
+	}
+
 private:
 	FILE* fp_ = nullptr;
 	bool piped_ = false;
@@ -180,6 +195,89 @@ inline void parse_fastq(LineReader& in, Batcher& out) // ntcard.cpp:173-189 (4-l
 		if (good) out.add(seq);
 		good = in.getline(skip);
 	}
+}
+
+// Block-based FASTQ splitter: the file is read in 32 MiB blocks, the four-line records are split in
+// place with memchr and the sequence lines are handed to the engine as SPANS of the block (ntc_submit_spans), which
+// copies them once, straight into its pinned staging buffer.  A second thread packs block i while this one reads and
+// splits block i + 1.  Same record semantics as parse_fastq / ntcard.cpp:173-189: a record counts once its quality
+// line could be read (with or without a final newline); CR bytes and lower case stay in the sequence.
+inline void parse_fastq_blocks(LineReader& in, ntc_engine* eng)
+{
+	constexpr size_t kBlock = 32u << 20;
+	struct Block {
+		std::vector<char> buf;
+		std::vector<uint64_t> starts;
+		std::vector<uint32_t> lens;
+		std::future<int> pending;
+	} blk[2];
+	int cur = 0;
+	blk[0].buf.resize(kBlock);
+	blk[1].buf.resize(kBlock);
+	size_t have = 0, pos = 0;  // bytes in the current block, next unparsed byte
+	int phase = 0;             // line expected next: 0 sequence, 1 '+', 2 quality, 3 header of the next record
+	size_t s_start = 0, s_len = 0;
+	bool eof = false;
+	auto wait = [&](Block& b) {
+		if (b.pending.valid() && b.pending.get() != 0) die_engine();
+	};
+	for (;;) {
+		Block& b = blk[cur];
+		if (!eof) {
+			const size_t n = in.read_raw(b.buf.data() + have, b.buf.size() - have);
+			if (n == 0) eof = true;
+			have += n;
+		}
+		for (;;) { // split the lines of [pos, have)
+			const char* base = b.buf.data();
+			const char* nl = static_cast<const char*>(std::memchr(base + pos, '\n', have - pos));
+			size_t line_end, next;
+			if (nl) {
+				line_end = (size_t)(nl - base);
+				next = line_end + 1;
+			} else if (eof && pos < have) { // last line of the file, no newline
+				line_end = next = have;
+			} else {
+				break;
+			}
+			if (phase == 0) {
+				s_start = pos;
+				s_len = line_end - pos;
+			} else if (phase == 2) { // the quality line could be read: the record counts
+				b.starts.push_back(s_start);
+				b.lens.push_back((uint32_t)s_len);
+			}
+			phase = (phase + 1) & 3;
+			pos = next;
+		}
+		if (eof && pos >= have) {
+			if (!b.starts.empty() && ntc_submit_spans(eng, b.buf.data(), b.starts.data(), b.lens.data(), b.starts.size()) != 0) die_engine();
+			break;
+		}
+		// the block is exhausted: everything from the first line still needed moves to the front of the other block
+		const size_t keep = (phase == 1 || phase == 2) ? s_start : pos;
+		Block& o = blk[cur ^ 1];
+		wait(o); // its previous contents have been packed
+		if (keep == 0 && have == b.buf.size()) { // one line longer than the block: grow and read on
+			b.buf.resize(b.buf.size() * 2);
+			continue;
+		}
+		const size_t tail = have - keep;
+		if (o.buf.size() < b.buf.size()) o.buf.resize(b.buf.size());
+		std::memcpy(o.buf.data(), b.buf.data() + keep, tail);
+		o.starts.clear();
+		o.lens.clear();
+		if (!b.starts.empty()) {
+			Block* pb = &b;
+			b.pending = std::async(std::launch::async, [eng, pb] { return ntc_submit_spans(eng, pb->buf.data(), pb->starts.data(), pb->lens.data(), pb->starts.size()); });
+		}
+		s_start -= keep;
+		pos -= keep;
+		have = tail;
+		cur ^= 1;
+	}
+	wait(blk[0]);
+	wait(blk[1]);
 }
 
 inline void parse_fasta(LineReader& in, Batcher& out) // ntcard.cpp:191-208 (multi-line records are concatenated)

@@ -38,6 +38,22 @@ int fail(int code, const char* fmt, ...)
 	return code;
 }
 
+} // namespace
+
+// the same for the other translation units of the library (ntc_estimator.cpp)
+int ntc_internal_fail(int code, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                               \
 	do {                                                                                            \
 		hipError_t e__ = (expr);                                                                    \
@@ -841,20 +857,22 @@ int ntc_submit_device(ntc_engine* e, const void* d_slots, uint64_t n_reads, uint
 	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride);
 }
 
-int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64_t n_reads)
+} // extern "C"
+
+namespace {
+// read i = bytes [ptr_of(i), ptr_of(i) + len_of(i)): ntc_submit (concatenated reads + offsets) and ntc_submit_spans (spans of
+// a caller buffer, e.g. the sequence lines inside a block of a FASTQ file) pack into the pinned staging pair the same way
+template <typename LenOf, typename PtrOf>
+int submit_impl(ntc_engine* e, uint64_t n_reads, LenOf len_of, PtrOf ptr_of)
 {
-	if (!e) return fail(NTC_ERR_ARG, "ntc_submit: null engine");
-	if (n_reads == 0) return 0;
-	if (!bases || !offsets) return fail(NTC_ERR_ARG, "ntc_submit: null buffer");
 	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
 	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
 	// ---- plan: one slot per read, or chunks with kmax-1 overlap for long sequences ----
 	uint64_t maxlen = 0;
 	bool uniform = true;
-	const uint64_t len0 = offsets[1] - offsets[0];
+	const uint64_t len0 = len_of(0);
 	for (uint64_t i = 0; i < n_reads; ++i) {
-		if (offsets[i + 1] < offsets[i]) return fail(NTC_ERR_ARG, "ntc_submit: offsets not monotone at read %llu", (unsigned long long)i);
-		const uint64_t l = offsets[i + 1] - offsets[i];
+		const uint64_t l = len_of(i);
 		maxlen = std::max(maxlen, l);
 		uniform &= (l == len0);
 	}
@@ -868,7 +886,7 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 		n_slots = n_reads;
 	} else {
 		for (uint64_t i = 0; i < n_reads; ++i) {
-			const uint64_t l = offsets[i + 1] - offsets[i];
+			const uint64_t l = len_of(i);
 			if (l < kmin) continue;
 			n_slots += l <= cap_chunk ? 1 : (l - (kmax - 1) + ch - 1) / ch;
 		}
@@ -949,17 +967,17 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 	if (!chunked && !uniform && n_reads < 0xffffffffull) {
 		std::vector<uint64_t> first(maxlen + 2, 0);
 		for (uint64_t i = 0; i < n_reads; ++i)
-			++first[maxlen - (offsets[i + 1] - offsets[i]) + 1];
+			++first[maxlen - len_of(i) + 1];
 		for (uint64_t l = 1; l <= maxlen + 1; ++l)
 			first[l] += first[l - 1];
 		order.resize(n_reads);
 		for (uint64_t i = 0; i < n_reads; ++i)
-			order[first[maxlen - (offsets[i + 1] - offsets[i])]++] = (uint32_t)i;
+			order[first[maxlen - len_of(i)]++] = (uint32_t)i;
 	}
 	for (uint64_t j = 0; j < n_reads; ++j) {
 		const uint64_t i = order.empty() ? j : order[j];
-		const uint64_t l = offsets[i + 1] - offsets[i];
-		const char* src = bases + offsets[i];
+		const uint64_t l = len_of(i);
+		const char* src = ptr_of(i);
 		if (!chunked) {
 			unsigned char* dst = hs + slot * stride;
 			std::memcpy(dst, src, l);
@@ -1004,6 +1022,28 @@ int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64
 		if (rc) return rc;
 	}
 	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int ntc_submit(ntc_engine* e, const char* bases, const uint64_t* offsets, uint64_t n_reads)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit: null engine");
+	if (n_reads == 0) return 0;
+	if (!bases || !offsets) return fail(NTC_ERR_ARG, "ntc_submit: null buffer");
+	for (uint64_t i = 0; i < n_reads; ++i)
+		if (offsets[i + 1] < offsets[i]) return fail(NTC_ERR_ARG, "ntc_submit: offsets not monotone at read %llu", (unsigned long long)i);
+	return submit_impl(e, n_reads, [&](uint64_t i) { return offsets[i + 1] - offsets[i]; }, [&](uint64_t i) { return bases + offsets[i]; });
+}
+
+int ntc_submit_spans(ntc_engine* e, const char* buf, const uint64_t* starts, const uint32_t* lens, uint64_t n_reads)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit_spans: null engine");
+	if (n_reads == 0) return 0;
+	if (!buf || !starts || !lens) return fail(NTC_ERR_ARG, "ntc_submit_spans: null buffer");
+	return submit_impl(e, n_reads, [&](uint64_t i) { return (uint64_t)lens[i]; }, [&](uint64_t i) { return buf + starts[i]; });
 }
 
 int ntc_sync(ntc_engine* e)

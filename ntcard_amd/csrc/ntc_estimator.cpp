@@ -14,12 +14,14 @@
 
 #include "../../include/ntcard_hip.h"
 
+int ntc_internal_fail(int code, const char* fmt, ...); // ntc_engine.hip: sets ntc_last_error()
+
 extern "C" {
 
 int ntc_estimate(const uint32_t* p_hist, uint32_t r_bits, uint32_t s_bits, uint32_t cov_max, double* F0_out,
                  double* f_out)
 {
-	if (!p_hist || !F0_out || !f_out) return NTC_ERR_ARG;
+	if (!p_hist || !F0_out || !f_out) return ntc_internal_fail(NTC_ERR_ARG, "ntc_estimate: null argument");
 	if (cov_max > 65535) cov_max = 65535; // ntcard.cpp:340-344
 	const unsigned n_samp = 2;
 	std::vector<double> p_mean(cov_max + 1, 0.0);
@@ -53,7 +55,7 @@ int ntc_estimate(const uint32_t* p_hist, uint32_t r_bits, uint32_t s_bits, uint3
 // nthll.cpp:247-254: alpha * m^2 / sum_j 2^-M[j], alpha halved because the hashes are canonical
 int ntc_hll_estimate(const uint8_t* regs, uint32_t n_bits, double* est_out)
 {
-	if (!regs || !est_out || n_bits > 31) return NTC_ERR_ARG;
+	if (!regs || !est_out || n_bits > 31) return ntc_internal_fail(NTC_ERR_ARG, "ntc_hll_estimate: null argument or n_bits %u > 31", n_bits);
 	const unsigned n_buck = 1u << n_bits;
 	double alpha = 1.4426 / (1 + 1.079 / n_buck);
 	alpha /= 2;
@@ -67,14 +69,14 @@ int ntc_hll_estimate(const uint8_t* regs, uint32_t n_bits, double* est_out)
 
 int ntc_write_hist(const char* path, uint64_t f1, double F0, const double* f, uint32_t cov_max)
 {
-	if (!path || !f) return NTC_ERR_ARG;
+	if (!path || !f) return ntc_internal_fail(NTC_ERR_ARG, "ntc_write_hist: null argument");
 	FILE* out = std::fopen(path, "w");
-	if (!out) return NTC_ERR_ARG;
+	if (!out) return ntc_internal_fail(NTC_ERR_ARG, "ntc_write_hist: cannot open %s for writing", path);
 	std::fprintf(out, "F1\t%llu\n", (unsigned long long)f1);
 	std::fprintf(out, "F0\t%llu\n", (unsigned long long)(uint64_t)F0);
 	for (uint32_t i = 1; i <= cov_max; ++i)
 		std::fprintf(out, "%u\t%llu\n", i, (unsigned long long)(uint64_t)f[i]);
-	return std::fclose(out) == 0 ? 0 : NTC_ERR_ARG;
+	return std::fclose(out) == 0 ? 0 : ntc_internal_fail(NTC_ERR_ARG, "ntc_write_hist: write to %s failed", path);
 }
 
 } // extern "C"

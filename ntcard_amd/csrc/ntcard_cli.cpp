@@ -67,7 +67,7 @@ void process_file(const std::string& path, ntc_engine* eng)
 	const unsigned type = sniff(first, sam_has_header);
 	Batcher batch(eng);
 	if (type == 0)
-		parse_fastq(in, batch);
+		parse_fastq_blocks(in, eng);
 	else if (type == 1)
 		parse_fasta(in, batch);
 	else if (type == 2)
@@ -154,6 +154,17 @@ int main(int argc, char** argv)
 	}
 	if (opt.gap != 0 && opt.klist.size() != 1) {
 		std::cerr << PROGRAM << ": -g does not support multiple k currently.\n";
+		die = true;
+	}
+	// engine limits the reference does not have (README "Limits"): k <= ntc_max_k() (the closed-form tables of the
+	// resolve stage live in LDS), at most NTC_MAX_K_LIST values of k
+	for (unsigned k : opt.klist)
+		if (k < 1 || k > ntc_max_k()) {
+			std::cerr << PROGRAM << ": k=" << k << " is outside the range 1.." << ntc_max_k() << " this GPU engine supports\n";
+			die = true;
+		}
+	if (opt.klist.size() > NTC_MAX_K_LIST) {
+		std::cerr << PROGRAM << ": at most " << NTC_MAX_K_LIST << " values of k per run\n";
 		die = true;
 	}
 	if (die) {

@@ -103,6 +103,10 @@ int main(int argc, char** argv)
 	}
 	int device = 0;
 	if (const char* dev = std::getenv("NTCARD_DEVICE")) device = std::atoi(dev);
+	if (k < 1 || k > ntc_max_k()) { // engine limit the reference does not have (README "Limits")
+		std::cerr << kProgram << ": k=" << k << " is outside the range 1.." << ntc_max_k() << " this GPU engine supports\n";
+		std::exit(EXIT_FAILURE);
+	}
 	ntc_engine* eng = nullptr;
 	if (ntc_hll_create(k, n_bits, device, nullptr, &eng) != 0) die_engine();
 	std::atomic<size_t> next(0);

@@ -79,6 +79,14 @@ class Engine:
             b = np.zeros(1, dtype=np.uint8)
         check(self._lib.ntc_submit(self._h, _np_ptr(b), _np_ptr(o), len(o) - 1))
 
+    def submit_spans(self, buf, starts, lens):
+        """reads as spans of one host buffer: read i = buf[starts[i] : starts[i] + lens[i]]"""
+        b = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else np.ascontiguousarray(buf, dtype=np.uint8)
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        ln = np.ascontiguousarray(lens, dtype=np.uint32)
+        assert len(st) == len(ln)
+        check(self._lib.ntc_submit_spans(self._h, _np_ptr(b), _np_ptr(st), _np_ptr(ln), len(st)))
+
     def submit_reads(self, reads):
         offs = np.zeros(len(reads) + 1, dtype=np.uint64)
         if reads:
