@@ -28,14 +28,6 @@ def main():
     for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    hash_kernels = {}
-    for k, v in agg.items():
-        if any(t in k for t in ("sketch_", "split_kernel", "count_kernel", "finalize")):
-            lines.append(f"== counters, mean per dispatch (separate --pmc passes): {k}")
-            for c, vals in sorted(v.items()):
-                lines.append("  %-28s %18.1f  n=%d" % (c, sum(vals) / len(vals), len(vals)))
-            if "sketch_" in k:
-                hash_kernels[k] = {c: sum(vals) / len(vals) for c, vals in v.items()}
     bj = os.path.join(src, "bench.json")
     bench = None
     if os.path.exists(bj):
@@ -44,8 +36,26 @@ def main():
             bench = json.loads(open(bj).read().strip().splitlines()[-1])
         except ValueError:
             bench = None
+    # A bench step is one batch; the engine may cut a batch into several dispatches of the hash kernel (the first batch
+    # of an engine is split into a small head, whose hit log is sampled to choose the update mode, and the rest), so the
+    # per-step figure is the SUM over all dispatches divided by the number of steps the command ran (warm-up + timed).
+    n_steps = (bench["steps"] + bench["warmup"]) if bench else None
+    if ks and n_steps:
+        for r in csv.DictReader(open(ks[0])):
+            if "sketch_" in r["Name"]:
+                lines.append("   -> %s: %d dispatches over %d bench steps = %.4f ms per step" %
+                             (r["Name"][:48], int(r["Calls"]), n_steps, float(r["TotalDurationNs"]) / n_steps / 1e6))
+    hash_kernels = {}
+    for k, v in agg.items():
+        if any(t in k for t in ("sketch_", "split_kernel", "count_kernel", "finalize")):
+            lines.append(f"== counters (separate --pmc passes), mean per dispatch | per bench step: {k}")
+            for c, vals in sorted(v.items()):
+                per_step = ("%18.1f" % (sum(vals) / n_steps)) if n_steps else "-"
+                lines.append("  %-28s %18.1f  n=%d | %s" % (c, sum(vals) / len(vals), len(vals), per_step))
+            if "sketch_" in k:
+                hash_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
     open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
-    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) summed over the hash kernels of one step (K1 / K1b + its redo pass)
+    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) of the hash kernels per bench step (K1 / K1b + its redo pass)
     if bench and hash_kernels:
         fetch = sum(v.get("FETCH_SIZE", 0.0) for v in hash_kernels.values())
         write = sum(v.get("WRITE_SIZE", 0.0) for v in hash_kernels.values())
