@@ -8,7 +8,11 @@
 // increments can be applied later and in any order:
 //
 //   A1/A2  split_kernel   radix partition of the log by the top bits of the key (one or two passes, <= 256 ways
-//                         each; per-workgroup private output runs, so no global cursor atomics)
+//                         each; per-workgroup private output runs, so no global cursor atomics).  Per round a
+//                         workgroup sorts 4096 keys by digit in LDS: ONE returning ds_add per key yields the digit
+//                         count and the key's rank, the next round's keys are already in flight, and the sorted
+//                         tile leaves as ~128-byte segments.  Round 2 history: two LDS atomics per key + no prefetch
+//                         0.85 + 0.65 ms per 92 M keys; this form 0.51 + 0.36 ms.
 //   A3     count_kernel   one workgroup per slice of 2^15 counters: histogram of the slice's keys in LDS
 //                         (ds_add on 16-bit fields, single writer per slice), then one coalesced `sketch[i] += n` sweep.
 //
@@ -24,8 +28,8 @@ namespace ntc {
 namespace {
 
 constexpr uint32_t kSplitThreads = 256;
-constexpr uint32_t kSplitKeys = 8;                              // keys per thread and round
-constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;      // 8192 keys per workgroup round: runs of ~32 keys (128 B) per digit
+constexpr uint32_t kSplitKeys = 16;                             // keys per thread and round
+constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;      // 4096 keys per workgroup round: runs of ~32 keys (128 B) per digit at 128 ways
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -42,11 +46,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 // A1/A2: partition the keys of this workgroup's input runs by digit = (key >> shift) & (2^bits - 1).
 __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 {
-	__shared__ uint32_t hist[256], excl[256], gcur[256], rankc[256];
+	// hist: digit counts of the round; excl: their exclusive scan; rel: gcur - excl (run offset of sorted position 0 of a
+	// digit); gcur: keys this workgroup has written per digit so far
+	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256];
 	__shared__ uint32_t sorted[kSplitRound];
 	const uint32_t tid = threadIdx.x, w = blockIdx.x;
 	const uint32_t nb = 1u << a.bits, dmask = nb - 1u;
-	if (tid < 256) gcur[tid] = 0;
+	if (tid < 256) {
+		gcur[tid] = 0;
+		hist[tid] = 0;
+	}
 	uint32_t seg, step;
 	if (a.mode == 0) {
 		seg = w;
@@ -57,27 +66,31 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 		step = a.parts * a.nb_in;
 	}
 	uint32_t* const outw = a.out + (uint64_t)w * nb * a.out_cap;
+	__syncthreads();
 	for (; seg < a.n_in; seg += step) {
 		uint32_t n = a.in_cnt[seg];
 		n = n < a.in_cap ? n : a.in_cap;
 		const uint32_t* src = a.in + (uint64_t)seg * a.in_cap;
-		for (uint32_t base = 0; base < n; base += kSplitRound) {
-			const uint32_t m = n - base < kSplitRound ? n - base : kSplitRound;
-			if (tid < 256) {
-				hist[tid] = 0;
-				rankc[tid] = 0;
-			}
-			__syncthreads();
-			uint32_t key[kSplitKeys];
+		uint32_t key[kSplitKeys], nxt[kSplitKeys];
+		auto fetch = [&](uint32_t base, uint32_t (&k)[kSplitKeys]) { // addresses clamped instead of predicated loads: branch-free, coalesced
 #pragma unroll
 			for (int j = 0; j < (int)kSplitKeys; ++j) {
-				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
-				key[j] = 0;
-				if (i < m) {
-					key[j] = src[base + i];
-					atomicAdd(&hist[(key[j] >> a.shift) & dmask], 1u);
-				}
+				const uint32_t i = base + (uint32_t)j * kSplitThreads + tid;
+				k[j] = src[i < n ? i : (n ? n - 1u : 0u)];
 			}
+		};
+		if (n) fetch(0, nxt);
+		for (uint32_t base = 0; base < n; base += kSplitRound) {
+			const uint32_t m = n - base < kSplitRound ? n - base : kSplitRound;
+			uint32_t rank[kSplitKeys];
+#pragma unroll
+			for (int j = 0; j < (int)kSplitKeys; ++j) {
+				key[j] = nxt[j];
+				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
+				// ONE returning LDS atomic per key gives both the digit count and the key's rank inside its digit
+				rank[j] = i < m ? atomicAdd(&hist[(key[j] >> a.shift) & dmask], 1u) : 0u;
+			}
+			if (base + kSplitRound < n) fetch(base + kSplitRound, nxt); // next round's keys are in flight during the sort
 			__syncthreads();
 			if (tid < 64) { // exclusive scan of the 256 digit counts
 				const uint32_t v0 = hist[4 * tid], v1 = hist[4 * tid + 1], v2 = hist[4 * tid + 2], v3 = hist[4 * tid + 3];
@@ -87,28 +100,31 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 				excl[4 * tid + 1] = b0 + v0;
 				excl[4 * tid + 2] = b0 + v0 + v1;
 				excl[4 * tid + 3] = b0 + v0 + v1 + v2;
+				rel[4 * tid] = gcur[4 * tid] - b0;
+				rel[4 * tid + 1] = gcur[4 * tid + 1] - (b0 + v0);
+				rel[4 * tid + 2] = gcur[4 * tid + 2] - (b0 + v0 + v1);
+				rel[4 * tid + 3] = gcur[4 * tid + 3] - (b0 + v0 + v1 + v2);
 			}
 			__syncthreads();
 #pragma unroll
 			for (int j = 0; j < (int)kSplitKeys; ++j) {
 				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
-				if (i < m) {
-					const uint32_t d = (key[j] >> a.shift) & dmask;
-					sorted[excl[d] + atomicAdd(&rankc[d], 1u)] = key[j];
-				}
+				if (i < m) sorted[excl[(key[j] >> a.shift) & dmask] + rank[j]] = key[j];
+			}
+			if (tid < 256) { // every thread owns its digit's slots: book the round, clear the counts for the next one
+				gcur[tid] += hist[tid];
+				hist[tid] = 0;
 			}
 			__syncthreads();
 			for (uint32_t i = tid; i < m; i += kSplitThreads) {
 				const uint32_t kk = sorted[i];
-				const uint32_t d = (kk >> a.shift) & dmask;
-				const uint32_t off = gcur[d] + (i - excl[d]);
+				const uint32_t off = rel[(kk >> a.shift) & dmask] + i;
 				if (off < a.out_cap)
-					outw[(uint64_t)d * a.out_cap + off] = kk;
+					outw[(uint64_t)((kk >> a.shift) & dmask) * a.out_cap + off] = kk;
 				else
 					atomicAdd(a.sketch + kk, 1u); // run is full: apply directly (exact, slower)
 			}
-			__syncthreads();
-			if (tid < 256) gcur[tid] += hist[tid]; // the same thread zeroes hist[tid] at the top of the next round
+			__syncthreads(); // sorted / rel are rewritten by the next round
 		}
 	}
 	__syncthreads();
