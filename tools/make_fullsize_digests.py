@@ -7,7 +7,8 @@ device generator K0) in the build container and commits, per k: F1, the sha1 of 
 the reference's own <prefix>_k<K>.hist bytes (tests/golden/fullsize/).  The -m gpu test
 tests/test_fullsize_gpu.py regenerates the same reads on the device and compares digests and .hist bytes.
 
-  python tools/make_fullsize_digests.py [n_reads]      (default 100000000; ~3 minutes on 8 cores, ~3 GB of RAM)
+  python tools/make_fullsize_digests.py [n_reads] [name ...]   (default 100000000 reads, all configs; ~4 minutes on 8 cores,
+                                                                ~3 GB of RAM; with names: only those, merged into digests.json)
 """
 import hashlib
 import json
@@ -20,11 +21,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "oracle", "_ref", "ref_tool")
 OUT = os.path.join(ROOT, "tests", "golden", "fullsize")
 
-CONFIGS = [  # (name, dist, klist, gap)
-    ("cfg2", 1, [32], 0),
-    ("cfg2u", 0, [32], 0),
-    ("cfg4", 1, [32, 64, 96, 128], 0),
-    ("cfg5", 1, [12], 2),
+CONFIGS = [  # (name, dist, klist, gap, s_bits)
+    ("cfg2", 1, [32], 0, 7),
+    ("cfg2u", 0, [32], 0, 7),
+    ("cfg4", 1, [32, 64, 96, 128], 0, 7),
+    ("cfg5", 1, [12], 2, 7),
+    ("cfg3s", 1, [32], 0, 11),  # config 3's sampling (the >= 50 GB branch of ntcard.cpp:427-431: sBits = 11), one GPU's share of reads
 ]
 
 
@@ -38,17 +40,25 @@ def sha1_file(path):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+    only = set(sys.argv[2:])
     os.makedirs(OUT, exist_ok=True)
     threads = os.cpu_count() or 1
     meta = {"n_reads": n, "read_len": 150, "seed": 1, "r_bits": 27, "s_bits": 7, "cov_max": 1000, "generator": "orc_gen_reads == K0",
             "made_by": "oracle/_ref/ref_tool fullsize (the reference's ntRead/stRead/outDefault)", "configs": {}}
+    dj = os.path.join(OUT, "digests.json")
+    if only and os.path.exists(dj):
+        old = json.load(open(dj))
+        assert old["n_reads"] == n, "partial regeneration must keep n_reads"
+        meta["configs"] = old["configs"]
     with tempfile.TemporaryDirectory() as tmp:
-        for name, dist, klist, gap in CONFIGS:
+        for name, dist, klist, gap, s_bits in CONFIGS:
+            if only and name not in only:
+                continue
             prefix = os.path.join(tmp, name)
-            cmd = [TOOL, "fullsize", "1", str(n), "150", str(dist), ",".join(map(str, klist)), str(gap), "27", "7", str(threads), prefix]
+            cmd = [TOOL, "fullsize", "1", str(n), "150", str(dist), ",".join(map(str, klist)), str(gap), "27", str(s_bits), str(threads), prefix]
             out = subprocess.run(cmd, stdout=subprocess.PIPE, check=True).stdout.decode()
             f1 = {int(l.split()[0][2:]): int(l.split()[1][3:]) for l in out.strip().splitlines()}
-            ent = {"dist": dist, "klist": klist, "gap": gap, "planes": []}
+            ent = {"dist": dist, "klist": klist, "gap": gap, "s_bits": s_bits, "planes": []}
             for k in klist:
                 hist = open(f"{prefix}_k{k}.hist", "rb").read()
                 gold = f"{name}_k{k}.hist"
