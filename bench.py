@@ -222,8 +222,8 @@ def main():
     eng.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter
     ph_merged = None
     if use_dist:
-        # the path's one exchange step: reduce-scatter of the sketches, per-rank value histograms of the summed slices,
-        # histograms to rank 0 (what compEst consumes) — see parallel.merge_to_value_histograms
+        # the path's one exchange step: all-to-all of the 16-bit counter slices, wrapping local sums, per-rank value
+        # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms
         def value_hist(counters, hist):
             nt.value_hist_device(counters.data_ptr(), counters.numel(), hist.data_ptr(), device=local_rank, stream=stream)
         ph_merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0)

@@ -1,6 +1,7 @@
 """Multi-GPU plumbing for the one exchange step the path has: reads are sharded by
-index range, every rank owns a private full sketch, and the per-rank sketches are merged with ONE
-integer SUM reduce (RCCL over xGMI when the tensors live on GPUs; gloo in the CPU tests).
+index range, every rank owns a private full sketch, and the per-rank sketches are merged once at the end
+(RCCL over xGMI when the tensors live on GPUs; gloo in the CPU tests): an all-to-all of 16-bit counter slices +
+local wrapping sums for the estimator (merge_to_value_histograms), or a plain uint32 SUM reduce (reduce_sketch).
 
 The reference's analogue is the shared t_Counter all OpenMP threads increment atomically
 (ntcard.cpp:142-143,445) and the atomic F1 merge (ntcard.cpp:464-466): both are commutative sums,
@@ -35,13 +36,44 @@ def reduce_sketch(sketch, f1, dst=0):
     return sketch, f1
 
 
+def exchange_and_sum_u16(sketch, shard):
+    """Slice `rank` of the SUM over ranks of the counters modulo 2^16, as an int32 tensor of values 0..65535.
+
+    t_Counter is uint16 with wrap-around (ntcard.cpp:142-143,439), so only the low 16 bits of every per-rank counter
+    matter for the merged sketch: (sum_r c_r) mod 2^16 == (sum_r (c_r mod 2^16)) mod 2^16.  Every rank therefore narrows
+    its counters to 16 bits, sends slice j to rank j (ONE all-to-all: 512 MiB·(N-1)/N per rank and k instead of the 1 GiB
+    a uint32 reduce-scatter moves, and every one of a rank's point-to-point xGMI links carries exactly one slice at the
+    same time, where a ring reduce-scatter makes N-1 dependent hops) and adds up the N slices it received with a
+    wrapping 16-bit add.  RCCL has no 16-bit integer SUM; none is needed.  gloo has no all-to-all for this either: the CPU
+    tests run the same exchange as batched isend/irecv."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    low = sketch.to(torch.int16)  # int32 -> int16 keeps the low 16 bits (two's complement)
+    recv = torch.empty(world * shard, dtype=torch.int16, device=sketch.device)
+    if dist.get_backend() == "gloo":
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                recv[rank * shard:(rank + 1) * shard] = low[rank * shard:(rank + 1) * shard]
+            else:
+                ops.append(dist.P2POp(dist.isend, low[peer * shard:(peer + 1) * shard].contiguous(), peer))
+                ops.append(dist.P2POp(dist.irecv, recv[peer * shard:(peer + 1) * shard], peer))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+    else:
+        dist.all_to_all_single(recv.view(torch.uint8), low.view(torch.uint8))  # bytes: RCCL has no 16-bit integer type, and none is needed to move them
+    parts = recv.view(world, shard)
+    acc = parts[0].clone()
+    for r in range(1, world):
+        acc += parts[r]  # int16 addition wraps: exactly the uint16 counter arithmetic
+    return acc.to(torch.int32) & 0xFFFF
+
+
 def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0):
     """Multi-GPU merge for the estimator (compEst only needs the value histogram p[2][65536] of the SUMMED counters,
-    ntcard.cpp:240-247): reduce-scatter the per-rank sketches so that every rank holds one slice of the sum, histogram
-    that slice locally, and send only the histograms (256 KiB per plane) to rank `dst`.  On a fully connected xGMI node a
-    reduce-scatter keeps every link busy, whereas a reduce to one rank funnels 1 GiB per k into it.
+    ntcard.cpp:240-247): every rank ends up with one slice of the summed uint16 counters (exchange_and_sum_u16),
+    histograms that slice locally, and only the histograms (256 KiB per plane) and F1 go to rank `dst`.
 
-    sketch: int32 tensor [n_k * 2 * 2^r_bits] (uint32 counters), f1: int64 [n_k]; both are consumed.
+    sketch: int32 tensor [n_k * 2 * 2^r_bits] (uint32 counters), f1: int64 [n_k]; f1 is reduced in place.
     value_hist(counters_slice, hist_slice): accumulates the histogram of (counter & 0xffff) into an int32[65536] view.
     Returns (p_hist int32 [n_k, 2, 65536], f1) — meaningful on rank dst."""
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -49,12 +81,7 @@ def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0):
     n = sketch.numel()
     assert n == n_k * 2 * plane and n % world == 0 and (n // world) % 4 == 0
     shard = n // world
-    if dist.get_backend() == "gloo":  # gloo has no reduce_scatter: same result through an all-reduce (CPU tests only)
-        dist.all_reduce(sketch, op=dist.ReduceOp.SUM)
-        mine = sketch[rank * shard:(rank + 1) * shard]
-    else:
-        mine = torch.empty(shard, dtype=sketch.dtype, device=sketch.device)
-        dist.reduce_scatter_tensor(mine, sketch, op=dist.ReduceOp.SUM)
+    mine = exchange_and_sum_u16(sketch, shard)
     hist = torch.zeros(n_k * 2 * 65536, dtype=torch.int32, device=sketch.device)
     pos, end = rank * shard, (rank + 1) * shard
     while pos < end:  # a slice may cover several (k, sample) planes, or a fraction of one

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -93,6 +94,7 @@ def _hist_worker(rank, world, port, out_dir):
     counters, f1 = orc.sketch_reads(reads, klist, 0, RB, SB)
     sk = torch.from_numpy(counters.astype(np.int64).reshape(-1)).to(torch.int32)
     sk[5] += 50000  # the merged counter wraps past 65535
+    sk[9] += 70000 + rank  # a per-rank uint32 counter that is itself past 65535 (only its low 16 bits may count)
 
     def value_hist(c, h):
         h += torch.bincount((c & 0xFFFF).to(torch.int64), minlength=65536).to(torch.int32)
@@ -104,15 +106,17 @@ def _hist_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_value_histogram_merge(tmp_path):
-    """reduce-scatter + per-rank histograms of the summed slices == histogram of the single-process sketch"""
-    world, klist = 2, [21, 40]
+@pytest.mark.parametrize("world", [2, 4])
+def test_value_histogram_merge(tmp_path, world):
+    """16-bit slice exchange + wrapping local sums + per-rank histograms == histogram of the single-process sketch"""
+    klist = [21, 40]
     mp.spawn(_hist_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     slots = orc.gen_reads(3, 0, N, L, L + 4, 1, genome_len=20_000)
     reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(N)]
     oc, of1 = orc.sketch_reads(reads, klist, 0, RB, SB)
     oc = oc.astype(np.int64)
-    oc[0, 0, 5] = (oc[0, 0, 5] + 100000) & 0xFFFF
+    oc[0, 0, 5] = (oc[0, 0, 5] + world * 50000) & 0xFFFF
+    oc[0, 0, 9] = (oc[0, 0, 9] + world * 70000 + world * (world - 1) // 2) & 0xFFFF
     ph = np.load(tmp_path / "ph.npy")
     for ki in range(len(klist)):
         assert np.array_equal(ph[ki].astype(np.uint32), orc.value_hist(oc[ki].astype(np.uint16), RB))
