@@ -516,7 +516,7 @@ def test_value_hist_device_matches_numpy(nt):
 
 
 def test_bench_under_torchrun_single_rank(tmp_path):
-    """the multi-GPU code path of bench.py (RCCL init, reduce-scatter merge, histogram reduce) with one rank"""
+    """the multi-GPU code path of bench.py (RCCL init, all-to-all slice exchange, histogram reduce) with one rank"""
     import json
     import subprocess
     import sys
