@@ -68,6 +68,8 @@ typedef struct {
                                       equal-length k = 32 batches (exact, but not yet faster than K1) */
 #define NTC_FLAG_ALWAYS_LOG 8u      /* keep logging whatever the data looks like (by default the engine switches to direct
                                       atomics when an apply finds few distinct counters per increment: repeats)       */
+#define NTC_FLAG_PARTITION_ALWAYS 16u /* validation: apply even a small hit log through the partition + histogram passes
+                                         (by default fewer than 4 M pending entries are applied with plain atomics)   */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 

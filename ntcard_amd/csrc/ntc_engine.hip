@@ -247,6 +247,7 @@ struct ntc_engine {
 	// log or direct atomics: decided ON THE DEVICE from a sample of what the first sizeable batch after a reset logged
 	// (repeated keys -> the counters stay cached -> direct atomics are cheaper; ntc_apply.hip, log_probe_kernel)
 	uint32_t* d_logmode = nullptr;          // 0 = log, 1 = direct atomics
+	bool partition_always = false;          // NTC_FLAG_PARTITION_ALWAYS
 	unsigned long long* d_logstats = nullptr; // {keys sampled, repeats among them}
 	uint32_t* d_probe = nullptr;            // 2^20-slot hash table of the probe
 	bool adaptive = true, probed = false;
@@ -374,7 +375,8 @@ int apply_log(ntc_engine* e)
 		HIP_TRY(hipEventRecord(ev0, e->stream));
 	}
 	// little in the log (decided on the device: fewer than 4 M entries): plain atomics, and the passes below find it empty
-	HIP_TRY(ntc::launch_log_atomics(e->d_log, e->d_logfill, e->log_region_cap, e->log_regions, (uint32_t*)(e->d_logstats + 2), e->d_sketch, e->stream));
+	if (!e->partition_always)
+		HIP_TRY(ntc::launch_log_atomics(e->d_log, e->d_logfill, e->log_region_cap, e->log_regions, (uint32_t*)(e->d_logstats + 2), e->d_sketch, e->stream));
 	ntc::CountArgs c;
 	std::memset(&c, 0, sizeof c);
 	c.slice_bits = ap.slice_bits;
@@ -760,6 +762,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		}
 	}
 	e->adaptive = !(cfg->flags & NTC_FLAG_ALWAYS_LOG);
+	e->partition_always = (cfg->flags & NTC_FLAG_PARTITION_ALWAYS) != 0;
 	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_DIRECT_ATOMICS) && plan_log(e, cfg->log_entries)) {
 		if (hipMalloc((void**)&e->d_log, e->log_cap * 4) != hipSuccess || hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) != hipSuccess ||
 		    hipMalloc((void**)&e->d_logmode, 4) != hipSuccess || hipMalloc((void**)&e->d_logstats, 24) != hipSuccess || hipMalloc((void**)&e->d_probe, 4u << 20) != hipSuccess) {

@@ -16,6 +16,7 @@ from ._abi import NtcConfig, NtcError, check
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
 FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: experimental bit-sliced kernel K1b for equal-length k = 32 batches
 FLAG_ALWAYS_LOG = 8  # NTC_FLAG_ALWAYS_LOG: never switch from the hit log to direct atomics
+FLAG_PARTITION_ALWAYS = 16  # NTC_FLAG_PARTITION_ALWAYS: small logs go through the partition passes too (validation)
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 

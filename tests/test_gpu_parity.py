@@ -213,7 +213,8 @@ def test_hit_log_geometries_match_direct_atomics(nt, r_bits, klist, log_entries)
     d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
     nt.gen_reads_device(d.data_ptr(), 77, 0, n, L, stride, 1, genome_len=200_000)
     res = []
-    for flags, le in ((nt.FLAG_DIRECT_ATOMICS, 0), (nt.FLAG_ALWAYS_LOG, log_entries), (0, log_entries)):
+    for flags, le in ((nt.FLAG_DIRECT_ATOMICS, 0), (nt.FLAG_ALWAYS_LOG, log_entries), (0, log_entries),
+                      (nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, log_entries)):  # the last one runs A1/A2/A3 on these small logs
         with nt.Engine(klist, r_bits=r_bits, s_bits=5, flags=flags, log_entries=le) as e:
             e.submit_device(d.data_ptr(), 20_032, L, stride)
             e.submit_device(d.data_ptr() + 20_032 * stride, n - 20_032, L, stride)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/fuzz_parity.py [n_cases] [seed] — randomised parity sweep: engine vs oracle on random shapes
-(read length / raggedness / dirt / k list / gap / sBits / rBits / submit pattern).  Prints the first mismatch and exits 1."""
+(read length / raggedness / dirt / k list / gap / sBits / rBits / submit pattern / sketch-update mode and log size).  Prints the first mismatch and exits 1."""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -42,14 +42,17 @@ for case in range(n_cases):
     else: lens = [rng.choice([L, 1000, 5000, 70000]) for _ in range(max(3, n // 50))]
     reads = [rseq(l, pn, 0.1) for l in lens]
     cuts = sorted(rng.sample(range(len(reads) + 1), min(len(reads) + 1, rng.choice([0, 1, 3]))))
-    with nt.Engine(klist, gap=gap, r_bits=r_bits, s_bits=s_bits) as e:
+    flags, log_entries = rng.choice([(0, 0), (nt.FLAG_ALWAYS_LOG, 0), (nt.FLAG_DIRECT_ATOMICS, 0),
+                                     (nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, 0),
+                                     (nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, 1 << rng.choice([14, 16, 18]))])
+    with nt.Engine(klist, gap=gap, r_bits=r_bits, s_bits=s_bits, flags=flags, log_entries=log_entries) as e:
         prev = 0
         for c in cuts + [len(reads)]:
             e.submit_reads(reads[prev:c]); prev = c
         tc, ph, f1 = e.finish(counters=True)
     oc, of1 = orc.sketch_reads(reads, klist, gap, r_bits, s_bits)
     ok = np.array_equal(f1, of1) and np.array_equal(tc, oc)
-    desc = "case %d: klist=%s gap=%d s=%d r=%d mode=%s L=%d n=%d pn=%g cuts=%s" % (case, klist, gap, s_bits, r_bits, mode, L, len(reads), pn, cuts)
+    desc = "case %d: klist=%s gap=%d s=%d r=%d mode=%s L=%d n=%d pn=%g cuts=%s flags=%d log=%d" % (case, klist, gap, s_bits, r_bits, mode, L, len(reads), pn, cuts, flags, log_entries)
     if not ok:
         print("MISMATCH", desc, "f1", list(f1), list(of1), "diff counters", int(np.count_nonzero(tc != oc)))
         sys.exit(1)
