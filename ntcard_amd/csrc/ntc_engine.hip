@@ -491,26 +491,30 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		return 0;
 	}
 	if (kind == KIND_HF) {
+		// upper estimate of the sampled k-mers per slot (both samples ~2^-sBits of the windows each, App. B of SURVEY.md)
+		double per_slot = 0.0;
+		for (uint32_t k : e->klist)
+			per_slot += (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
 		// The first sizeable equal-length batch after a reset is cut in two: a small head goes first, the probe samples what
 		// it logged and decides log vs direct atomics on the device, and the bulk of the batch already runs in that mode.
-		constexpr uint64_t kProbeHead = 2048ull * 320ull;
-		if (e->d_log && e->adaptive && !e->probed && d_meta == nullptr && n_slots >= 4 * kProbeHead) {
-			if (int rc = run_batch(e, d_slots, nullptr, kProbeHead, read_len, stride)) return rc;
-			return run_batch(e, d_slots + kProbeHead * stride, nullptr, n_slots - kProbeHead, read_len, stride);
+		// The head is sized to log the ~2^20 entries the probe wants (0.6 M slots at sBits = 7, k = 32); a batch that is
+		// not several heads long (large sBits, small batches) is not cut: the probe then runs once enough has been logged.
+		constexpr double kProbeEntries = 1.25 * (1 << 20);
+		if (e->d_log && e->adaptive && !e->probed && d_meta == nullptr && per_slot > 0.0) {
+			const uint64_t head = (((uint64_t)(kProbeEntries / per_slot) + 2047) / 2048) * 2048;
+			if (e->log_est < (double)(1u << 20) && n_slots >= 4 * head) {
+				if (int rc = run_batch(e, d_slots, nullptr, head, read_len, stride)) return rc;
+				return run_batch(e, d_slots + head * stride, nullptr, n_slots - head, read_len, stride);
+			}
 		}
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
-		double batch_est = 0.0;
 		if (e->d_log) {
-			// upper estimate of the sampled k-mers of this batch (both samples ~2^-sBits of the windows each, App. B of
-			// SURVEY.md) + what every wave may leave unused at the end of a region; apply first if the log could fill up
-			double est = 64.0 * 4096;
-			for (uint32_t k : e->klist)
-				est += (double)n_slots * (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+			// this batch's sampled k-mers + what every wave may leave unused at the end of a region; apply first if the log could fill up
+			const double est = 64.0 * 4096 + (double)n_slots * per_slot;
 			if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
 				if (int rc = apply_log(e)) return rc;
 			e->log_est += est;
 			e->log_pending = true;
-			batch_est = est;
 		}
 		if (e->profiling) { // the hash kernels of this batch only: an apply has its own pair of events
 			HIP_TRY(hipEventCreate(&ev0));
@@ -637,7 +641,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
 		}
-		if (e->d_log && e->adaptive && !e->probed && batch_est >= (double)(1u << 20)) { // first sizeable batch: sample its log, decide log vs atomics
+		if (e->d_log && e->adaptive && !e->probed && e->log_est >= (double)(1u << 20)) { // enough logged since the reset: sample the log, decide log vs atomics
 			e->probed = true;
 			HIP_TRY(ntc::launch_log_probe(e->d_log, e->d_logfill, e->log_region_cap, std::min<uint32_t>(e->log_regions, 1024), 256, e->d_probe, 1u << 20,
 			                              e->d_logstats, e->d_logmode, e->stream));
