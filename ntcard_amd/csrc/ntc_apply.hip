@@ -9,10 +9,13 @@
 //
 //   A1/A2  split_kernel   radix partition of the log by the top bits of the key (one or two passes, <= 256 ways
 //                         each; per-workgroup private output runs, so no global cursor atomics).  Per round a
-//                         workgroup sorts 4096 keys by digit in LDS: ONE returning ds_add per key yields the digit
+//                         workgroup sorts 8192 keys by digit in LDS: ONE returning ds_add per key yields the digit
 //                         count and the key's rank, the next round's keys are already in flight, and the sorted
-//                         tile leaves as ~128-byte segments.  Round 2 history: two LDS atomics per key + no prefetch
-//                         0.85 + 0.65 ms per 92 M keys; this form 0.51 + 0.36 ms.
+//                         tile leaves as ~256-byte segments.  One 1024-thread workgroup per CU: the number of open
+//                         runs (workgroups x digits x one 128-byte line) has to stay inside L2 for the run tails to
+//                         be written once, so parallelism comes from the workgroup size, not from their number.
+//                         Round 2 history per 92 M keys: two LDS atomics per key, 256 threads x 1024 workgroups
+//                         0.85 + 0.65 ms; one returning atomic + prefetch, 256 x 512: 0.51 + 0.36 ms; this form ~0.6 ms.
 //   A3     count_kernel   one workgroup per slice of 2^15 counters: histogram of the slice's keys in LDS
 //                         (ds_add on 16-bit fields, single writer per slice), then one coalesced `sketch[i] += n` sweep.
 //
@@ -27,9 +30,9 @@ namespace ntc {
 
 namespace {
 
-constexpr uint32_t kSplitThreads = 256;
-constexpr uint32_t kSplitKeys = 16;                             // keys per thread and round
-constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;      // 4096 keys per workgroup round: runs of ~32 keys (128 B) per digit at 128 ways
+constexpr uint32_t kSplitThreads = 1024;
+constexpr uint32_t kSplitKeys = 8;                              // keys per thread and round
+constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;      // 8192 keys per workgroup round: runs of ~64 keys (256 B) per digit at 128 ways
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {

@@ -342,11 +342,11 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	e->log_cap = (uint64_t)e->log_regions * e->log_region_cap;
 	// pass 1: g1 workgroups, each owns every g1-th region and writes 2^b1 private runs; a run holds its expected
 	// share of a FULL log + 25 % (+64); what does not fit is applied directly (exact), so the margin is about speed only
-	ap.g1 = std::min<uint32_t>(e->log_regions, 512); // two workgroups per CU: long private runs matter more than occupancy (measured 256 … 4096)
+	ap.g1 = std::min<uint32_t>(e->log_regions, 256); // one 1024-thread workgroup per CU: few, long private runs (measured 128 … 4096)
 	const uint64_t share1 = (uint64_t)((e->log_regions + ap.g1 - 1) / ap.g1) * e->log_region_cap;
 	ap.cap1 = (uint32_t)((share1 >> ap.b1) * 5 / 4 + 64);
 	// pass 2: bucket b of pass 1 is split again by `parts2` workgroups
-	ap.parts2 = 8;
+	ap.parts2 = 4;
 	const uint64_t share2 = ((e->log_cap >> ap.b1) * 5 / 4) / ap.parts2 + 1;
 	ap.cap2 = (uint32_t)((share2 >> ap.b2) * 13 / 10 + 64);
 	return true;
