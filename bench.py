@@ -49,6 +49,8 @@ def parse():
                     help="BASELINE.json config: 2 (default) 100 M reads k=32 sBits=7; 3: 1 B reads in total, sBits=11, read-index ranges split "
                          "over the ranks (strong scaling); 4: k=32,64,96,128 in one run; 5: spaced seed k=12 g=2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run this command under rocprofv3 --pmc for roofline.traffic / valu "
+                                                               "(the committed table profiles/traffic_pmc.json is looked up instead)")
     ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
     ap.add_argument("--bitslice", action="store_true", help="use the experimental bit-sliced kernel K1b (k = 32, equal-length reads)")
@@ -103,6 +105,52 @@ def cpu_baseline(args, nt_stride):
             "sample": f"{chunks} x {n} reads x {args.read_len} bp (same generator, dist={args.dist}), k={kl}, gap={args.gap}, "
                       f"oracle port of ntRead+ntComp (per-k tables, one thread per shard; 1.40 x the reference's per-thread speed in "
                       f"the build container), {dt:.2f} s timed"}
+
+
+def under_profiler():
+    """true when this process is itself being profiled (rocprofv3 preloads its tool library): no nested profiler runs"""
+    return any("rocprof" in k.lower() or "rocprof" in v.lower() for k, v in os.environ.items() if k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")
+               or k.startswith("ROCPROF"))
+
+
+def live_pmc(argv_inner, n_steps):
+    """HBM traffic and VALU instruction counts of the hash kernels, measured NOW: this same command is re-run under
+    `rocprofv3 --pmc <counter>` once per counter (separate passes, as MI355X_MICROARCH.md prescribes for FETCH_SIZE /
+    WRITE_SIZE; no tracing domains), the counter is summed over every dispatch of the hash kernels and divided by the
+    number of bench steps the command ran.  Returns {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "SQ_INSTS_VALU": n} per step,
+    or None when rocprofv3 is missing or a pass fails (the committed table is the fallback then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.access(rp, os.X_OK):
+        return None
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        d = tempfile.mkdtemp(prefix="ntc_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv_inner,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            tot, seen = 0.0, 0
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == ctr and ("sketch_hf_kernel" in row["Kernel_Name"] or "sketch_bs_kernel" in row["Kernel_Name"]):
+                            tot += float(row["Counter_Value"])
+                            seen += 1
+            if seen == 0:
+                return None
+            res[ctr] = tot / n_steps
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return res
 
 
 def traffic_key(args, reads_per_launch):
@@ -272,7 +320,7 @@ def main():
             "config": {"workload": f"{world}x{reads_per_rank} synthetic {L} bp reads (dist={args.dist}, seed={args.seed}), "
                                    f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
                                    f"{K} steps x {R} reads per GPU" + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
-                                   + (", RCCL reduce-scatter of the sketches + value histograms to rank 0 inside the timed region" if world > 1 else ""),
+                                   + (", RCCL all-to-all of 16-bit counter slices + value histograms to rank 0 inside the timed region" if world > 1 else ""),
                        "traffic_key": traffic_key(args, R), "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
                        "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -291,6 +339,23 @@ def main():
             "f1_total": total_kmers,
             "sampled_increments": hits,
         }
+        # roofline.traffic / valu: measured live (this command again under rocprofv3 --pmc, one counter per pass) at N = 1;
+        # the committed table of the same passes (profiles/traffic_pmc.json, tools/prof.sh) is the fallback
+        out["roofline"]["traffic_source"] = "profiles/traffic_pmc.json" if out["roofline"]["traffic"] is not None else None
+        if world == 1 and not use_dist and not args.no_live_pmc and not under_profiler():
+            eng.close()
+            del batches, wb
+            torch.cuda.empty_cache()
+            inner = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline", "--no-live-pmc")] + ["--no-cpu-baseline", "--no-live-pmc"]
+            live = live_pmc(inner, K + W)
+            if live is not None:
+                # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KB; wide streaming reads are
+                # under-counted by half on gfx950 -> traffic = 2 * FETCH_SIZE + WRITE_SIZE (an upper bound: applied to all of FETCH)
+                out["roofline"]["traffic"] = int((2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
+                out["roofline"]["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"
+                v = live["SQ_INSTS_VALU"]
+                out["valu"].update({"wave_insts_per_launch": v, "per_wave_step": v / (R * L / 64.0),
+                                    "wave_insts_per_s": (v / (avg_ms * 1e-3)) if avg_ms > 0 else None, "source": "live: rocprofv3 --pmc SQ_INSTS_VALU"})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, stride)

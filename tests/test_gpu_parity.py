@@ -542,12 +542,12 @@ def test_bench_under_torchrun_single_rank(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--reads-per-step", "1000000", "--no-cpu-baseline"]
+           "--reads-per-step", "1000000", "--no-cpu-baseline", "--no-live-pmc"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.decode().strip().splitlines()[-1])
     ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--reads-per-step", "1000000",
-                          "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+                          "--no-cpu-baseline", "--no-live-pmc"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
     k = json.loads(ref.stdout.decode().strip().splitlines()[-1])
     assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"] and j["n_gpus"] == 1
 

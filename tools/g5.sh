@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmc_ic -o p -- python $R/bench.py --steps 4 --warmup 1 --reads-per-step 4000000 --no-cpu-baseline --dist u > $R/gpurun_out/pmc_ic.log 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmc_ic -o p -- python $R/bench.py --steps 4 --warmup 1 --reads-per-step 4000000 --no-cpu-baseline --no-live-pmc --dist u > $R/gpurun_out/pmc_ic.log 2>&1
 python - <<PY
 import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # PROF_DEFAULT=1: profile exactly the default bench command (what BENCH_rNN.json is measured with)
-if [ "${PROF_DEFAULT:-0}" = 1 ]; then ARGS="--no-cpu-baseline $*"; else ARGS="--steps 4 --warmup 1 --reads-per-step 4000000 --no-cpu-baseline $*"; fi
+if [ "${PROF_DEFAULT:-0}" = 1 ]; then ARGS="--no-cpu-baseline --no-live-pmc $*"; else ARGS="--steps 4 --warmup 1 --reads-per-step 4000000 --no-cpu-baseline --no-live-pmc $*"; fi
 python $ROOT/bench.py $ARGS 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
