@@ -110,7 +110,7 @@ __device__ __forceinline__ void pin31(uint32_t (&X)[31])
 constexpr int kTileReads = 2048;
 constexpr int kGroupLoads = 10;  // loads per staging group
 constexpr int kGroups = 8;       // 80 loads of 1 KiB per helper and tile: strides up to 160 B
-constexpr uint32_t kQueueCap = 1024; // sampled (read, window) pairs a helper can hold in LDS
+constexpr uint32_t kQueueCap = 1088; // queue items per walker: 63 left over from the previous block + 16 steps x 64 lanes
 
 // inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS round trip)
 __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
@@ -141,15 +141,14 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 	const uint32_t tile_dw = 128u * stride; // packed dwords per tile (one per 16 raw bytes)
 	const uint32_t qd = 32u * stride;       // chunks (= packed dwords) per helper quarter
 	const uint32_t cbm_words = tile_dw >> 5;
-	// LDS: [packed tile + 64 dwords][closed-form table][2 chunk-dirty bitmaps][read-dirty bitmap][4 hit buffers][4 queues]
+	// LDS: [packed tile + 64 dwords][closed-form table][2 chunk-dirty bitmaps][read-dirty bitmap][4 item queues]
 	uint32_t* const tile = reinterpret_cast<uint32_t*>(smem);
 	unsigned char* const t4 = smem + (size_t)(tile_dw + 64u) * 4u;
 	const uint32_t t4_bytes = (uint32_t)(K / 4) * 4096u;
 	uint32_t* const cbm0 = reinterpret_cast<uint32_t*>(t4 + t4_bytes);
 	uint32_t* const cbm1 = cbm0 + cbm_words;
 	uint32_t* const rdirty = cbm1 + cbm_words; // 64 words
-	uint32_t* const hitbuf = rdirty + 64 + part * (17u * 64u); // 16 steps + the first window, x 64 lanes
-	uint32_t* const queue = rdirty + 64 + 4u * (17u * 64u) + part * kQueueCap;
+	uint2* const queue = reinterpret_cast<uint2*>(rdirty + 64) + part * (kQueueCap + 1u); // 8-byte aligned: every size before it is a multiple of 8; + 1 spare slot
 	{
 		const uint4* src = reinterpret_cast<const uint4*>(a.t4);
 		for (uint32_t i = tid; i < t4_bytes / 16u; i += 512u)
@@ -316,9 +315,11 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 		}
 	};
 	// ---- resolve: 64 (read, window) pairs -> full canonical hash from the packed bases -> ntComp -> log ----
-	auto resolve_round = [&](uint32_t e, uint32_t count) {
+	auto resolve_round = [&](uint32_t mask, uint32_t lw, uint32_t count) {
+		// item = (hit plane word of one lane and step, that lane << 8 | window): this round takes the lowest set bit (read
+		// 64 bit + lane); the queue loop puts what is left of the word back in line
 		const bool act = (uint32_t)lane < count;
-		const uint32_t r = act ? e >> 8 : 0u, win = act ? e & 0xffu : 0u;
+		const uint32_t r = act ? (uint32_t)__builtin_ctz(mask | 0x80000000u) * 64u + (lw >> 8) : 0u, win = act ? lw & 0xffu : 0u;
 		const uint32_t B = r * stride + win;          // tile byte offset of the window's first base
 		const uint32_t sh = (B & 15u) * 2u;           // bit offset inside the packed dword
 		const uint32_t* dp = tile + (B >> 4);
@@ -363,47 +364,39 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 		else if (hit)
 			atomicAdd(a.sketch0 + key, 1u);
 	};
-	// ---- LDS queue of sampled (read, window) pairs: [qhead, qhead + qfill) mod kQueueCap ----
-	uint32_t qhead = 0, qfill = 0;
-	auto drain_queue = [&](uint32_t keep) { // resolve until at most `keep` pairs are left (keep < 64: the last round is partial)
+	// ---- LDS queue of hit-plane items: [qhead, qhead + qfill) mod kQueueCap.  A step hands its hit plane over with ONE
+	// ballot-compacted 8-byte store per lane that saw a hit (no per-bit loop, no prefix sum over counts); the bits of a
+	// word are taken one per resolve round ----
+	uint32_t qhead = 0, qfill = 0; // wave-uniform
+	const uint32_t lane8 = (uint32_t)lane << 8;
+	auto qslot = [&](uint32_t x) { return x >= kQueueCap ? x - kQueueCap : x; }; // x < 2 kQueueCap
+	auto drain_queue = [&](uint32_t keep) { // resolve until at most `keep` items are left (keep < 64: the last round is partial)
 		while (qfill > keep) {
 			const uint32_t n = qfill < 64u ? qfill : 64u;
-			const uint32_t e = queue[(qhead + (uint32_t)lane) & (kQueueCap - 1u)];
-			resolve_round(e, n);
-			qhead = (qhead + n) & (kQueueCap - 1u);
-			qfill -= n;
+			const uint2 it = queue[qslot(qhead + (uint32_t)lane)];
+			const bool act = (uint32_t)lane < n;
+			const uint32_t rest = act ? it.x & (it.x - 1u) : 0u;
+			const uint64_t m = ballot(rest != 0u);
+			// words with more bits go to the back of the line first (the slots this round frees are not reused before it ends:
+			// the tail never catches up with the head because every round frees n and re-queues at most n)
+			if (m != 0) {
+				const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				if (rest != 0u) queue[qslot(qslot(qhead + qfill) + pos)] = make_uint2(rest, it.y);
+			}
+			resolve_round(it.x, it.y, n);
+			qhead = (uint32_t)__builtin_amdgcn_readfirstlane((int)qslot(qhead + n));
+			qfill = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qfill - n + (uint32_t)__popcll(m)));
 		}
 	};
-	auto append = [&](uint32_t cur, uint32_t win) { // cur: bit i set <=> read 64 i + lane sampled at window `win`
-		if (ballot(cur != 0u) == 0) return;
-		const uint32_t cnt = (uint32_t)__popc(cur);
-		const uint32_t incl = wave_scan(cnt);
-		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		if (total <= kQueueCap - 64u) {
-			if (qfill + total > kQueueCap) drain_queue(63u);
-			uint32_t pos = qhead + qfill + incl - cnt;
-			while (cur != 0u) {
-				const uint32_t bit = (uint32_t)__builtin_ctz(cur);
-				cur &= cur - 1u;
-				queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
-			}
-			qfill += total;
-			return;
-		}
-		for (uint32_t sl = 0; sl < 4u; ++sl) { // more sampled reads than the queue holds: a byte slice adds at most 512 pairs
-			uint32_t bits = cur & (0xffu << (8u * sl));
-			const uint32_t c8 = (uint32_t)__popc(bits);
-			const uint32_t in8 = wave_scan(c8);
-			const uint32_t tot8 = (uint32_t)__builtin_amdgcn_readlane((int)in8, 63);
-			if (qfill + tot8 > kQueueCap) drain_queue(63u);
-			uint32_t pos = qhead + qfill + in8 - c8;
-			while (bits != 0u) {
-				const uint32_t bit = (uint32_t)__builtin_ctz(bits);
-				bits &= bits - 1u;
-				queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
-			}
-			qfill += tot8;
-		}
+	auto push = [&](uint32_t h, uint32_t win, bool valid) { // h: bit i set <=> read 64 i + lane sampled at window `win`; valid: wave-uniform
+		// straight-line on purpose (a branch inside the 16-step block costs the register allocator its plan, measured 148
+		// spilled VGPRs): lanes without a hit store to the spare slot behind the queue; room is guaranteed by the caller
+		h = valid ? h : 0u;
+		const uint64_t m = ballot(h != 0u);
+		const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+		const uint32_t slot = qslot(qslot(qhead + qfill) + pos);
+		queue[h != 0u ? slot : kQueueCap] = make_uint2(h, lane8 | win);
+		qfill = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qfill + (uint32_t)__popcll(m)));
 	};
 	const uint32_t abase = (uint32_t)lane * s4; // packed BYTE offset of read `lane`; reads 64 i + lane follow every 16 * s4 dwords
 	auto fetch_planes = [&](uint32_t (&P)[32], uint32_t pos) { // planes of bases [pos, pos + 16) of the lane's 32 reads
@@ -461,7 +454,10 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 			BS_T(tf2);
 			BS_ACC(5, tf1, tf2);
 		}
-		hitbuf[16 * 64 + lane] = test(); // window sb itself: drained with the first block
+		{ // window sb itself
+			const uint32_t h0 = test();
+			push(h0, sb, Q != 0u && sb < W);
+		}
 		BS_T(tw2);
 		BS_ACC(1, tw1, tw2);
 #pragma unroll 1
@@ -472,7 +468,10 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 #pragma unroll
 			for (int q = 0; q < 16; ++q) {
 				if constexpr (K == 32) bs_step_main_k32(F, R, I[2 * q], I[2 * q + 1], H[0][2 * q], H[0][2 * q + 1]);
-				hitbuf[q * 64 + lane] = test();
+				{ // local window 16 bq + q + 1 (window Q belongs to the next walker); the condition is wave-uniform
+					const uint32_t hq = test(), lw = 16u * bq + (uint32_t)q + 1u;
+					push(hq, sb + lw, lw < Q && sb + lw < W);
+				}
 			}
 			// the chunk that just came in leaves the window KB blocks from now
 #pragma unroll
@@ -487,46 +486,7 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 			pin31(R);
 			BS_T(tw4);
 			BS_ACC(2, tw3, tw4);
-			// drain the block's sampled windows: slot 16 = window sb (first block only), slot q = local window 16 bq + q + 1
-			// (window Q belongs to the next walker).  ONE prefix sum per block places every lane's pairs in the queue.
-			{
-				uint32_t hp[17];
-#pragma unroll
-				for (int q = 0; q < 17; ++q)
-					hp[q] = hitbuf[q * 64 + lane];
-				__builtin_amdgcn_sched_barrier(0);
-				uint32_t cnt = 0;
-#pragma unroll
-				for (int q = 0; q < 17; ++q) {
-					const uint32_t lw = q == 16 ? 0u : 16u * bq + (uint32_t)q + 1u;
-					const bool valid = (q != 16 || bq == 0u) && lw < Q && sb + lw < W; // wave-uniform
-					hp[q] = valid ? hp[q] : 0u;
-					cnt += (uint32_t)__popc(hp[q]);
-				}
-				const uint32_t incl = wave_scan(cnt);
-				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-				if (total <= kQueueCap - 64u) {
-					if (qfill + total > kQueueCap) drain_queue(63u);
-					uint32_t pos = qhead + qfill + incl - cnt;
-#pragma unroll
-					for (int q = 0; q < 17; ++q) {
-						const uint32_t win = sb + (q == 16 ? 0u : 16u * bq + (uint32_t)q + 1u);
-						uint32_t bits = hp[q];
-						while (bits != 0u) {
-							const uint32_t bit = (uint32_t)__builtin_ctz(bits);
-							bits &= bits - 1u;
-							queue[pos++ & (kQueueCap - 1u)] = ((bit * 64u + (uint32_t)lane) << 8) | win;
-						}
-					}
-					qfill += total;
-				} else { // more sampled windows than the queue holds (repeats): plane by plane
-#pragma unroll 1
-					for (uint32_t q = 0; q < 17u; ++q) {
-						const uint32_t lw = q == 16u ? 0u : 16u * bq + q + 1u;
-						if ((q != 16u || bq == 0u) && lw < Q && sb + lw < W) append(hitbuf[q * 64u + (uint32_t)lane], sb + lw);
-					}
-				}
-			}
+			// at most 63 items stay queued: the next block adds at most 16 x 64
 			drain_queue(63u);
 			BS_T(tw5);
 			BS_ACC(3, tw4, tw5);
@@ -555,7 +515,7 @@ bool sketch_bs_supports(uint32_t k, uint32_t s_bits) { return k == 32 && s_bits 
 size_t sketch_bs_smem(uint32_t k, uint32_t stride)
 {
 	const size_t tile_dw = 128u * (size_t)stride;
-	return (tile_dw + 64) * 4 + (size_t)(k / 4) * 4096 + 2 * (tile_dw / 32) * 4 + 64 * 4 + 4 * 17 * 64 * 4 + 4 * 1024 * 4;
+	return (tile_dw + 64) * 4 + (size_t)(k / 4) * 4096 + 2 * (tile_dw / 32) * 4 + 64 * 4 + 4 * (size_t)(kQueueCap + 1) * 8;
 }
 
 hipError_t launch_sketch_bs(const BsArgs& a, unsigned grid, hipStream_t st)
