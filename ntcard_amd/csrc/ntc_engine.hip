@@ -523,6 +523,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		}
 		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
 		// a group whose closed-form tables would push the CU below 12 waves (and below what its members reach alone) is split in two
+		uint32_t gather_tail_first = 0, gather_tail_n = 0;
 		std::function<int(size_t, size_t, const unsigned char*, uint64_t, const uint32_t*, const uint32_t*)> launch_group =
 		    [&](size_t b, size_t n, const unsigned char* slots, uint64_t ns, const uint32_t* gather, const uint32_t* gather_count) -> int {
 			HfPlan hp;
@@ -556,6 +557,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.gapt = e->d_gapt;
 			a.gather = gather;
 			a.gather_count = gather_count;
+			a.gather_tail_first = gather ? gather_tail_first : 0u;
+			a.gather_tail_n = gather ? gather_tail_n : 0u;
 			if (e->gap) ntc::build_gap_roll_table(e->klist[b], a.gap_first, e->gap, a.tabg);
 			for (size_t j = 0; j < n; ++j)
 				a.ks[j] = e->hfk[b + j];
@@ -631,7 +634,11 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			ba.dbg = dbg;
 #endif
 			HIP_TRY(ntc::launch_sketch_bs(ba, (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)di.cus), e->stream));
+			// ONE K1 launch in gather mode takes the reads K1b handed back and the tail of the batch behind the whole tiles
+			gather_tail_first = (uint32_t)bs_slots;
+			gather_tail_n = (uint32_t)(n_slots - bs_slots);
 			if (int rc = launch_group(0, 1, d_slots, bs_slots, e->d_redo, redo_count)) return rc;
+			bs_slots = n_slots;
 		}
 		if (bs_slots < n_slots)
 			for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)

@@ -66,6 +66,7 @@ struct HfArgs {
 	uint32_t dump_win, pad3_;
 	const uint32_t* gather;     // != NULL: the batch is the listed slots, gather[i] = slot index, i < *gather_count
 	const uint32_t* gather_count; // (reads the bit-sliced kernel K1b handed back: a non-ACGTU byte somewhere in the read)
+	uint32_t gather_tail_first, gather_tail_n; // gather mode: slots [first, first + n) follow the listed ones (the batch's tail behind K1b's whole tiles)
 	const void* gapt;
 	const uint32_t* hll_thr;
 	uint32_t tabg[kMainSlots][2]; // spaced seed, rolling form: per (leaving, entering) base pair of the don't-care block
