@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 	uint32_t* const cbm0 = reinterpret_cast<uint32_t*>(t4 + t4_bytes);
 	uint32_t* const cbm1 = cbm0 + cbm_words;
 	uint32_t* const rdirty = cbm1 + cbm_words; // 64 words
-	uint2* const queue = reinterpret_cast<uint2*>(rdirty + 64) + part * (kQueueCap + 1u); // 8-byte aligned: every size before it is a multiple of 8; + 1 spare slot
+	uint2* const queue = reinterpret_cast<uint2*>(rdirty + 64) + part * (kQueueCap + 64u); // 8-byte aligned: every size before it is a multiple of 8; + 64 spare slots
 	{
 		const uint4* src = reinterpret_cast<const uint4*>(a.t4);
 		for (uint32_t i = tid; i < t4_bytes / 16u; i += 512u)
@@ -390,12 +390,12 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 	};
 	auto push = [&](uint32_t h, uint32_t win, bool valid) { // h: bit i set <=> read 64 i + lane sampled at window `win`; valid: wave-uniform
 		// straight-line on purpose (a branch inside the 16-step block costs the register allocator its plan, measured 148
-		// spilled VGPRs): lanes without a hit store to the spare slot behind the queue; room is guaranteed by the caller
+		// spilled VGPRs): lanes without a hit store to their spare slot behind the queue; room is guaranteed by the caller
 		h = valid ? h : 0u;
 		const uint64_t m = ballot(h != 0u);
 		const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 		const uint32_t slot = qslot(qslot(qhead + qfill) + pos);
-		queue[h != 0u ? slot : kQueueCap] = make_uint2(h, lane8 | win);
+		queue[h != 0u ? slot : kQueueCap + (uint32_t)lane] = make_uint2(h, lane8 | win); // a spare slot per lane: one shared slot is a 40-way bank conflict
 		qfill = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qfill + (uint32_t)__popcll(m)));
 	};
 	const uint32_t abase = (uint32_t)lane * s4; // packed BYTE offset of read `lane`; reads 64 i + lane follow every 16 * s4 dwords
@@ -515,7 +515,7 @@ bool sketch_bs_supports(uint32_t k, uint32_t s_bits) { return k == 32 && s_bits 
 size_t sketch_bs_smem(uint32_t k, uint32_t stride)
 {
 	const size_t tile_dw = 128u * (size_t)stride;
-	return (tile_dw + 64) * 4 + (size_t)(k / 4) * 4096 + 2 * (tile_dw / 32) * 4 + 64 * 4 + 4 * (size_t)(kQueueCap + 1) * 8;
+	return (tile_dw + 64) * 4 + (size_t)(k / 4) * 4096 + 2 * (tile_dw / 32) * 4 + 64 * 4 + 4 * (size_t)(kQueueCap + 64) * 8;
 }
 
 hipError_t launch_sketch_bs(const BsArgs& a, unsigned grid, hipStream_t st)
