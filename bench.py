@@ -53,7 +53,8 @@ def parse():
                                                                "(the committed table profiles/traffic_pmc.json is looked up instead)")
     ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
-    ap.add_argument("--bitslice", action="store_true", help="use the experimental bit-sliced kernel K1b (k = 32, equal-length reads)")
+    ap.add_argument("--bitslice", action="store_true", help="A/B: the bit-sliced kernel K1b even for small batches (it is the default for k = 32 batches of >= 128 tiles)")
+    ap.add_argument("--lane-kernel", action="store_true", help="A/B: never use K1b, the lane-per-read kernel K1 takes every batch")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
     return ap.parse_args()
@@ -156,7 +157,7 @@ def live_pmc(argv_inner, n_steps):
 def traffic_key(args, reads_per_launch):
     k = ",".join(map(str, klist_of(args)))
     return (f"dist={args.dist},L={args.read_len},k={k},gap={args.gap},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
-            + (",bitslice" if args.bitslice else "") + (",direct-atomics" if args.direct_atomics else "")
+            + (",bitslice" if args.bitslice else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
             + (",always-log" if args.always_log else ""))
 
 
@@ -243,7 +244,7 @@ def main():
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
     eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
-                    ext_sketch=sketch, ext_f1=f1_dev, flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
+                    ext_sketch=sketch, ext_f1=f1_dev, flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0) | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0)
                     | (nt.FLAG_ALWAYS_LOG if args.always_log else 0))
 
     def barrier():
@@ -325,7 +326,10 @@ def main():
                        "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),
-                         "kernel": "sketch_hf_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                         "kernel": ("sketch_bs_kernel (whole 2048-read tiles) + sketch_hf_kernel (handed-back reads and tail)"
+                                    if nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255
+                                    and (args.bitslice or (R >= 2048 * 128 and not args.lane_kernel and not args.direct_atomics)) else "sketch_hf_kernel"),
+                         "avg_launch_ms": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_launch_kmers},
             # deferred sketch update (ntc_apply.hip), HIP-event timed like the hash kernel; inside the timed region

@@ -248,6 +248,7 @@ struct ntc_engine {
 	// (repeated keys -> the counters stay cached -> direct atomics are cheaper; ntc_apply.hip, log_probe_kernel)
 	uint32_t* d_logmode = nullptr;          // 0 = log, 1 = direct atomics
 	bool partition_always = false;          // NTC_FLAG_PARTITION_ALWAYS
+	uint64_t bs_min_tiles = 128;            // K1b takes batches of at least this many 2048-read tiles
 	unsigned long long* d_logstats = nullptr; // {keys sampled, repeats among them}
 	uint32_t* d_probe = nullptr;            // 2^20-slot hash table of the probe
 	bool adaptive = true, probed = false;
@@ -500,7 +501,13 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		// The head is sized to log the ~2^20 entries the probe wants (0.6 M slots at sBits = 7, k = 32); a batch that is
 		// not several heads long (large sBits, small batches) is not cut: the probe then runs once enough has been logged.
 		constexpr double kProbeEntries = 1.25 * (1 << 20);
-		if (e->d_log && e->adaptive && !e->probed && d_meta == nullptr && per_slot > 0.0) {
+		const uint32_t k0 = e->klist[0];
+		// K1b pays when its four walkers are evenly loaded: 4 x 32 windows cover 112 .. 128 windows per read (143 .. 159 bp at
+		// k = 32; measured: 93 windows 0.95 T vs K1's 1.0 T, 119 windows 1.5 T vs 1.3 T); NTC_FLAG_BITSLICE_KERNEL lifts that
+		const uint32_t n_win = read_len >= k0 ? read_len - k0 + 1 : 0;
+		const bool use_bs = e->d_t4 && e->d_log && d_meta == nullptr && n_win >= (e->bs_min_tiles > 1 ? 112u : 1u) && n_win <= 255 && stride >= 128 && stride <= 160 &&
+		                    ntc::sketch_bs_smem(k0, stride) <= kMaxDynLds && n_slots >= 2048 * e->bs_min_tiles;
+		if (e->d_log && e->adaptive && !e->probed && !use_bs && d_meta == nullptr && per_slot > 0.0) {
 			const uint64_t head = (((uint64_t)(kProbeEntries / per_slot) + 2047) / 2048) * 2048;
 			if (e->log_est < (double)(1u << 20) && n_slots >= 4 * head) {
 				if (int rc = run_batch(e, d_slots, nullptr, head, read_len, stride)) return rc;
@@ -577,9 +584,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		// for this k; reads with a non-ACGTU byte come back on a device list and go through K1 in gather mode, and so
 		// does the tail of the batch.
 		uint64_t bs_slots = 0;
-		const uint32_t k0 = e->klist[0];
-		if (e->d_t4 && d_meta == nullptr && read_len >= k0 && stride >= 128 && stride <= 160 && read_len - k0 + 1 <= 255 &&
-		    ntc::sketch_bs_smem(k0, stride) <= kMaxDynLds && n_slots >= 2048) {
+		if (use_bs) {
 			const uint64_t n_tiles = n_slots / 2048;
 			bs_slots = n_tiles * 2048;
 			if (bs_slots > e->redo_cap) {
@@ -611,7 +616,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				ba.log_fill = e->d_logfill;
 				ba.log_regions = e->log_regions;
 				ba.log_region_cap = e->log_region_cap;
-				ba.log_mode = e->d_logmode;
+				ba.log_mode = nullptr; // K1b always logs
 			}
 			ba.sketch0 = e->d_sketch;
 			ba.f1 = e->d_f1;
@@ -648,7 +653,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
 		}
-		if (e->d_log && e->adaptive && !e->probed && e->log_est >= (double)(1u << 20)) { // enough logged since the reset: sample the log, decide log vs atomics
+		if (e->d_log && e->adaptive && !e->probed && !use_bs && e->log_est >= (double)(1u << 20)) { // enough logged since the reset: sample the log, decide log vs atomics
 			e->probed = true;
 			HIP_TRY(ntc::launch_log_probe(e->d_log, e->d_logfill, e->log_region_cap, std::min<uint32_t>(e->log_regions, 1024), 256, e->d_probe, 1u << 20,
 			                              e->d_logstats, e->d_logmode, e->stream));
@@ -781,7 +786,12 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log on device", (unsigned long long)e->log_cap);
 		}
 	}
-	if (e->kernel_kind == KIND_HF && (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) && e->klist.size() == 1 && e->gap == 0 &&
+	// K1b (bit-sliced filter walk) is instantiated for k = 32: such an engine gives it every large equal-length batch.  K1b
+	// always logs (a single walker wave per SIMD cannot hide the latency of direct atomics: 1.07 vs 0.61 ms); the batches K1
+	// takes (ragged, short or long slots, small) keep the adaptive choice
+	const bool bs_wanted = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) || (!(cfg->flags & (NTC_FLAG_LANE_KERNEL | NTC_FLAG_DIRECT_ATOMICS)) && e->d_log != nullptr);
+	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
+	if (e->kernel_kind == KIND_HF && bs_wanted && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
 	    ntc::sketch_bs_supports(e->klist[0], e->s_bits)) {
 		std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[0]) * 256 * 4);
 		ntc::build_t4(e->klist[0], t4.data());

@@ -14,7 +14,8 @@ from . import _abi
 from ._abi import NtcConfig, NtcError, check
 
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
-FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: experimental bit-sliced kernel K1b for equal-length k = 32 batches
+FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: K1b for every equal-length k = 32 batch, however small (default: batches of >= 128 tiles)
+FLAG_LANE_KERNEL = 32  # NTC_FLAG_LANE_KERNEL: never use the bit-sliced kernel K1b
 FLAG_ALWAYS_LOG = 8  # NTC_FLAG_ALWAYS_LOG: never switch from the hit log to direct atomics
 FLAG_PARTITION_ALWAYS = 16  # NTC_FLAG_PARTITION_ALWAYS: small logs go through the partition passes too (validation)
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer

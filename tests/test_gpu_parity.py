@@ -234,13 +234,14 @@ def test_hit_log_geometries_match_direct_atomics(nt, r_bits, klist, log_entries)
 
 @pytest.mark.parametrize("s_bits,dist,want_mode", [(7, 1, 1), (7, 0, 0), (11, 1, 1), (11, 0, 0), (9, 1, 1)])
 def test_adaptive_mode_probes_once(nt, s_bits, dist, want_mode):
-    """the update mode is decided ONCE per engine from a sample of the first ~2^20 logged entries: repeat-rich reads
-    (dist g) -> direct atomics, uniform reads -> hit log; a batch is cut into head + rest at most once, whatever sBits is
-    (regression: at sBits = 11 the head never logged enough for the probe and EVERY batch was cut into 0.65 M-slot pieces)"""
+    """lane-per-read engines decide the update mode ONCE from a sample of the first ~2^20 logged entries: repeat-rich
+    reads (dist g) -> direct atomics, uniform reads -> hit log; a batch is cut into head + rest at most once, whatever
+    sBits is (regression: at sBits = 11 the head never logged enough for the probe and EVERY batch was cut into
+    0.65 M-slot pieces).  An engine that can use the bit-sliced kernel (k = 32) stays in hit-log mode."""
     n, L, stride = 6_000_000, 150, 152
     d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
     nt.gen_reads_device(d.data_ptr(), 5, 0, n, L, stride, dist, genome_len=3_000_000)
-    with nt.Engine([32], r_bits=27, s_bits=s_bits) as e:
+    with nt.Engine([32], r_bits=27, s_bits=s_bits, flags=nt.FLAG_LANE_KERNEL) as e:
         e.set_profiling(True)
         for _ in range(4):
             e.submit_device(d.data_ptr(), n, L, stride)
@@ -248,6 +249,13 @@ def test_adaptive_mode_probes_once(nt, s_bits, dist, want_mode):
         _, launches = e.kernel_time()
         assert e.update_mode() == want_mode
         assert 4 <= launches <= 5, launches
+    with nt.Engine([32], r_bits=27, s_bits=s_bits) as e:
+        e.set_profiling(True)
+        for _ in range(2):
+            e.submit_device(d.data_ptr(), n, L, stride)
+        e.flush()
+        _, launches = e.kernel_time()
+        assert e.update_mode() == 0 and launches == 2, (e.update_mode(), launches)
 
 
 @pytest.mark.parametrize("L,stride,s_bits,pn", [
