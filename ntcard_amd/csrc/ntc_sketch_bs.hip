@@ -76,8 +76,16 @@ __device__ __forceinline__ void transpose_stage(uint32_t (&A)[32])
 	for (int k = 0; k < 32; ++k) {
 		if ((k & J) == 0) {
 			const uint32_t x = A[k], y = A[k + J];
-			A[k] = bfi(m, x, y << J);
-			A[k + J] = bfi(m, x >> J, y);
+			if constexpr (J == 16) { // whole bytes move: one v_perm_b32 per output instead of a shift + v_bfi_b32
+				A[k] = perm(y, x, 0x05040100u);     // x.b0 x.b1 y.b0 y.b1
+				A[k + J] = perm(y, x, 0x07060302u); // x.b2 x.b3 y.b2 y.b3
+			} else if constexpr (J == 8) {
+				A[k] = perm(y, x, 0x06020400u);     // x.b0 y.b0 x.b2 y.b2
+				A[k + J] = perm(y, x, 0x07030501u); // x.b1 y.b1 x.b3 y.b3
+			} else {
+				A[k] = bfi(m, x, y << J);
+				A[k + J] = bfi(m, x >> J, y);
+			}
 		}
 	}
 }
