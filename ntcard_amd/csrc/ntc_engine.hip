@@ -258,8 +258,15 @@ struct ntc_engine {
 	} ap;
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
 	void* d_t4 = nullptr;           // K1b: closed-form table, 4 bases per entry (NULL: K1b not used by this engine)
-	uint32_t* d_redo = nullptr;     // K1b: [redo_cap] slot indices handed to K1 + the count word behind them
-	uint64_t redo_cap = 0;
+	// K1b hands the reads with a non-ACGTU byte and the batch tails to K1 as a list of slot ADDRESSES.  For device-resident
+	// batches (valid until ntc_sync by contract) the list is kept across batches and K1 takes it in ONE gather pass when it
+	// could overflow, when the slot geometry changes, and before anything needs the counters: the pass has fixed costs
+	// (tables, first batch, last partial resolve) that one pass per batch pays ten times (0.13 vs 0.06 ms per 10 M reads)
+	uint64_t* d_redo = nullptr;     // [redo_cap] slot addresses
+	uint32_t* d_redo_count = nullptr;
+	uint64_t redo_cap = 0, redo_bound = 0; // capacity; upper bound of what the pending batches may have appended
+	bool redo_pending = false;
+	uint32_t redo_stride = 0, redo_len = 0;
 	double apply_ms = 0.0;
 	uint64_t applies = 0;
 	uint32_t hll_bits = 0;       // != 0: nthll engine (d_sketch holds uint32 M[1<<hll_bits])
@@ -353,9 +360,51 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	return true;
 }
 
+// K1 in gather mode over the pending list of slot addresses (the reads K1b handed back and the batch tails), then the list is empty
+int flush_redo(ntc_engine* e)
+{
+	if (!e->redo_pending) return 0;
+	e->redo_pending = false;
+	HfPlan hp;
+	if (int rc = hf_plan(e->device, std::max<uint64_t>(e->redo_bound, 64), e->redo_stride, &e->klist[0], 1, 0, hp)) return rc;
+	e->redo_bound = 0;
+	ntc::HfArgs a;
+	std::memset(&a, 0, sizeof a);
+	a.stride = e->redo_stride;
+	a.read_len = e->redo_len;
+	a.r_bits = e->r_bits;
+	a.s_bits = e->s_bits;
+	a.n_k = 1;
+	a.gather = e->d_redo;
+	a.gather_count = e->d_redo_count;
+	a.ks[0] = e->hfk[0];
+	if (e->d_log) {
+		a.log = e->d_log;
+		a.log_fill = e->d_logfill;
+		a.log_regions = e->log_regions;
+		a.log_region_cap = e->log_region_cap;
+		a.log_mode = e->d_logmode;
+	}
+	a.sketch0 = e->d_sketch;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (e->profiling) {
+		HIP_TRY(hipEventCreate(&ev0));
+		HIP_TRY(hipEventCreate(&ev1));
+		HIP_TRY(hipEventRecord(ev0, e->stream));
+	}
+	HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
+	HIP_TRY(hipMemsetAsync(e->d_redo_count, 0, 4, e->stream));
+	if (e->profiling) {
+		HIP_TRY(hipEventRecord(ev1, e->stream));
+		e->pending.emplace_back(ev0, ev1);
+	}
+	return 0;
+}
+
 // Apply the pending hit log to the sketch (asynchronous on the engine's stream): partition, count, add, clear.
 int apply_log(ntc_engine* e)
 {
+	if (int rc = flush_redo(e)) return rc; // K1 may log too: its pass comes first
 	if (!e->d_log || !e->log_pending) return 0;
 	const auto& ap = e->ap;
 	const uint32_t nb1 = 1u << ap.b1, nb2 = 1u << ap.b2;
@@ -454,7 +503,7 @@ int apply_log(ntc_engine* e)
 
 // launch the hash->sample->count kernel for every k of the list over one device-resident batch
 int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_meta, uint64_t n_slots,
-              uint32_t read_len, uint32_t stride)
+              uint32_t read_len, uint32_t stride, bool may_defer = false)
 {
 	if (n_slots == 0) return 0;
 	unsigned grid = 0;
@@ -514,6 +563,27 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				return run_batch(e, d_slots + head * stride, nullptr, n_slots - head, read_len, stride);
 			}
 		}
+		if (use_bs) {
+			// the redo list: room for a few batches of this size (every slot of a batch could end up on it); the deferred K1
+			// pass runs first when the list could overflow or the slot geometry changes
+			if (e->redo_pending && (e->redo_stride != stride || e->redo_len != read_len || e->redo_bound + n_slots > e->redo_cap))
+				if (int rc = flush_redo(e)) return rc;
+			if (n_slots > e->redo_cap) {
+				if (int rc = flush_redo(e)) return rc;
+				HIP_TRY(hipStreamSynchronize(e->stream));
+				if (e->d_redo) (void)hipFree(e->d_redo);
+				e->d_redo = nullptr;
+				e->redo_cap = 0;
+				const uint64_t cap = std::min<uint64_t>(8 * n_slots, std::max<uint64_t>(n_slots, 128ull << 20));
+				if (hipMalloc((void**)&e->d_redo, cap * 8) != hipSuccess)
+					return fail(NTC_ERR_MEMORY, "cannot allocate the %llu-entry redo list on device", (unsigned long long)cap);
+				if (!e->d_redo_count) {
+					if (hipMalloc((void**)&e->d_redo_count, 8) != hipSuccess) return fail(NTC_ERR_MEMORY, "cannot allocate the redo counter on device");
+					HIP_TRY(hipMemsetAsync(e->d_redo_count, 0, 8, e->stream));
+				}
+				e->redo_cap = cap;
+			}
+		}
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
 		if (e->d_log) {
 			// this batch's sampled k-mers + what every wave may leave unused at the end of a region; apply first if the log could fill up
@@ -530,9 +600,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		}
 		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
 		// a group whose closed-form tables would push the CU below 12 waves (and below what its members reach alone) is split in two
-		uint32_t gather_tail_first = 0, gather_tail_n = 0;
-		std::function<int(size_t, size_t, const unsigned char*, uint64_t, const uint32_t*, const uint32_t*)> launch_group =
-		    [&](size_t b, size_t n, const unsigned char* slots, uint64_t ns, const uint32_t* gather, const uint32_t* gather_count) -> int {
+		std::function<int(size_t, size_t, const unsigned char*, uint64_t, const uint64_t*, const uint32_t*)> launch_group =
+		    [&](size_t b, size_t n, const unsigned char* slots, uint64_t ns, const uint64_t* gather, const uint32_t* gather_count) -> int {
 			HfPlan hp;
 			if (int rc = hf_plan(e->device, ns, stride, &e->klist[b], (uint32_t)n, e->gap, hp)) {
 				if (n == 1) return rc;
@@ -564,8 +633,6 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.gapt = e->d_gapt;
 			a.gather = gather;
 			a.gather_count = gather_count;
-			a.gather_tail_first = gather ? gather_tail_first : 0u;
-			a.gather_tail_n = gather ? gather_tail_n : 0u;
 			if (e->gap) ntc::build_gap_roll_table(e->klist[b], a.gap_first, e->gap, a.tabg);
 			for (size_t j = 0; j < n; ++j)
 				a.ks[j] = e->hfk[b + j];
@@ -587,17 +654,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		if (use_bs) {
 			const uint64_t n_tiles = n_slots / 2048;
 			bs_slots = n_tiles * 2048;
-			if (bs_slots > e->redo_cap) {
-				HIP_TRY(hipStreamSynchronize(e->stream));
-				if (e->d_redo) (void)hipFree(e->d_redo);
-				e->d_redo = nullptr;
-				e->redo_cap = 0;
-				if (hipMalloc((void**)&e->d_redo, (bs_slots + 1) * 4) != hipSuccess)
-					return fail(NTC_ERR_MEMORY, "cannot allocate the %llu-entry redo list on device", (unsigned long long)bs_slots);
-				e->redo_cap = bs_slots;
-			}
-			uint32_t* redo_count = e->d_redo + e->redo_cap; // the word behind the list
-			HIP_TRY(hipMemsetAsync(redo_count, 0, 4, e->stream));
+			uint32_t* redo_count = e->d_redo_count;
 			DevInfo di;
 			if (int rc = device_info(e->device, di)) return rc;
 			ntc::BsArgs ba;
@@ -639,10 +696,16 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			ba.dbg = dbg;
 #endif
 			HIP_TRY(ntc::launch_sketch_bs(ba, (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)di.cus), e->stream));
-			// ONE K1 launch in gather mode takes the reads K1b handed back and the tail of the batch behind the whole tiles
-			gather_tail_first = (uint32_t)bs_slots;
-			gather_tail_n = (uint32_t)(n_slots - bs_slots);
-			if (int rc = launch_group(0, 1, d_slots, bs_slots, e->d_redo, redo_count)) return rc;
+			// the tail of the batch behind the whole tiles joins the handed-back reads on the list; K1 takes the list in gather
+			// mode: now for a staged host batch (its buffer is recycled), later and together with other batches otherwise
+			if (bs_slots < n_slots)
+				HIP_TRY(ntc::launch_append_slots(e->d_redo, redo_count, d_slots, stride, bs_slots, (uint32_t)(n_slots - bs_slots), e->stream));
+			e->redo_pending = true;
+			e->redo_bound += n_slots;
+			e->redo_stride = stride;
+			e->redo_len = read_len;
+			if (!may_defer)
+				if (int rc = flush_redo(e)) return rc;
 			bs_slots = n_slots;
 		}
 		if (bs_slots < n_slots)
@@ -825,7 +888,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
-	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
+	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo, (void*)e->d_redo_count, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
 		(void)hipEventDestroy(pr.first);
@@ -849,6 +912,11 @@ int ntc_reset(ntc_engine* e)
 	if (!e) return fail(NTC_ERR_ARG, "ntc_reset: null engine");
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
+	if (e->redo_pending) { // what was handed to the deferred K1 pass belongs to the counts that are being dropped
+		e->redo_pending = false;
+		e->redo_bound = 0;
+		HIP_TRY(hipMemsetAsync(e->d_redo_count, 0, 4, e->stream));
+	}
 	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->hll_bits ? (sizeof(uint32_t) << e->hll_bits) : e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
 	e->hll_reads_seen = 0;
 	if (e->d_logfill) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
@@ -878,7 +946,7 @@ int ntc_submit_device(ntc_engine* e, const void* d_slots, uint64_t n_reads, uint
 	if (read_len > 0xffffu) return fail(NTC_ERR_ARG, "ntc_submit_device: read_len %u > 65535", read_len);
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride);
+	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride, /*may_defer=*/true); // the caller's buffer stays valid until ntc_sync
 }
 
 } // extern "C"
@@ -1075,6 +1143,7 @@ int ntc_sync(ntc_engine* e)
 	if (!e) return fail(NTC_ERR_ARG, "ntc_sync: null engine");
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
+	if (int rc = flush_redo(e)) return rc; // after ntc_sync the caller may recycle its batches: the listed slots are read now
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return drain_events(e);
 }

@@ -64,9 +64,8 @@ struct HfArgs {
 	uint64_t* dump;             // validation build of K1 (kDump): [n_slots][dump_win] canonical hash of the window starting at each position
 	uint32_t* dump_valid;       //   [n_slots][ceil(dump_win / 32)] bit set where a hash was written (window without a non-ACGTU byte)
 	uint32_t dump_win, pad3_;
-	const uint32_t* gather;     // != NULL: the batch is the listed slots, gather[i] = slot index, i < *gather_count
+	const uint64_t* gather;     // != NULL: the batch is the listed slots, gather[i] = ADDRESS of slot i's bytes (they may lie in different buffers), i < *gather_count
 	const uint32_t* gather_count; // (reads the bit-sliced kernel K1b handed back: a non-ACGTU byte somewhere in the read)
-	uint32_t gather_tail_first, gather_tail_n; // gather mode: slots [first, first + n) follow the listed ones (the batch's tail behind K1b's whole tiles)
 	const void* gapt;
 	const uint32_t* hll_thr;
 	uint32_t tabg[kMainSlots][2]; // spaced seed, rolling form: per (leaving, entering) base pair of the don't-care block
@@ -88,11 +87,13 @@ struct BsArgs {
 	const uint32_t* log_mode;
 	unsigned long long* f1;
 	const void* t4;             // [k/4][256] x {fwd.lo, fwd.hi, rev.lo, rev.hi}: closed form, 4 bases per entry (code2 order)
-	uint32_t* redo_list;        // slot indices of the reads left to the lane-per-read kernel
+	uint64_t* redo_list;        // addresses of the slots left to the lane-per-read kernel (appended: the list outlives the launch)
 	uint32_t* redo_count;
 	uint64_t* dbg;              // instrumentation builds only (NTC_BS_TIMERS)
 };
 hipError_t launch_sketch_bs(const BsArgs& a, unsigned grid, hipStream_t st);
+// append the addresses of slots [first, first + n) of a batch to a redo list (the tail behind K1b's whole tiles)
+hipError_t launch_append_slots(uint64_t* list, uint32_t* count, const unsigned char* slots, uint32_t stride, uint64_t first, uint32_t n, hipStream_t st);
 hipError_t set_sketch_bs_smem_limit(size_t smem);
 size_t sketch_bs_smem(uint32_t k, uint32_t stride);
 bool sketch_bs_supports(uint32_t k, uint32_t s_bits);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 						base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - cnt;
 						uint32_t w2 = word;
 						while (w2 != 0u) {
-							a.redo_list[base++] = (uint32_t)(t * kTileReads) + (uint32_t)lane * 32u + (uint32_t)__builtin_ctz(w2);
+							a.redo_list[base++] = (uint64_t)(uintptr_t)a.slots + ((uint64_t)(t * kTileReads) + (uint32_t)lane * 32u + (uint32_t)__builtin_ctz(w2)) * stride;
 							w2 &= w2 - 1u;
 						}
 					}
@@ -532,6 +532,21 @@ hipError_t launch_sketch_bs(const BsArgs& a, unsigned grid, hipStream_t st)
 	if (a.k == 32 && a.s_bits == 7) return launch_one<32, 7>(a, grid, smem, st);
 	if (a.k == 32 && a.s_bits >= 8) return launch_one<32, 8>(a, grid, smem, st);
 	return hipErrorInvalidValue;
+}
+
+__global__ __launch_bounds__(256) void append_slots_kernel(uint64_t* list, uint32_t* count, const unsigned char* slots, uint32_t stride, uint64_t first, uint32_t n)
+{
+	const uint32_t base = *count; // one workgroup, stream-ordered behind the kernel that filled the list so far
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+		list[base + i] = (uint64_t)(uintptr_t)slots + (first + i) * stride;
+	if (threadIdx.x == 0) *count = base + n;
+}
+
+hipError_t launch_append_slots(uint64_t* list, uint32_t* count, const unsigned char* slots, uint32_t stride, uint64_t first, uint32_t n, hipStream_t st)
+{
+	hipLaunchKernelGGL(append_slots_kernel, dim3(1), dim3(256), 0, st, list, count, slots, stride, first, n);
+	return hipGetLastError();
 }
 
 hipError_t set_sketch_bs_smem_limit(size_t smem)

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
 	// gather mode: the batch is a device-side list of slot indices (its length is only known on the device)
 	const uint32_t n_listed = kGather ? (uint32_t)__builtin_amdgcn_readfirstlane(*a.gather_count) : 0u;
-	const uint64_t n_slots = kGather ? (uint64_t)n_listed + a.gather_tail_n : a.n_slots;
+	const uint64_t n_slots = kGather ? (uint64_t)n_listed : a.n_slots;
 	const uint64_t n_wb = (n_slots + 63) / 64;
 	// Hit log: ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is not executed here.  The wave appends the counter
 	// index of every sampled k-mer to its private log regions gwave, gwave + W, ... (W = waves of this launch) with one
@@ -276,8 +276,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			// row i of the wave's LDS block <- slot gather[slot0 + i]: lane i fetches index i, every lane then copies
 			// dwords d = lane, lane + 64, ... of the 64 x stride/4 block (row = d / (stride/4) by multiply-high)
 			const uint32_t s4 = stride >> 2, magic = 0xffffffffu / s4 + 1u;
-			const uint64_t gi = slot0 + (uint32_t)lane; // listed slots first, then the contiguous tail range
-			const uint32_t my_idx = (uint32_t)lane < nvalid ? (gi < n_listed ? a.gather[gi] : a.gather_tail_first + (uint32_t)(gi - n_listed)) : 0u;
+			const uint64_t my_ptr = (uint32_t)lane < nvalid ? a.gather[slot0 + (uint32_t)lane] : 0ull; // the slot's address (any buffer)
 			const uint32_t total = nvalid * s4;
 			for (uint32_t d0 = 0; d0 < total; d0 += 64u * 8u) {
 				uint32_t v[8];
@@ -285,8 +284,8 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				for (int u = 0; u < 8; ++u) {
 					const uint32_t d = d0 + (uint32_t)u * 64u + (uint32_t)lane;
 					const uint32_t row = __umulhi(d, magic), col = d - row * s4;
-					const uint32_t idx = (uint32_t)__shfl((int)my_idx, (int)(row & 63u));
-					v[u] = d < total ? reinterpret_cast<const uint32_t*>(a.slots + (uint64_t)idx * stride)[col] : 0x41414141u;
+					const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)my_ptr, (int)(row & 63u)), phi = (uint32_t)__shfl((int)(uint32_t)(my_ptr >> 32), (int)(row & 63u));
+					v[u] = d < total ? reinterpret_cast<const uint32_t*>(((uint64_t)phi << 32) | plo)[col] : 0x41414141u;
 				}
 #pragma unroll
 				for (int u = 0; u < 8; ++u) {
