@@ -103,7 +103,8 @@ int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, con
  * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Padding bytes
  * (read_len..stride) are never hashed; filling them with a base letter ('A') keeps the kernel on
  * its fast path (a non-ACGTU byte anywhere in a wave's 64 slots selects the dirty-window path).
- * Asynchronous on the engine's stream; the buffer must stay valid until ntc_sync/ntc_finish.
+ * Asynchronous on the engine's stream; the buffer must stay valid AND UNCHANGED until ntc_sync/ntc_finish returns:
+ * reads with a non-ACGTU byte (and a batch's last few reads) are hashed in a deferred pass that several batches share.
  * A wave parks its 64 slots in LDS, so stride is limited to about 2.4 KB (64 * stride + tables <= 160 KiB);
  * longer sequences go through ntc_submit, which splits them into overlapping chunks.            */
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
