@@ -232,6 +232,33 @@ def test_hit_log_geometries_match_direct_atomics(nt, r_bits, klist, log_entries)
     assert int(res[0][2].sum(dtype=torch.int64)) > 0
 
 
+def test_deferred_pass_over_several_buffers(nt):
+    """K1b hands reads with a non-ACGTU byte and batch tails to ONE deferred K1 pass as a list of slot ADDRESSES: several
+    device batches in different buffers, different tails, a change of slot geometry (flushes the list), a reset (drops
+    it), no ntc_sync in between -> counters and F1 equal the oracle's over everything submitted after the reset"""
+    rng = random.Random(99)
+
+    def batch(n, L, stride, pn):
+        reads = [rseq(rng, L, pn=pn, plow=0.05) for _ in range(n)]
+        buf, _ = to_slots(reads, stride=stride)
+        buf[buf == 10] = ord("A")
+        return reads, torch.from_numpy(buf).cuda()
+    dropped = batch(2048 * 2 + 5, 150, 152, 0.01)
+    batches = [batch(2048 * 2 + 300, 150, 152, 0.002), batch(2048 + 1, 150, 152, 0.02), batch(2048 * 3, 150, 152, 0.0),
+               batch(2048 * 2 + 77, 148, 156, 0.004), batch(2048 + 900, 150, 152, 0.001)]
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_BITSLICE_KERNEL) as e:
+        e.submit_device(dropped[1].data_ptr(), len(dropped[0]), 150, 152)
+        e.reset()
+        for reads, d in batches:
+            L = len(reads[0])
+            e.submit_device(d.data_ptr(), len(reads), L, 156 if L == 148 else 152)
+        tc, ph, f1 = e.finish(counters=True)
+    allreads = [r for reads, _ in batches for r in reads]
+    oc, of1 = orc.sketch_reads(allreads, [32], 0, 20, 7)
+    assert np.array_equal(f1, of1)
+    assert np.array_equal(tc, oc)
+
+
 @pytest.mark.parametrize("s_bits,dist,want_mode", [(7, 1, 1), (7, 0, 0), (11, 1, 1), (11, 0, 0), (9, 1, 1)])
 def test_adaptive_mode_probes_once(nt, s_bits, dist, want_mode):
     """lane-per-read engines decide the update mode ONCE from a sample of the first ~2^20 logged entries: repeat-rich
