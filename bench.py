@@ -133,7 +133,7 @@ def live_pmc(argv_inner, n_steps):
         d = tempfile.mkdtemp(prefix="ntc_pmc_", dir="/tmp")
         try:
             r = subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv_inner,
-                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return None
