@@ -65,7 +65,7 @@ typedef struct {
 #define NTC_FLAG_NONE 0u
 #define NTC_FLAG_SIMPLE_KERNEL 1u  /* run the simple validation kernel instead of the production ones */
 #define NTC_FLAG_BITSLICE_KERNEL 4u /* use the bit-sliced kernel K1b for the whole 2048-read tiles of EVERY equal-length k = 32
-                                      batch, however small (by default it takes batches of >= 128 tiles; it always runs in
+                                      batch, however small (by default it takes batches of >= 128 tiles of 128-159 bp reads; it always runs in
                                       hit-log mode: an engine that can use it never switches to direct atomics)           */
 #define NTC_FLAG_LANE_KERNEL 32u    /* never use K1b: the lane-per-read kernel K1 takes every batch (cross-check, A/B runs)  */
 #define NTC_FLAG_ALWAYS_LOG 8u      /* keep logging whatever the data looks like (by default the engine switches to direct

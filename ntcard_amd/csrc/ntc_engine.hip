@@ -551,10 +551,11 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		// not several heads long (large sBits, small batches) is not cut: the probe then runs once enough has been logged.
 		constexpr double kProbeEntries = 1.25 * (1 << 20);
 		const uint32_t k0 = e->klist[0];
-		// K1b pays when its four walkers are evenly loaded: 4 x 32 windows cover 112 .. 128 windows per read (143 .. 159 bp at
-		// k = 32; measured: 93 windows 0.95 T vs K1's 1.0 T, 119 windows 1.5 T vs 1.3 T); NTC_FLAG_BITSLICE_KERNEL lifts that
+		// K1b pays when all four walkers have work: 4 x 32 windows cover 97 .. 128 windows per read (128 .. 159 bp at k = 32;
+		// measured on genome-like reads, hash kernels per 10 M reads: 97 windows 0.63 vs K1's 0.74 ms, 109: 0.65 vs 0.80, 119: 0.68
+		// vs 0.87, 128: 0.72 vs 1.10; 93 windows, where the fourth walker idles: about equal); NTC_FLAG_BITSLICE_KERNEL lifts that
 		const uint32_t n_win = read_len >= k0 ? read_len - k0 + 1 : 0;
-		const bool use_bs = e->d_t4 && e->d_log && d_meta == nullptr && n_win >= (e->bs_min_tiles > 1 ? 112u : 1u) && n_win <= 255 && stride >= 128 && stride <= 160 &&
+		const bool use_bs = e->d_t4 && e->d_log && d_meta == nullptr && n_win >= (e->bs_min_tiles > 1 ? 97u : 1u) && n_win <= 255 && stride >= 128 && stride <= 160 &&
 		                    ntc::sketch_bs_smem(k0, stride) <= kMaxDynLds && n_slots >= 2048 * e->bs_min_tiles;
 		if (e->d_log && e->adaptive && !e->probed && !use_bs && d_meta == nullptr && per_slot > 0.0) {
 			const uint64_t head = (((uint64_t)(kProbeEntries / per_slot) + 2047) / 2048) * 2048;
