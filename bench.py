@@ -328,7 +328,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),
                          "kernel": ("sketch_bs_kernel (whole 2048-read tiles) + sketch_hf_kernel (handed-back reads and tail)"
                                     if nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255
-                                    and (args.bitslice or (R >= 2048 * 128 and not args.lane_kernel and not args.direct_atomics)) else "sketch_hf_kernel"),
+                                    and (args.bitslice or (R >= 2048 * 128 and L - 31 >= 97 and not args.lane_kernel and not args.direct_atomics)) else "sketch_hf_kernel"),
                          "avg_launch_ms": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_launch_kmers},
