@@ -14,7 +14,7 @@
 //                         tile leaves as ~256-byte segments.  One 1024-thread workgroup per CU: the number of open
 //                         runs (workgroups x digits x one 128-byte line) has to stay inside L2 for the run tails to
 //                         be written once, so parallelism comes from the workgroup size, not from their number.
-//                         Round 2 history per 92 M keys: two LDS atomics per key, 256 threads x 1024 workgroups
+//                         Round 2 history per 183 M keys: two LDS atomics per key, 256 threads x 1024 workgroups
 //                         0.85 + 0.65 ms; one returning atomic + prefetch, 256 x 512: 0.51 + 0.36 ms; this form ~0.6 ms.
 //   A3     count_kernel   one workgroup per slice of 2^15 counters: histogram of the slice's keys in LDS
 //                         (ds_add on 16-bit fields, single writer per slice), then one coalesced `sketch[i] += n` sweep.
