@@ -110,6 +110,21 @@ int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, con
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
                       uint32_t stride);
 
+/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernel (K1c) streams, and the
+ * one ntc_submit / ntc_submit_spans pack equal-length host batches into:
+ *     tile t   = reads [2048 t, 2048 t + 2048) of the batch,       n_chunks = ceil(read_len / 16)
+ *     piece    = the 16 raw bytes of bases [16 c, 16 c + 16) of read i, at byte offset
+ *                ((i / 2048 * n_chunks + c) * 2048 + i % 2048) * 16          (ntc_tiled_bytes() bytes in all)
+ * i.e. the pieces of one base range of a tile's 2048 reads are contiguous (32 KiB): one coalesced load hands every lane
+ * the next 16 bases of "its" read, in the position-major order the bit-sliced hash walk consumes.  Bytes are raw sequence
+ * bytes as the parsers produce them (any case, N / IUPAC); bytes behind a read's end and the slots behind the batch's last
+ * read must hold a base letter ('A').  All reads of a batch have the same length.  Asynchronous on the engine's stream; the
+ * buffer may be reused as soon as the stream has passed the call (nothing refers to it afterwards).  Configurations the
+ * tiled kernel is not built for (k != 32, several k, spaced seeds, nthll, sBits < 7) are re-laid out on the device and
+ * take the general kernel: same results, not the fast path.                                                           */
+int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);
+uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
+
 int ntc_sync(ntc_engine *e); /* wait for all submitted work */
 
 /* Apply the pending hit log to the device sketch (asynchronous on the engine's stream).  After it the
@@ -166,6 +181,10 @@ int ntc_hash_dump_k1_device(int32_t device, void *stream, const void *d_slots, u
 int ntc_gen_reads_device(int32_t device, void *stream, void *d_slots, uint64_t seed,
                          uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint32_t stride,
                          uint32_t dist, uint64_t genome_len);
+
+/* the same reads (bit-identical bases) in the tiled layout of ntc_submit_tiled_device; fills ntc_tiled_bytes() bytes */
+int ntc_gen_reads_tiled_device(int32_t device, void *stream, void *d_tiles, uint64_t seed, uint64_t first_read,
+                               uint64_t n_reads, uint32_t read_len, uint32_t dist, uint64_t genome_len);
 
 /* compEst (ntcard.cpp:249-274) from the value histogram of ONE k.  f_out has cov_max+1 doubles
  * (f_out[0] unused); only i <= cov_max is evaluated (identical values).          */

@@ -105,6 +105,7 @@ int ensure_kernel_attrs(int dev)
 	HIP_TRY(ntc::set_hash_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_apply_smem_limit());
 	HIP_TRY(ntc::set_sketch_bs_smem_limit(kMaxDynLds));
+	HIP_TRY(ntc::set_sketch_ts_smem_limit(kMaxDynLds));
 	done[dev] = 1;
 	return 0;
 }
@@ -257,7 +258,10 @@ struct ntc_engine {
 		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
 	} ap;
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
-	void* d_t4 = nullptr;           // K1b: closed-form table, 4 bases per entry (NULL: K1b not used by this engine)
+	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry (NULL: neither is used by this engine)
+	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
+	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1c does not cover
+	size_t untile_cap = 0;
 	// K1b hands the reads with a non-ACGTU byte and the batch tails to K1 as a list of slot ADDRESSES.  For device-resident
 	// batches (valid until ntc_sync by contract) the list is kept across batches and K1 takes it in ONE gather pass when it
 	// could overflow, when the slot geometry changes, and before anything needs the counters: the pass has fixed costs
@@ -758,6 +762,76 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	return 0;
 }
 
+// K1c over one device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)
+int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len)
+{
+	if (n_reads == 0) return 0;
+	const uint32_t k0 = e->klist[0];
+	if (read_len < k0) return 0; // no window (ntHashIterator.hpp:61-64)
+	if (!e->ts_ok) {
+		// this configuration is served by K1 only: re-lay the batch out as row-major slots (exact; not a fast path)
+		const uint32_t stride = pick_stride(read_len, e->klist, e->gap);
+		const size_t need = (size_t)n_reads * stride + 16;
+		if (need > e->untile_cap) {
+			HIP_TRY(hipStreamSynchronize(e->stream));
+			if (e->d_untile) (void)hipFree(e->d_untile);
+			e->d_untile = nullptr;
+			e->untile_cap = 0;
+			if (hipMalloc((void**)&e->d_untile, need) != hipSuccess) return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of row-major scratch on device", need);
+			e->untile_cap = need;
+		}
+		HIP_TRY(ntc::launch_untile(d_tiles, e->d_untile, n_reads, read_len, stride, e->stream));
+		return run_batch(e, e->d_untile, nullptr, n_reads, read_len, stride);
+	}
+	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
+	if (n_tiles > 0xffffffffull / 64) return fail(NTC_ERR_ARG, "tiled batch of %llu reads is too large for one submit", (unsigned long long)n_reads);
+	if (e->d_log) {
+		// candidates of this batch (both samples ~2^-sBits of the windows each) + what every logging wave may leave unused at the end of a region
+		const double per_read = (double)(read_len - k0 + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+		const double est = 64.0 * 4096 + (double)n_reads * per_read;
+		if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
+			if (int rc = apply_log(e)) return rc;
+		e->log_est += est;
+		e->log_pending = true;
+	}
+	DevInfo di;
+	if (int rc = device_info(e->device, di)) return rc;
+	ntc::TsArgs a;
+	std::memset(&a, 0, sizeof a);
+	a.tiles = d_tiles;
+	a.n_reads = n_reads;
+	a.n_tiles = (uint32_t)n_tiles;
+	a.n_chunks = (read_len + 15u) / 16u;
+	a.read_len = read_len;
+	a.k = k0;
+	a.r_bits = e->r_bits;
+	a.s_bits = e->s_bits;
+	a.key_base = 0;
+	if (e->d_log) {
+		a.log = e->d_log;
+		a.log_fill = e->d_logfill;
+		a.log_regions = e->log_regions;
+		a.log_region_cap = e->log_region_cap;
+		a.log_mode = nullptr; // K1c logs whenever the engine has a log
+	}
+	a.sketch0 = e->d_sketch;
+	a.f1 = e->d_f1;
+	a.t4 = e->d_t4;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (e->profiling) {
+		HIP_TRY(hipEventCreate(&ev0));
+		HIP_TRY(hipEventCreate(&ev1));
+		HIP_TRY(hipEventRecord(ev0, e->stream));
+	}
+	const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 1) / 2, (uint64_t)di.cus);
+	HIP_TRY(ntc::launch_sketch_ts(a, grid, e->stream));
+	if (e->profiling) {
+		HIP_TRY(hipEventRecord(ev1, e->stream));
+		e->pending.emplace_back(ev0, ev1);
+	}
+	return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -855,7 +929,9 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	// takes (ragged, short or long slots, small) keep the adaptive choice
 	const bool bs_wanted = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) || (!(cfg->flags & (NTC_FLAG_LANE_KERNEL | NTC_FLAG_DIRECT_ATOMICS)) && e->d_log != nullptr);
 	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
-	if (e->kernel_kind == KIND_HF && bs_wanted && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
+	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
+	           ntc::sketch_ts_supports(e->klist[0], e->s_bits) && ntc::sketch_ts_smem(e->klist[0]) <= kMaxDynLds;
+	if (e->kernel_kind == KIND_HF && (bs_wanted || e->ts_ok) && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
 	    ntc::sketch_bs_supports(e->klist[0], e->s_bits)) {
 		std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[0]) * 256 * 4);
 		ntc::build_t4(e->klist[0], t4.data());
@@ -864,6 +940,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the bit-sliced kernel on device");
 		}
 	}
+	if (!e->d_t4) e->ts_ok = false;
 	e->hfk.resize(e->klist.size());
 	for (size_t ki = 0; ki < e->klist.size(); ++ki)
 		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki], (uint32_t)(ki * e->plane_elems()));
@@ -889,6 +966,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
+	if (e->d_untile) (void)hipFree(e->d_untile);
 	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo, (void*)e->d_redo_count, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
@@ -950,6 +1028,35 @@ int ntc_submit_device(ntc_engine* e, const void* d_slots, uint64_t n_reads, uint
 	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride, /*may_defer=*/true); // the caller's buffer stays valid until ntc_sync
 }
 
+
+int ntc_submit_tiled_device(ntc_engine* e, const void* d_tiles, uint64_t n_reads, uint32_t read_len)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: null engine");
+	if (n_reads == 0) return 0;
+	if (!d_tiles || ((uintptr_t)d_tiles & 15u)) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: need a 16-byte aligned buffer");
+	if (read_len == 0 || read_len > 0xffffu) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: read_len %u outside 1..65535", read_len);
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	return run_tiled(e, (const unsigned char*)d_tiles, n_reads, read_len);
+}
+
+uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len)
+{
+	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
+	return n_tiles * ((read_len + 15u) / 16u) * (uint64_t)ntc::kTileReads * 16u;
+}
+
+int ntc_gen_reads_tiled_device(int32_t device, void* stream, void* d_tiles, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                               uint32_t dist, uint64_t genome_len)
+{
+	if (!d_tiles || ((uintptr_t)d_tiles & 15u) || read_len == 0) return fail(NTC_ERR_ARG, "ntc_gen_reads_tiled_device: bad layout");
+	if (dist > 1) return fail(NTC_ERR_ARG, "ntc_gen_reads_tiled_device: dist must be 0 (uniform) or 1 (genome)");
+	if (dist == 1 && genome_len < read_len) return fail(NTC_ERR_ARG, "ntc_gen_reads_tiled_device: genome shorter than a read");
+	if (n_reads == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(ntc::launch_gen_tiled((unsigned char*)d_tiles, seed, first_read, n_reads, read_len, dist, genome_len, (hipStream_t)stream));
+	return 0;
+}
 } // extern "C"
 
 namespace {

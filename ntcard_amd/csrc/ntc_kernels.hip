@@ -361,6 +361,78 @@ __global__ __launch_bounds__(256) void gen_reads_kernel(unsigned char* __restric
 	}
 }
 
+// K0 for the TILED slot layout (ntc_kernels.hpp, TsArgs): the same reads as gen_reads_kernel (bit-identical bases), the 16-byte
+// piece c of read i at ((i / 2048 * n_chunks + c) * 2048 + i % 2048) * 16; bytes behind a read's end and the slots behind the
+// last read of the last tile are 'A'
+__global__ __launch_bounds__(256) void gen_reads_tiled_kernel(unsigned char* __restrict__ out, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                                              uint32_t read_len, uint32_t dist, uint64_t genome_len)
+{
+	const uint64_t rseed = mix64(seed);
+	const uint64_t gseed = mix64(seed ^ 0x47454E4F4D45ULL);
+	const uint32_t acgt = 0x54474341u; // 'A','C','G','T' little-endian
+	const uint32_t n_chunks = (read_len + 15u) / 16u;
+	const uint64_t n_slots = (n_reads + kTileReads - 1) / kTileReads * kTileReads;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t r = first_read + i;
+		unsigned char* dst = out + ((i / kTileReads) * n_chunks * kTileReads + (i % kTileReads)) * 16u;
+		const bool real = i < n_reads;
+		const uint64_t hr = mix64(rseed + r);
+		uint64_t pos = 0, hs = 0, hm = 0, h = 0;
+		unsigned rev = 0;
+		if (dist != 0) {
+			const uint64_t span = genome_len - read_len + 1;
+			pos = __umul64hi(hr, span);
+			hs = mix64(hr ^ 0xA5A5A5A5A5A5A5A5ULL);
+			rev = (unsigned)(hs & 1u);
+		}
+		for (uint32_t c = 0; c < n_chunks; ++c) {
+			uint32_t w4[4];
+			for (uint32_t q = 0; q < 4; ++q) {
+				uint32_t word = 0;
+				for (uint32_t t = 0; t < 4; ++t) {
+					const uint32_t j = 16u * c + 4u * q + t;
+					uint32_t ch = 'A';
+					if (real && j < read_len) {
+						if (dist == 0) {
+							if ((j & 31) == 0) h = mix64(hr + (j >> 5));
+							ch = (acgt >> (8 * ((h >> (2 * (j & 31))) & 3u))) & 0xffu;
+						} else {
+							unsigned code = rev ? 3u - genome_code(gseed, pos + read_len - 1 - j) : genome_code(gseed, pos + j);
+							if ((j & 3) == 0) hm = mix64(hs + 1 + (j >> 2));
+							const unsigned u = (unsigned)(hm >> (16 * (j & 3))) & 0xFFFFu;
+							if (u < 655u)
+								ch = (acgt >> (8 * ((code + 1u + (u % 3u)) & 3u))) & 0xffu;
+							else if (u < 688u)
+								ch = 'N';
+							else
+								ch = (acgt >> (8 * code)) & 0xffu;
+						}
+					}
+					word |= ch << (8 * t);
+				}
+				w4[q] = word;
+			}
+			*reinterpret_cast<uint4*>(dst + (uint64_t)c * kTileReads * 16u) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+		}
+	}
+}
+
+// tiled layout -> row-major slots (fallback for configurations K1c is not instantiated for; validation)
+__global__ __launch_bounds__(256) void untile_kernel(const unsigned char* __restrict__ tiles, unsigned char* __restrict__ slots, uint64_t n_reads,
+                                                     uint32_t read_len, uint32_t stride)
+{
+	const uint32_t n_chunks = (read_len + 15u) / 16u;
+	const uint32_t dw = stride / 4u; // dwords per slot
+	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_reads * dw; idx += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t i = idx / dw;
+		const uint32_t d = (uint32_t)(idx % dw), c = d / 4u;
+		uint32_t v = 0x41414141u;
+		if (c < n_chunks)
+			v = *reinterpret_cast<const uint32_t*>(tiles + ((i / kTileReads) * n_chunks * kTileReads + (c * (uint64_t)kTileReads) + (i % kTileReads)) * 16u + (d & 3u) * 4u);
+		reinterpret_cast<uint32_t*>(slots + i * stride)[d] = v;
+	}
+}
+
 // nthll: the next batch only needs to look at hashes that can still raise SOME register: run0 > min_j M[j].
 // thr = 2^(32 - (min+1)) on the top 32 bits (hash < thr<<32  <=>  at least min+1 leading zeros).
 __global__ __launch_bounds__(1024) void hll_threshold_kernel(const uint32_t* __restrict__ regs, uint32_t n_regs, uint32_t* thr)
@@ -460,6 +532,24 @@ hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32
 hipError_t launch_value_hist(const uint32_t* counters, uint64_t n, uint32_t* p_hist, hipStream_t st)
 {
 	hipLaunchKernelGGL(finalize_kernel, dim3(2048, 1), dim3(256), 0, st, counters, n, p_hist, (uint16_t*)nullptr);
+	return hipGetLastError();
+}
+
+hipError_t launch_gen_tiled(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint32_t dist, uint64_t glen, hipStream_t st)
+{
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	if (blocks == 0) blocks = 1;
+	hipLaunchKernelGGL(gen_reads_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, seed, first, n, len, dist, glen);
+	return hipGetLastError();
+}
+
+hipError_t launch_untile(const unsigned char* tiles, unsigned char* slots, uint64_t n_reads, uint32_t read_len, uint32_t stride, hipStream_t st)
+{
+	uint64_t blocks = (n_reads * (stride / 4u) + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	if (blocks == 0) blocks = 1;
+	hipLaunchKernelGGL(untile_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tiles, slots, n_reads, read_len, stride);
 	return hipGetLastError();
 }
 

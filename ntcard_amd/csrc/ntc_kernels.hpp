@@ -98,6 +98,33 @@ hipError_t set_sketch_bs_smem_limit(size_t smem);
 size_t sketch_bs_smem(uint32_t k, uint32_t stride);
 bool sketch_bs_supports(uint32_t k, uint32_t s_bits);
 
+// K1c (sketch_ts_kernel, ntc_sketch_ts.hip): tiled streaming kernel.  TILED slot layout: tile t = reads [2048 t, 2048 t + 2048);
+// the 16 raw bytes of bases [16 c, 16 c + 16) of read r of tile t sit at ((t * n_chunks + c) * 2048 + r) * 16.
+constexpr uint32_t kTileReads = 2048;
+struct TsArgs {
+	const unsigned char* tiles;
+	uint64_t n_reads;           // reads of the batch; slots behind the last one (in the last tile) hold 'A's and are ignored
+	uint32_t n_tiles, n_chunks; // ceil(n_reads / 2048), ceil(read_len / 16)
+	uint32_t read_len;
+	uint32_t k, r_bits, s_bits;
+	uint32_t key_base;
+	uint32_t log_regions, log_region_cap;
+	uint32_t* log;
+	uint32_t* log_fill;
+	uint32_t* sketch0;
+	const uint32_t* log_mode;
+	unsigned long long* f1;
+	const void* t4;             // [k/4][256] x {fwd.lo, fwd.hi, rev.lo, rev.hi}: closed form, 4 bases per entry (code2 order)
+	uint32_t* dbg;              // debugging builds only (tools/dbg)
+};
+hipError_t launch_sketch_ts(const TsArgs& a, unsigned grid, hipStream_t st);
+hipError_t set_sketch_ts_smem_limit(size_t smem);
+size_t sketch_ts_smem(uint32_t k);
+bool sketch_ts_supports(uint32_t k, uint32_t s_bits);
+// row-major slots -> tiled layout (and back): device-side re-layout for callers that hold the other form
+hipError_t launch_gen_tiled(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint32_t dist, uint64_t glen, hipStream_t st);
+hipError_t launch_untile(const unsigned char* tiles, unsigned char* slots, uint64_t n_reads, uint32_t read_len, uint32_t stride, hipStream_t st);
+
 // ---- deferred sketch update (ntc_apply.hip) ----
 // A1/A2: radix partition of key runs.  Input run `seg` = in[seg * in_cap, +min(in_cnt[seg], in_cap)).
 //   mode 0: workgroup w reads runs w, w + grid, ...                      (first pass over the raw log regions)

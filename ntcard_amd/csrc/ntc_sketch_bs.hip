@@ -115,7 +115,7 @@ __device__ __forceinline__ void pin31(uint32_t (&X)[31])
 #define BS_ACC(slot, t0, t1)
 #endif
 
-constexpr int kTileReads = 2048;
+// kTileReads (2048) comes from ntc_kernels.hpp
 constexpr int kGroupLoads = 10;  // loads per staging group
 constexpr int kGroups = 8;       // 80 loads of 1 KiB per helper and tile: strides up to 160 B
 constexpr uint32_t kQueueCap = 1088; // queue items per walker: 63 left over from the previous block + 16 steps x 64 lanes

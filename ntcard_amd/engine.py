@@ -98,6 +98,10 @@ class Engine:
     def submit_device(self, d_slots_ptr, n_reads, read_len, stride):
         check(self._lib.ntc_submit_device(self._h, C.c_void_p(d_slots_ptr), n_reads, read_len, stride))
 
+    def submit_tiled_device(self, d_tiles_ptr, n_reads, read_len):
+        """a device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)"""
+        check(self._lib.ntc_submit_tiled_device(self._h, C.c_void_p(d_tiles_ptr), n_reads, read_len))
+
     def sync(self):
         check(self._lib.ntc_sync(self._h))
 
@@ -196,6 +200,31 @@ def write_hist(path, f1, F0, f, cov_max=1000):
 def gen_reads_device(d_ptr, seed, first, n, read_len, stride, dist, genome_len=100_000_000, device=0, stream=None):
     check(_abi.lib().ntc_gen_reads_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_ptr), seed, first, n,
                                           read_len, stride, dist, genome_len))
+
+
+def tiled_bytes(n_reads, read_len):
+    """size of a batch in the tiled layout"""
+    return int(_abi.lib().ntc_tiled_bytes(n_reads, read_len))
+
+
+def gen_reads_tiled_device(d_ptr, seed, first, n, read_len, dist, genome_len=100_000_000, device=0, stream=None):
+    """the reads of gen_reads_device (bit-identical bases) in the tiled layout"""
+    check(_abi.lib().ntc_gen_reads_tiled_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_ptr), seed, first, n,
+                                                read_len, dist, genome_len))
+
+
+def tile_reads(reads, read_len=None):
+    """host-side packing of equal-length reads (list of bytes) into the tiled layout -> uint8 array (tests, small inputs)"""
+    n = len(reads)
+    L = read_len if read_len is not None else (len(reads[0]) if n else 0)
+    C16 = (L + 15) // 16
+    nt = (n + 2047) // 2048
+    out = np.full((nt, C16, 2048, 16), ord("A"), dtype=np.uint8)
+    if n:
+        a = np.full((nt * 2048, C16 * 16), ord("A"), dtype=np.uint8)
+        a[:n, :L] = np.frombuffer(b"".join(reads), dtype=np.uint8).reshape(n, L)
+        out[:] = a.reshape(nt, 2048, C16, 16).transpose(0, 2, 1, 3)
+    return out.reshape(-1)
 
 
 def value_hist_device(d_counters_ptr, n, d_hist_ptr, device=0, stream=None):
