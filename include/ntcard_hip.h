@@ -72,6 +72,7 @@ typedef struct {
                                       atomics when an apply finds few distinct counters per increment: repeats)       */
 #define NTC_FLAG_PARTITION_ALWAYS 16u /* validation: apply even a small hit log through the partition + histogram passes
                                          (by default fewer than 4 M pending entries are applied with plain atomics)   */
+#define NTC_FLAG_REQUIRE_TILED 64u  /* validation: ntc_submit_tiled_device fails instead of re-laying a batch out for the general kernel */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 

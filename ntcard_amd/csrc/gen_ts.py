@@ -23,6 +23,18 @@ import sys
 from gen_bs import Emit, g_of, plane, step_terms, hseed, rol31, COMP, CODE2, ttbl  # noqa: F401
 
 
+def plane2(e, cache, t4, b0, b1):
+    """gen_bs.plane with the two-input planes that are one plain VOP2 instruction (and / or / xor issue at about 1.8 clk per
+    wave on gfx950, a three-operand v_bitop3_b32 at 2.9) written as C operators"""
+    ops = {0b1000: "&", 0b1110: "|", 0b0110: "^"}
+    t = t4 ^ 0xf if t4 & 1 else t4
+    if t in ops and t not in cache:
+        v = e.tmp()
+        e.lines.append(f"\tconst uint32_t {v} = {b0} {ops[t]} {b1}; // plane {t:04b}")
+        cache[t] = v
+    return plane(e, cache, t4, b0, b1)
+
+
 def emit_strand_step(name, k, strand, main):
     f_terms, r_terms = step_terms(k)
     terms = f_terms if strand == "F" else r_terms
@@ -35,8 +47,8 @@ def emit_strand_step(name, k, strand, main):
         prev = f"S[{(j - 1) % 31}]" if strand == "F" else f"S[{(j + 1) % 31}]"
         tin, tout = terms[j]
         if main:
-            x, xi = plane(e, cin, tin, "i0", "i1")
-            y, yi = plane(e, cout, tout, "o0", "o1")
+            x, xi = plane2(e, cin, tin, "i0", "i1")
+            y, yi = plane2(e, cout, tout, "o0", "o1")
             inv = xi ^ yi
             if x is None and y is None:
                 v = e.op(prev, prev, prev, lambda a, b, c: a ^ inv)
@@ -89,6 +101,45 @@ def emit_cand(name, s_bits):
     return head + "\n" + "\n".join(e.lines) + f"\n\treturn {hit};\n}}\n", len(e.lines)
 
 
+def emit_xplanes(name, s_bits):
+    """the three planes of ONE strand behind the exchanged candidate test.  With A = the strand's top s_bits bits (8 bits for
+    s_bits >= 8) and P = 01..1:  eqA: A == P,  geA: A >= P,  eqB: top s_bits + 1 bits == 0..01 (top 8 bits == 0 for s_bits >= 8).
+    min(f, r) matches ntComp's sample-1 pattern through THIS strand iff eqA(own) & geA(other); the sample-0 pattern through
+    this strand iff eqB(own) (and the other strand is not smaller still: one window in 2^16, left to the resolve stage)."""
+    e = Emit()
+    n = min(s_bits + 1, 8)
+    x = [f"S[{30 - (n - 1) + i}]" for i in range(n)]  # x[n-1] = top bit of the hash
+    if s_bits <= 7:
+        ones = [(x[i], 0) for i in range(1, n - 1)]                             # the s_bits - 1 bits below the top one
+        b_l = [(x[i], 1) for i in range(1, n)] + [(x[0], 0)]
+    else:
+        ones = [(x[i], 0) for i in range(7)]
+        b_l = [(x[i], 1) for i in range(8)]
+    top = x[n - 1]
+    # all-ones of `ones` as at most two partial conjunctions, folded into the last instruction of eqA / geA
+    parts = []
+    items = list(ones)
+    while len(items) > 2:
+        grp, items = items[:3], items[3:]
+        parts.append(conj(e, grp))
+    parts += items
+    while len(parts) > 2:
+        grp, parts = parts[:3], parts[3:]
+        parts.append(conj(e, grp))
+    if len(parts) == 1:
+        (p, np_), = parts
+        eqa = e.op(top, p, p, lambda a, b, c: (~a) & (b ^ np_), "A == 01..1")
+        gea = e.op(top, p, p, lambda a, b, c: a | (b ^ np_), "A >= 01..1")
+    else:
+        (p, np_), (q, nq) = parts
+        eqa = e.op(top, p, q, lambda a, b, c: (~a) & (b ^ np_) & (c ^ nq), "A == 01..1")
+        gea = e.op(top, p, q, lambda a, b, c: a | ((b ^ np_) & (c ^ nq)), "A >= 01..1")
+    b, nb = conj(e, b_l)
+    assert nb == 0
+    head = f"__device__ __forceinline__ void {name}(const uint32_t (&S)[31], uint32_t& eqA, uint32_t& geA, uint32_t& eqB)\n{{"
+    return head + "\n" + "\n".join(e.lines) + f"\n\teqA = {eqa};\n\tgeA = {gea};\n\teqB = {b};\n}}\n", len(e.lines)
+
+
 def generate(ks=(32,)):
     out = ["// ntc_ts_gen.inc — GENERATED by gen_ts.py (do not edit): per-strand step bodies of the tiled streaming kernel K1c.",
            "// See gen_ts.py / gen_bs.py for the derivation; tables follow from the four seeds of nthash.hpp:25-28.", ""]
@@ -104,6 +155,9 @@ def generate(ks=(32,)):
         s, n = emit_cand(f"ts_cand_s{sb}", sb)
         out.append(s)
         stats[f"s{sb}"] = n
+        s, n = emit_xplanes(f"ts_xplanes_s{sb}", sb)
+        out.append(s)
+        stats[f"x{sb}"] = n
     return "\n".join(out), stats
 
 
@@ -115,7 +169,11 @@ def run_body(src, S, planes):
     new = list(S)
     for line in src.splitlines():
         line = line.strip()
-        if line.startswith("const uint32_t"):
+        if line.startswith("const uint32_t") and "bitop3" not in line:
+            name, _, x, op, y = line.split("//")[0].rstrip("; ").split()[2:7]
+            a, b = env[x], env[y]
+            env[name] = (a & b if op == "&" else a | b if op == "|" else a ^ b) & full
+        elif line.startswith("const uint32_t"):
             name = line.split()[2]
             inner = line[line.index("bitop3_b32(") + 11: line.index(");")]
             x, y, z, t = [s.strip() for s in inner.split(",")]
@@ -188,7 +246,64 @@ def selftest():
             else:
                 want = v == 0 or v == 0x7f
             assert bool(got) == want, (sb, v)
+    for sb in (2, 3, 5, 7, 8, 11):
+        src = emit_xplanes("x", min(sb, 8))[0]
+        n = min(sb + 1, 8)
+        for v in range(1 << n):
+            S = [0] * 31
+            for i in range(n):
+                S[30 - (n - 1) + i] = (v >> i) & 1
+            env = run_xplanes(src, S)
+            if sb <= 7:
+                A, P = v >> 1, (1 << (sb - 1)) - 1
+                want = (A == P, A >= P, v == 1)
+            else:
+                want = (v == 0x7f, v >= 0x7f, v == 0)
+            assert (bool(env["eqA"]), bool(env["geA"]), bool(env["eqB"])) == want, (sb, v, env, want)
+    # the exchanged test is exact up to the canonical-strand rule of the resolve stage: for every pair of prefixes,
+    # "some strand flags" == "min matches a pattern" (s_bits <= 7), with the one documented exception f or r == 0 next to 0..01
+    for sb in (3, 7):
+        n = sb + 1
+        for f in range(1 << n):
+            for r in range(1 << n):
+                def pl(v):
+                    A, P = v >> 1, (1 << (sb - 1)) - 1
+                    return A == P, A >= P, v == 1
+                fa, fg, fb = pl(f)
+                ra, rg, rb = pl(r)
+                flag_f, flag_r = (fa and rg) or fb, (ra and fg) or rb
+                m = min(f, r)
+                hit = m == 1 or (m >> 1) == (1 << (sb - 1)) - 1
+                # the resolve keeps a forward flag iff f <= r, a reverse flag iff r < f
+                kept = (flag_f and f <= r) or (flag_r and r < f)
+                assert kept == hit, (sb, f, r)
     print("gen_ts selftest ok")
+
+
+def run_xplanes(src, S):
+    body = src[:src.index("\teqA =")]
+    env = {"_full": 1}
+    # reuse run_body's interpreter on the straight-line part, then pick the three named results
+    lines = body.splitlines()
+    tmp = {}
+    full = 1
+    for line in lines:
+        line = line.strip()
+        if line.startswith("const uint32_t") and "bitop3" in line:
+            name = line.split()[2]
+            inner = line[line.index("bitop3_b32(") + 11: line.index(");")]
+            x, y, z, t = [q.strip() for q in inner.split(",")]
+            t = int(t, 16)
+
+            def val(q):
+                return tmp[q] if q in tmp else S[int(q[2:-1])]
+            a, b, c = val(x), val(y), val(z)
+            tmp[name] = (t >> ((a << 2) | (b << 1) | c)) & 1
+    out = {}
+    for key in ("eqA", "geA", "eqB"):
+        ref = src[src.index(f"\t{key} = ") + len(key) + 4:].split(";")[0]
+        out[key] = tmp[ref]
+    return out
 
 
 if __name__ == "__main__":

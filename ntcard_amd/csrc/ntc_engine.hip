@@ -260,6 +260,7 @@ struct ntc_engine {
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
 	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry (NULL: neither is used by this engine)
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
+	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
 	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1c does not cover
 	size_t untile_cap = 0;
 	// K1b hands the reads with a non-ACGTU byte and the batch tails to K1 as a list of slot ADDRESSES.  For device-resident
@@ -768,6 +769,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 	if (n_reads == 0) return 0;
 	const uint32_t k0 = e->klist[0];
 	if (read_len < k0) return 0; // no window (ntHashIterator.hpp:61-64)
+	if (!e->ts_ok && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
 	if (!e->ts_ok) {
 		// this configuration is served by K1 only: re-lay the batch out as row-major slots (exact; not a fast path)
 		const uint32_t stride = pick_stride(read_len, e->klist, e->gap);
@@ -941,6 +943,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		}
 	}
 	if (!e->d_t4) e->ts_ok = false;
+	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
 	e->hfk.resize(e->klist.size());
 	for (size_t ki = 0; ki < e->klist.size(); ++ki)
 		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki], (uint32_t)(ki * e->plane_elems()));

@@ -58,19 +58,20 @@ constexpr uint32_t kExpS0 = 0x47ff5554u; // idx 7:'G' 6:- 5:'U' 4:'T'
 constexpr uint32_t kExpS1 = 0x43ff41ffu; // idx 3:'C' 2:- 1:'A' 0:-
 
 // 16 raw bytes -> 32 bits (2 per base, code2 = (ascii >> 1) & 3: A=0 C=1 T/U=2 G=3, base q in bits 2q+1:2q);
-// dirty = 1 if some byte is not ACGTU/acgtu, else 0
-__device__ __forceinline__ uint32_t pack16(const v4u32 v, uint32_t& dirty)
+// bad != 0 iff some byte is not ACGTU/acgtu
+__device__ __forceinline__ uint32_t pack16(const v4u32 v, uint32_t& bad)
 {
+	// code2 of 4 bytes lands in the top byte of (w & 0x06060606) * 0x00820820 (fields 2 bits wide, no carries)
 	const uint32_t p0 = (v.x & 0x06060606u) * 0x00820820u, p1 = (v.y & 0x06060606u) * 0x00820820u;
 	const uint32_t p2 = (v.z & 0x06060606u) * 0x00820820u, p3 = (v.w & 0x06060606u) * 0x00820820u;
 	const uint32_t lo = perm(p1, p0, 0x0c0c0703u);
 	const uint32_t hi = perm(p3, p2, 0x07030c0cu);
+	// the letter (byte & 7) may stand for, XORed with the byte: zero (or the case bit) for a base letter
 	uint32_t x = perm(kExpS0, kExpS1, v.x & 0x07070707u) ^ v.x;
-	x |= perm(kExpS0, kExpS1, v.y & 0x07070707u) ^ v.y;
-	x |= perm(kExpS0, kExpS1, v.z & 0x07070707u) ^ v.z;
-	x |= perm(kExpS0, kExpS1, v.w & 0x07070707u) ^ v.w;
-	x &= 0xdfdfdfdfu;
-	dirty = (x | (0u - x)) >> 31;
+	x = (uint32_t)__builtin_amdgcn_bitop3_b32(perm(kExpS0, kExpS1, v.y & 0x07070707u), v.y, x, 0xbe); // (a ^ b) | c
+	x = (uint32_t)__builtin_amdgcn_bitop3_b32(perm(kExpS0, kExpS1, v.z & 0x07070707u), v.z, x, 0xbe);
+	x = (uint32_t)__builtin_amdgcn_bitop3_b32(perm(kExpS0, kExpS1, v.w & 0x07070707u), v.w, x, 0xbe);
+	bad = x & 0xdfdfdfdfu;
 	return lo | hi;
 }
 
@@ -137,6 +138,17 @@ __device__ __forceinline__ uint32_t ts_cand(const uint32_t (&S)[31])
 	else if constexpr (SB == 7) return ts_cand_s7(S);
 	else return ts_cand_s8(S);
 }
+template <int SB>
+__device__ __forceinline__ void ts_xplanes(const uint32_t (&S)[31], uint32_t& eqA, uint32_t& geA, uint32_t& eqB)
+{
+	if constexpr (SB == 2) ts_xplanes_s2(S, eqA, geA, eqB);
+	else if constexpr (SB == 3) ts_xplanes_s3(S, eqA, geA, eqB);
+	else if constexpr (SB == 4) ts_xplanes_s4(S, eqA, geA, eqB);
+	else if constexpr (SB == 5) ts_xplanes_s5(S, eqA, geA, eqB);
+	else if constexpr (SB == 6) ts_xplanes_s6(S, eqA, geA, eqB);
+	else if constexpr (SB == 7) ts_xplanes_s7(S, eqA, geA, eqB);
+	else ts_xplanes_s8(S, eqA, geA, eqB);
+}
 template <bool FWD>
 __device__ __forceinline__ void ts_warm(uint32_t (&S)[31], uint32_t i0, uint32_t i1)
 {
@@ -154,23 +166,26 @@ __device__ __forceinline__ void ts_main(uint32_t (&S)[31], uint32_t i0, uint32_t
 constexpr uint32_t kTile = kTileReads;
 constexpr uint32_t kRing = 5;            // packed chunks kept: a block's candidates need chunks n-2 .. n, the walkers are one ahead, and a fifth
                                          // slot lets A1 park a chunk before the block two behind is resolved (no copy held in registers)
-constexpr uint32_t kQCap = 512;          // candidate items per strand queue (power of two)
-constexpr uint32_t kLCap = 128;          // A2's private ring of words with bits left
-constexpr uint32_t kSCap = 128;          // suspects (candidates next to a dirty piece) waiting for their raw bytes
+constexpr uint32_t kQCap = 256;          // candidate items per strand queue (power of two)
+constexpr uint32_t kSCap = 320;          // suspects (candidates next to a dirty piece) waiting for their raw bytes: up to 256 join per pass
 constexpr uint32_t kDCap = 128;          // dirty pieces (A1 -> A2)
 constexpr uint32_t kOffPR = 0;                               // packed ring  [kRing][32][64] dwords
-constexpr uint32_t kOffPL = kOffPR + kRing * 8192u;          // plane slot   [8][64] x 16 B
+constexpr uint32_t kOffPL = kOffPR + kRing * 8192u;          // plane slot   [32][64] dwords
 constexpr uint32_t kOffDB = kOffPL + 8192u;                  // dirty words  [kRing][64] dwords
 constexpr uint32_t kOffQF = kOffDB + kRing * 256u;           // F queue      [kQCap + 64] x 8 B
 constexpr uint32_t kOffQR = kOffQF + (kQCap + 64u) * 8u;     // R queue
-constexpr uint32_t kOffLQ = kOffQR + (kQCap + 64u) * 8u;     // leftover ring [kLCap] x 8 B
-constexpr uint32_t kOffSQ = kOffLQ + kLCap * 8u;             // suspects     [kSCap] x 16 B
-constexpr uint32_t kOffDQ = kOffSQ + kSCap * 16u;            // dirty queue  [kDCap] x 8 B
-constexpr uint32_t kOffCT = kOffDQ + kDCap * 8u;             // control words
-constexpr uint32_t kTeamBytes = kOffCT + 128u;
-// control words (all monotonic)
-enum { C_PL_READY = 0, C_PL_TAKEN_F, C_PL_TAKEN_R, C_PR_READY, C_RESOLVED, C_QF_TAIL, C_QF_HEAD, C_QR_TAIL, C_QR_HEAD, C_BLK_F, C_BLK_R,
-       C_DQ_TAIL, C_DQ_HEAD, C_BT_F = 16 /* 8 words: F's queue tail at the end of block b & 7 */, C_BT_R = 24 };
+constexpr uint32_t kOffSQ = kOffQR + (kQCap + 64u) * 8u;     // suspects     [kSCap] x 8 B
+constexpr uint32_t kOffDQ = kOffSQ + kSCap * 8u;             // dirty queue  [kDCap] x 8 B
+constexpr uint32_t kOffXF = kOffDQ + kDCap * 8u;             // F's "top bits >= 01..1" planes of half a block [8][64] dwords
+constexpr uint32_t kOffXR = kOffXF + 2048u;                  // R's
+constexpr uint32_t kOffCT = kOffXR + 2048u;                  // control words
+constexpr uint32_t kTeamBytes = kOffCT + 256u;
+// control words (all monotonic).  Words that one wave reads together sit together: {BLK_F, QF_TAIL, BLK_R, QR_TAIL} is one
+// ds_read_b128 for A2, {PL_TAKEN_F, PL_TAKEN_R} one ds_read_b64 for A1, the block-end tails are {F, R} pairs.
+enum { C_BLK_F = 0, C_QF_TAIL = 1, C_BLK_R = 2, C_QR_TAIL = 3, C_PL_TAKEN_F = 4, C_PL_TAKEN_R = 5, C_PL_READY = 6, C_PR_READY = 7, C_RESOLVED = 8,
+       C_QF_HEAD = 9, C_QR_HEAD = 10, C_DQ_TAIL = 11, C_DQ_HEAD = 12,
+       C_XPUB_F = 13, C_XPUB_R = 14 /* half blocks whose planes are in the exchange area */, C_XCONS_F = 15 /* half blocks of R's planes F has read */,
+       C_XCONS_R = 32, C_BT = 16 /* 8 pairs: queue tails {F, R} at the end of block b & 7 */ };
 
 // Control words are read and written with explicit DS instructions: a `volatile` access through a generic pointer is
 // compiled to FLAT, and a FLAT store to LDS is not ordered against the DS writes before it (nor a FLAT load against the DS
@@ -186,12 +201,46 @@ __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p)
 	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
 	return rfl(v);
 }
+__device__ __forceinline__ uint2 lds_peek2(const uint32_t* p) // 8-byte aligned pair
+{
+	uint2 v;
+	asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+	return make_uint2(rfl(v.x), rfl(v.y));
+}
+__device__ __forceinline__ uint4 lds_peek4(const uint32_t* p) // 16-byte aligned quad
+{
+	v4u32 v;
+	asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+	return make_uint4(rfl(v.x), rfl(v.y), rfl(v.z), rfl(v.w));
+}
 // spin until *p >= v (wrapping compare)
 __device__ __forceinline__ void lds_wait_ge(const uint32_t* p, uint32_t v)
 {
 	while ((int32_t)(lds_peek(p) - v) < 0)
 		__builtin_amdgcn_s_sleep(1);
 }
+#ifdef TS_TIMERS // instrumentation build (tools/dbg): cycles per role and per wait site, summed over waves into a.dbg (uint64 [4][8])
+#define TS_T(var) const uint64_t var = __builtin_readcyclecounter()
+#define TS_ACC(slot, t0, t1) tacc[slot] += (t1) - (t0)
+#define TS_WAIT(slot, p, v)                          \
+	do {                                             \
+		const uint64_t w0__ = __builtin_readcyclecounter(); \
+		lds_wait_ge(p, v);                           \
+		tacc[slot] += __builtin_readcyclecounter() - w0__;  \
+	} while (0)
+#define TS_FLUSH(role)                                                                                            \
+	do {                                                                                                          \
+		tacc[0] = __builtin_readcyclecounter() - t_start;                                                         \
+		if (lane == 0 && a.dbg)                                                                                   \
+			for (int i = 0; i < 8; ++i)                                                                           \
+				atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg) + (role) * 8 + i, (unsigned long long)tacc[i]); \
+	} while (0)
+#else
+#define TS_T(var)
+#define TS_ACC(slot, t0, t1)
+#define TS_WAIT(slot, p, v) lds_wait_ge(p, v)
+#define TS_FLUSH(role)
+#endif
 
 } // namespace
 
@@ -214,10 +263,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		const uint4* src = reinterpret_cast<const uint4*>(a.t4);
 		for (uint32_t i = tid; i < t4_bytes / 16u; i += 512u)
 			reinterpret_cast<uint4*>(t4)[i] = src[i];
-		if (tid < 64) {
-			reinterpret_cast<uint32_t*>(smem + t4_bytes + 0u * kTeamBytes + kOffCT)[tid & 31] = 0;
-			reinterpret_cast<uint32_t*>(smem + t4_bytes + 1u * kTeamBytes + kOffCT)[tid & 31] = 0;
-		}
+		if (tid < 128) reinterpret_cast<uint32_t*>(smem + t4_bytes + (uint32_t)(tid >> 6) * kTeamBytes + kOffCT)[tid & 63] = 0;
 	}
 	__syncthreads(); // the only workgroup barrier: table and zeroed control words are in place
 	const uint32_t C = a.n_chunks;
@@ -225,6 +271,10 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 	const uint32_t n_teams = gridDim.x * 2u;
 	const uint32_t team_g = blockIdx.x * 2u + team;
 	const bool has_partial = (a.n_reads & (kTile - 1u)) != 0u;
+#ifdef TS_TIMERS
+	uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const uint64_t t_start = __builtin_readcyclecounter();
+#endif
 
 #ifndef TS_NO_A1
 	if (role == 2u) {
@@ -232,42 +282,62 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		uint32_t n = 0;
 		v4u32 raw[32];
 		const uint32_t voff = (uint32_t)lane * 16u;
-		auto issue = [&](uint32_t t, uint32_t c) {
-			// wave-uniform chunk base (scalar registers) + one 32-bit lane offset: global_load ... saddr, no 64-bit address per load
-			const unsigned char* p = a.tiles + ((size_t)t * C + c) * (size_t)(kTile * 16u);
+		// The chunk's 32 loads are BUFFER loads: resource descriptor of the chunk (scalar registers) + one 32-bit lane offset +
+		// scalar / immediate offsets.  As flat global loads the in-loop copy gets a 64-bit vector address per load (64 more
+		// registers, spills).  28 of them fly while the previous chunk is transposed and published, the last 4 are issued just
+		// before the chunk is packed and land while the first 28 are (16 registers less at the tightest point).
+		auto chunk_rsrc = [&](uint32_t t, uint32_t c) {
+			const unsigned char* p = a.tiles + ((size_t)rfl(t) * C + rfl(c)) * (size_t)(kTile * 16u);
+			return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p), 0, (int)(kTile * 16u), 0x00020000);
+		};
+		auto issue28 = [&](uint32_t t, uint32_t c) {
+			const __amdgpu_buffer_rsrc_t r = chunk_rsrc(t, c);
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const unsigned char* pj = p + (size_t)j * 4096u; // scalar add: keeps the immediate offsets within 12 bits
+			for (int j = 0; j < 7; ++j)
 #pragma unroll
 				for (int i = 0; i < 4; ++i)
-					raw[4 * j + i] = __builtin_nontemporal_load(reinterpret_cast<const v4u32*>(pj + (voff + (uint32_t)i * 1024u)));
-			}
+					raw[4 * j + i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + (uint32_t)i * 1024u, j * 4096, 2 /* slc: read once */);
+		};
+		auto issue4 = [&](uint32_t t, uint32_t c) {
+			const __amdgpu_buffer_rsrc_t r = chunk_rsrc(t, c);
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				raw[28 + i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + (uint32_t)i * 1024u, 7 * 4096, 2);
 		};
 		uint32_t dq_tail = 0;
 		// this team's chunks as one flat sequence (one load site: two of them cost the register allocator its plan)
 		const uint32_t my_tiles = team_g < a.n_tiles ? (a.n_tiles - team_g + n_teams - 1u) / n_teams : 0u;
 		const uint32_t total = my_tiles * C;
-		if (total != 0u) issue(team_g, 0);
+		if (total != 0u) issue28(team_g, 0u);
 		{
 			uint32_t t = team_g, seq = 0, c = 0;
 			for (; n < total; ++n) {
 				uint32_t P[32];
 				uint32_t dirtyword = 0;
+				TS_T(tloop);
+				issue4(t, c); // this chunk's last four loads
 #pragma unroll
-				for (int m = 0; m < 32; ++m) {
-					uint32_t d;
-					P[m] = pack16(raw[m], d);
-					dirtyword |= d << m;
+				for (int m = 0; m < 28; ++m) {
+					uint32_t bad;
+					P[m] = pack16(raw[m], bad);
+					dirtyword |= (bad != 0u ? 1u : 0u) << m;
+				}
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int m = 28; m < 32; ++m) {
+					uint32_t bad;
+					P[m] = pack16(raw[m], bad);
+					dirtyword |= (bad != 0u ? 1u : 0u) << m;
 				}
 				__builtin_amdgcn_sched_barrier(0);
 				// the next chunk's loads fly while this one is transposed and published
 				const bool last_c = c + 1u == C;
 				const uint32_t tn = last_c ? t + n_teams : t, cn = last_c ? 0u : c + 1u;
 				const bool more = n + 1u < total;
-				issue(more ? tn : t, more ? cn : c); // unconditional (a conditional load site makes all 128 registers a phi): the last one re-reads its chunk
+				issue28(more ? tn : t, more ? cn : c); // unconditional (a conditional load site makes all the registers a phi): the last one re-reads its chunk
 				__builtin_amdgcn_sched_barrier(0);
 				// the packed words overwrite chunk n - 5, which blocks <= n - 3 read: this wave is never that far ahead of A2 in practice
-				if (n >= 3u) lds_wait_ge(ctl + C_RESOLVED, n - 2u);
+				if (n >= 3u) TS_WAIT(1, ctl + C_RESOLVED, n - 2u);
 				const uint32_t slot = n % kRing;
 				{
 					uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
@@ -276,20 +346,35 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 						pr[m * 64] = P[m];
 					reinterpret_cast<uint32_t*>(tb + kOffDB)[slot * 64u + lane] = dirtyword;
 				}
+				TS_T(tt0);
 				transpose32(P); // P[2 q + b] = bit b of the code of base 16 c + q, one bit per read
-				lds_wait_ge(ctl + C_PL_TAKEN_F, n);
-				lds_wait_ge(ctl + C_PL_TAKEN_R, n);
+#ifdef TS_TIMERS
+				__builtin_amdgcn_sched_barrier(0);
 				{
-					v4u32* pl = reinterpret_cast<v4u32*>(tb + kOffPL) + lane;
+					uint32_t keep = 0;
 #pragma unroll
-					for (int g = 0; g < 8; ++g) {
-						v4u32 v;
-						v.x = P[4 * g];
-						v.y = P[4 * g + 1];
-						v.z = P[4 * g + 2];
-						v.w = P[4 * g + 3];
-						pl[g * 64] = v;
+					for (int m = 0; m < 32; ++m)
+						asm volatile("" : "+v"(P[m]));
+					(void)keep;
+				}
+#endif
+				TS_T(tt1);
+				TS_ACC(5, tt0, tt1);
+				{
+					TS_T(tk0);
+					while (true) {
+						const uint2 tk = lds_peek2(ctl + C_PL_TAKEN_F);
+						if ((int32_t)(tk.x - n) >= 0 && (int32_t)(tk.y - n) >= 0) break;
+						__builtin_amdgcn_s_sleep(1);
 					}
+					TS_T(tk1);
+					TS_ACC(2, tk0, tk1);
+				}
+				{
+					uint32_t* pl = reinterpret_cast<uint32_t*>(tb + kOffPL) + lane; // [plane][lane]: one conflict-free dword store per plane
+#pragma unroll
+					for (int j = 0; j < 32; ++j)
+						pl[j * 64] = P[j];
 				}
 				lds_publish(ctl + C_PL_READY, n + 1u);
 				const uint64_t dm = ballot(dirtyword != 0u);
@@ -308,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				c = cn;
 			}
 		}
+		TS_FLUSH(2);
 		return;
 	}
 
@@ -322,25 +408,36 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			const uint32_t* const c_head = ctl + (FWD ? C_QF_HEAD : C_QR_HEAD);
 			uint32_t qtail = 0, qhead_c = 0; // wave-uniform
 			uint32_t n = 0;
-			uint32_t meta_tile = 0;
+			uint32_t xhalf = 0; // half blocks of planes exchanged so far
+			uint32_t* const x_mine = reinterpret_cast<uint32_t*>(tb + (FWD ? kOffXF : kOffXR)) + lane;
+			const uint32_t* const x_other = reinterpret_cast<const uint32_t*>(tb + (FWD ? kOffXR : kOffXF)) + lane;
+			uint32_t* const x_pub_mine = ctl + (FWD ? C_XPUB_F : C_XPUB_R);
+			const uint32_t* const x_pub_other = ctl + (FWD ? C_XPUB_R : C_XPUB_F);
+			uint32_t* const x_cons_mine = ctl + (FWD ? C_XCONS_F : C_XCONS_R);
+			const uint32_t* const x_cons_other = ctl + (FWD ? C_XCONS_R : C_XCONS_F);
+			uint32_t meta_tile = 0, nb0 = 0; // nb0: ring slot of chunk 0 of the current tile
 			auto push = [&](uint32_t h, uint32_t w) { // h: bit m set <=> read 64 m + lane is a candidate at window w
 				// straight-line: lanes without a candidate store to their spare slot behind the queue
 				h = w < W ? h : 0u;
 				const uint64_t m = ballot(h != 0u);
 				const uint32_t slot = (qtail + mbcnt(m)) & (kQCap - 1u);
-				queue[h != 0u ? slot : kQCap + (uint32_t)lane] = make_uint2(h, meta_tile | (w << 11));
+				queue[h != 0u ? slot : kQCap + (uint32_t)lane] = make_uint2(h, meta_tile | (((nb0 + (w >> 4)) % kRing) << 8) | (w << 11)); // wave-uniform arithmetic
 				qtail = rfl(qtail + (uint32_t)__popcll(m));
 				if (__builtin_expect(qtail - qhead_c > kQCap - 64u, 0)) { // the next step may not fit: let A2 catch up
 					lds_publish(c_tail, qtail);
+					TS_T(tg0);
 					do {
 						qhead_c = lds_peek(c_head);
 						if (qtail - qhead_c <= kQCap - 64u) break;
 						__builtin_amdgcn_s_sleep(1);
 					} while (true);
+					TS_T(tg1);
+					TS_ACC(2, tg0, tg1);
 				}
 			};
 			for (uint32_t t = team_g, seq = 0; t < a.n_tiles; t += n_teams, ++seq) {
-				meta_tile = (uint32_t)lane | (FWD ? 0u : 64u) | ((has_partial && t == a.n_tiles - 1u) ? 128u : 0u) | (((seq * C) % kRing) << 8);
+				meta_tile = (uint32_t)lane | (FWD ? 0u : 64u) | ((has_partial && t == a.n_tiles - 1u) ? 128u : 0u);
+				nb0 = (seq * C) % kRing;
 				uint32_t S[31];
 #pragma unroll
 				for (int j = 0; j < 31; ++j)
@@ -354,20 +451,12 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll 1
 				for (uint32_t c = 0; c < C; ++c, ++n) {
 					uint32_t I[32];
-					lds_wait_ge(ctl + C_PL_READY, n + 1u);
+					TS_WAIT(1, ctl + C_PL_READY, n + 1u);
 					{
-						const v4u32* pl = reinterpret_cast<const v4u32*>(tb + kOffPL) + lane;
-						v4u32 v[8];
+						const uint32_t* pl = reinterpret_cast<const uint32_t*>(tb + kOffPL) + lane;
 #pragma unroll
-						for (int g = 0; g < 8; ++g)
-							v[g] = pl[g * 64];
-#pragma unroll
-						for (int g = 0; g < 8; ++g) {
-							I[4 * g] = v[g].x;
-							I[4 * g + 1] = v[g].y;
-							I[4 * g + 2] = v[g].z;
-							I[4 * g + 3] = v[g].w;
-						}
+						for (int j = 0; j < 32; ++j)
+							I[j] = pl[j * 64];
 					}
 					lds_publish(ctl + (FWD ? C_PL_TAKEN_F : C_PL_TAKEN_R), n + 1u);
 					if (c < (uint32_t)KB) { // window filling: no outgoing base; the last step completes window 0
@@ -378,12 +467,35 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 						}
 						if (c == (uint32_t)KB - 1u) push(ts_cand<SB>(S), 0u);
 					} else {
+						// Candidates with the other strand's help: a window is sampled through THIS strand iff its top bits carry a pattern and
+						// the other strand's are not smaller (gen_ts.py, emit_xplanes).  Each walker posts one plane per step (its top bits
+						// >= 01..1) and, every half block, combines its own equality planes with the other walker's: a third fewer
+						// candidates for the resolve stage than either strand's pattern alone.
 						const uint32_t w0 = 16u * c - (uint32_t)K + 1u;
 #pragma unroll
-						for (int q = 0; q < 16; ++q) {
-							ts_main<FWD>(S, I[2 * q], I[2 * q + 1], H[0][2 * q], H[0][2 * q + 1]);
-							pin31(S);
-							push(ts_cand<SB>(S), w0 + (uint32_t)q);
+						for (int hb = 0; hb < 2; ++hb) {
+							uint32_t eqA[8], eqB[8];
+							if (xhalf != 0u) lds_wait_ge(x_cons_other, xhalf); // the other walker has read my planes of the previous half block
+#pragma unroll
+							for (int q8 = 0; q8 < 8; ++q8) {
+								const int q = hb * 8 + q8;
+								ts_main<FWD>(S, I[2 * q], I[2 * q + 1], H[0][2 * q], H[0][2 * q + 1]);
+								pin31(S);
+								uint32_t ge;
+								ts_xplanes<SB>(S, eqA[q8], ge, eqB[q8]);
+								x_mine[q8 * 64] = ge;
+							}
+							++xhalf;
+							lds_publish(x_pub_mine, xhalf);
+							TS_WAIT(3, x_pub_other, xhalf);
+							uint32_t og[8];
+#pragma unroll
+							for (int q8 = 0; q8 < 8; ++q8)
+								og[q8] = x_other[q8 * 64];
+							lds_publish(x_cons_mine, xhalf); // (behind the reads above)
+#pragma unroll
+							for (int q8 = 0; q8 < 8; ++q8)
+								push((eqA[q8] & og[q8]) | eqB[q8], w0 + (uint32_t)(hb * 8 + q8));
 						}
 					}
 #pragma unroll
@@ -395,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					for (int i = 0; i < 32; ++i)
 						H[KB - 1][i] = I[i];
 					// block n is complete: its items end at qtail
-					lds_publish(ctl + (FWD ? C_BT_F : C_BT_R) + (n & 7u), qtail);
+					lds_publish(ctl + C_BT + 2u * (n & 7u) + (FWD ? 0u : 1u), qtail);
 					lds_publish(c_tail, qtail);
 					lds_publish(ctl + (FWD ? C_BLK_F : C_BLK_R), n + 1u);
 				}
@@ -403,6 +515,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		};
 		if (role == 0u) walk(std::true_type{});
 		else walk(std::false_type{});
+		TS_FLUSH(role);
 		return;
 	}
 
@@ -437,12 +550,10 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		};
 		const uint32_t* const pr = reinterpret_cast<const uint32_t*>(tb + kOffPR);
 		const uint32_t* const db = reinterpret_cast<const uint32_t*>(tb + kOffDB);
-		uint2* const qF = reinterpret_cast<uint2*>(tb + kOffQF);
-		uint2* const qR = reinterpret_cast<uint2*>(tb + kOffQR);
-		uint2* const lq = reinterpret_cast<uint2*>(tb + kOffLQ);
-		uint4* const sq = reinterpret_cast<uint4*>(tb + kOffSQ);
+		const uint2* const qF = reinterpret_cast<const uint2*>(tb + kOffQF);
+		uint2* const sq = reinterpret_cast<uint2*>(tb + kOffSQ);
 		const uint2* const dq = reinterpret_cast<const uint2*>(tb + kOffDQ);
-		uint32_t hF = 0, hR = 0, lq_head = 0, lq_fill = 0, sq_fill = 0, dq_head = 0; // wave-uniform
+		uint32_t hF = 0, hR = 0, sq_fill = 0, dq_head = 0; // wave-uniform
 		uint64_t f1_add = 0;  // wave-uniform: reads x windows
 		uint32_t f1_sub = 0;  // per lane: windows lost to non-ACGTU bytes
 		const uint32_t n_valid_last = has_partial ? (uint32_t)(a.n_reads & (kTile - 1u)) : kTile;
@@ -450,11 +561,12 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			return *reinterpret_cast<const v4u32*>(a.tiles + (((size_t)t * C + c) * kTile + r) * 16u);
 		};
 		// ---- suspects: candidates whose window touches a dirty piece; exact validity from the raw bytes ----
-		auto flush_suspects = [&]() {
+		auto flush_suspects = [&](uint32_t seq_now) { // entry: {counter index, read | window << 11 | (tile sequence number & 15) << 27}
 			for (uint32_t base = 0; base < sq_fill; base += 64u) {
 				const bool act = base + (uint32_t)lane < sq_fill;
-				const uint4 s = sq[act ? base + (uint32_t)lane : 0u];
-				const uint32_t r = s.y, w = s.z, t = s.w, c0 = w >> 4;
+				const uint2 s = sq[act ? base + (uint32_t)lane : 0u];
+				const uint32_t r = s.y & 2047u, w = (s.y >> 11) & 0xffffu, c0 = w >> 4;
+				const uint32_t t = team_g + (seq_now - ((seq_now - (s.y >> 27)) & 15u)) * n_teams; // taken at most a tile ago
 				uint32_t m0 = 0, m1 = 0, m2 = 0;
 				if (act) {
 					m0 = inv16(raw_piece(t, c0, r));
@@ -499,128 +611,278 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				lds_publish(ctl + C_DQ_HEAD, dq_head);
 			}
 		};
-		// ---- one round: up to 64 items -> full canonical hash -> ntComp -> log ----
-		auto round = [&](uint32_t nL, uint32_t nF, uint32_t nR, uint32_t t) {
-			const uint32_t cnt = nL + nF + nR;
-			const bool act = (uint32_t)lane < cnt;
-			uint2 it;
-			if ((uint32_t)lane < nL) it = lq[(lq_head + (uint32_t)lane) & (kLCap - 1u)];
-			else if ((uint32_t)lane < nL + nF) it = qF[(hF + (uint32_t)lane - nL) & (kQCap - 1u)];
-			else it = qR[(hR + (uint32_t)lane - nL - nF) & (kQCap - 1u)];
-			if (!act) it = make_uint2(0u, 0u);
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the items are in registers: their queue slots may be reused
-			lq_head += nL;
-			lq_fill -= nL;
+		// ---- resolve pass.  Every lane owns NI item SLOTS (registers): a slot holds one candidate word of some lane and step and
+		// gives up its lowest set bit (one read) per pass; an empty slot takes the next word from the strand queues.  One pass =
+		// up to 64 NI candidates: full canonical hash from the packed ring -> ntComp -> hit log.  The LDS round trips of a pass
+		// (items, packed words, table entries) are each issued for all NI slots at once: one wave has nobody to hide them behind ----
+		constexpr int NI = 4;
+		uint32_t sh_[NI], sm_[NI], sb_[NI]; // slot: candidate word, its meta word, the block it was taken in
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+			sh_[j] = sm_[j] = sb_[j] = 0;
+		auto pass = [&](uint32_t aF, uint32_t aR, uint32_t blk) { // aF / aR: words the queues may hand out now
+			// 1. refill the empty slots, in queue order: first from F, then from R.  Straight-line: a slot that takes nothing reads
+			// the queue's spare area
+			TS_T(pp0);
+			uint32_t idx[NI], base = 0;
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				const uint64_t fm = ballot(sh_[j] == 0u);
+				idx[j] = base + mbcnt(fm);
+				base += (uint32_t)__popcll(fm);
+			}
+			const uint32_t n_new = base < aF + aR ? base : aF + aR;
+			const uint32_t nF = n_new < aF ? n_new : aF, nR = n_new - nF;
+			uint2 nw[NI];
+			bool take[NI];
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				take[j] = sh_[j] == 0u && idx[j] < n_new;
+				const uint32_t iF = (hF + idx[j]) & (kQCap - 1u), iR = kQCap + 64u + ((hR + idx[j] - nF) & (kQCap - 1u)); // qR follows qF
+				const uint32_t i = idx[j] < nF ? iF : iR;
+				nw[j] = qF[take[j] ? i : kQCap + (uint32_t)lane];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				sh_[j] = take[j] ? nw[j].x : sh_[j];
+				sm_[j] = take[j] ? nw[j].y : sm_[j];
+				sb_[j] = take[j] ? blk : sb_[j];
+			}
 			hF += nF;
 			hR += nR;
-			if (nF) lds_publish(ctl + C_QF_HEAD, hF);
+			if (nF) lds_publish(ctl + C_QF_HEAD, hF); // (behind the item reads above)
 			if (nR) lds_publish(ctl + C_QR_HEAD, hR);
-			// words with more than one bit go back in line (private ring: at most 64 stay after a round that took them first)
-			const uint32_t rest = it.x & (it.x - 1u);
-			const uint64_t rm = ballot(rest != 0u);
-			if (rm != 0) {
-				if (rest != 0u) lq[(lq_head + lq_fill + mbcnt(rm)) & (kLCap - 1u)] = make_uint2(rest, it.y);
-				lq_fill += (uint32_t)__popcll(rm);
-			}
-			const uint32_t m = (uint32_t)__builtin_ctz(it.x | 0x80000000u);
-			const uint32_t l0 = it.y & 63u, w = it.y >> 11, nb = (it.y >> 8) & 7u;
-			const bool from_r = (it.y & 64u) != 0u;
-			const uint32_t r = m * 64u + l0;
-			const uint32_t c0 = w >> 4, sh = (w & 15u) * 2u;
-			const uint32_t col = m * 64u + l0;
-			const uint32_t s0 = (nb + c0) % kRing, s1 = s0 + 1u == kRing ? 0u : s0 + 1u, s2 = s1 + 1u == kRing ? 0u : s1 + 1u;
-			const uint32_t d0 = pr[s0 * 2048u + col], d1 = pr[s1 * 2048u + col], d2 = pr[s2 * 2048u + col];
-			// dirty words of the pieces the window touches (the third only when the window is not chunk-aligned)
-			const uint32_t dd = (db[s0 * 64u + l0] | db[s1 * 64u + l0] | (sh != 0u ? db[s2 * 64u + l0] : 0u)) >> m;
-			uint32_t toff[K / 4];
+			// 2. one candidate per slot: packed words + dirty words of the pieces its window touches
+			TS_T(pp1);
+			TS_ACC(5, pp0, pp1);
+			uint32_t d0[NI], d1[NI], d2[NI], db0[NI], db1[NI], db2[NI], rr[NI], ww[NI], mm[NI];
+			bool act[NI];
 #pragma unroll
-			for (int i = 0; i < KB; ++i) {
-				const uint32_t x = i == 0 ? alignbit(d1, d0, sh) : alignbit(d2, d1, sh); // 16 bases of the window
-#pragma unroll
-				for (int g = 0; g < 4; ++g)
-					toff[i * 4 + g] = (uint32_t)(i * 4 + g) * 4096u + ((x >> (8 * g)) & 0xffu) * 16u;
+			for (int j = 0; j < NI; ++j) {
+				const uint32_t h = sh_[j], y = sm_[j];
+				act[j] = h != 0u;
+				const uint32_t m = (uint32_t)__builtin_ctz(h | 0x80000000u);
+				sh_[j] = h & (h - 1u);
+				const uint32_t l0 = y & 63u, s0 = (y >> 8) & 7u;
+				const uint32_t col = m * 64u + l0;
+				const uint32_t s1 = s0 + 1u == kRing ? 0u : s0 + 1u, s2 = s1 + 1u == kRing ? 0u : s1 + 1u;
+				d0[j] = pr[s0 * 2048u + col];
+				d1[j] = pr[s1 * 2048u + col];
+				d2[j] = pr[s2 * 2048u + col];
+				db0[j] = db[s0 * 64u + l0];
+				db1[j] = db[s1 * 64u + l0];
+				db2[j] = db[s2 * 64u + l0];
+				rr[j] = col;
+				ww[j] = y >> 11;
+				mm[j] = m;
 			}
 			__builtin_amdgcn_sched_barrier(0);
-			v4u32 tv[K / 4];
+			// 3. closed form, 4 bases per lookup: all table addresses, then all lookups in flight together, then the XORs
+			uint32_t toff[NI][K / 4];
 #pragma unroll
-			for (int j = 0; j < K / 4; ++j)
-				tv[j] = *reinterpret_cast<const v4u32*>(t4 + toff[j]);
-			__builtin_amdgcn_sched_barrier(0);
-			uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+			for (int j = 0; j < NI; ++j) {
+				const uint32_t sh = (ww[j] & 15u) * 2u;
 #pragma unroll
-			for (int j = 0; j < K / 4; ++j) {
-				flo ^= tv[j].x;
-				fhi ^= tv[j].y;
-				rlo ^= tv[j].z;
-				rhi ^= tv[j].w;
-			}
-			const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
-			const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
-			// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
-			const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
-			const bool c0m = (hi >> (31 - s_bits)) == 1u;
-			// the candidate of the canonical strand only (both strands may have flagged the window)
-			bool hit = act & (rev == from_r) & (c0m | c1);
-			if ((it.y & 128u) != 0u) hit &= r < n_valid_last; // slots behind the last read of the batch
-			const uint32_t key = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
-			const bool suspect = hit & ((dd & 1u) != 0u);
-			const uint64_t sm = ballot(suspect);
-			if (sm != 0) { // rare: the window touches a 16-byte piece with a non-ACGTU byte somewhere
-				if (suspect) sq[sq_fill + mbcnt(sm)] = make_uint4(key, r, w, t);
-				sq_fill += (uint32_t)__popcll(sm);
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				if (sq_fill > kSCap - 64u) flush_suspects();
-			}
-#ifdef TS_DEBUG
-			if (act && a.dbg) {
-				const uint32_t idx = atomicAdd(a.dbg, 1u);
-				uint32_t* o = a.dbg + 16 + 12 * (size_t)idx;
-				o[0] = r; o[1] = w; o[2] = it.x; o[3] = it.y; o[4] = d0; o[5] = d1; o[6] = d2; o[7] = flo; o[8] = fhi; o[9] = rlo; o[10] = rhi;
-				o[11] = (rev ? 1u : 0u) | (from_r ? 2u : 0u) | (hit ? 4u : 0u);
-			}
-#endif
-			log_emit(hit & !suspect, key);
-		};
-		uint32_t n_res = 0;
-		for (uint32_t t = team_g, seq = 0; t < a.n_tiles; t += n_teams, ++seq) {
-			for (uint32_t c = 0; c < C; ++c, ++n_res) {
-				while ((int32_t)(lds_peek(ctl + C_PR_READY) - (n_res + 1u)) < 0) { // A1 may be waiting for room in the dirty queue
-					drain_dirty(t, seq);
-					__builtin_amdgcn_s_sleep(1);
+				for (int i = 0; i < KB; ++i) {
+					const uint32_t x = i == 0 ? alignbit(d1[j], d0[j], sh) : alignbit(d2[j], d1[j], sh); // 16 bases of the window
+#pragma unroll
+					for (int g = 0; g < 4; ++g)
+						toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
 				}
-				while (true) {
-					// block counters first, then tails: a tail read after "block complete" covers the whole block
-					const uint32_t bF = lds_peek(ctl + C_BLK_F), bR = lds_peek(ctl + C_BLK_R);
-					const bool doneF = (int32_t)(bF - (n_res + 1u)) >= 0, doneR = (int32_t)(bR - (n_res + 1u)) >= 0;
-					const uint32_t tF = doneF ? lds_peek(ctl + C_BT_F + (n_res & 7u)) : lds_peek(ctl + C_QF_TAIL);
-					const uint32_t tR = doneR ? lds_peek(ctl + C_BT_R + (n_res & 7u)) : lds_peek(ctl + C_QR_TAIL);
-					const uint32_t aF = tF - hF, aR = tR - hR;
-					const uint32_t avail = lq_fill + aF + aR;
-					const bool complete = doneF & doneR;
-					if (avail >= 64u || (complete && avail != 0u)) {
-						const uint32_t nL = lq_fill < 64u ? lq_fill : 64u;
-						const uint32_t nF = aF < 64u - nL ? aF : 64u - nL;
-						const uint32_t nR = aR < 64u - nL - nF ? aR : 64u - nL - nF;
-						round(nL, nF, nR, t);
-					} else if (complete) {
-						break;
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			v4u32 tv[NI][K / 4];
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+#pragma unroll
+				for (int i = 0; i < K / 4; ++i)
+					tv[j][i] = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)i * 4096u + toff[j][i]); // the group's 4 KiB rides in the offset field
+			__builtin_amdgcn_sched_barrier(0);
+			TS_T(pp2);
+			TS_ACC(6, pp1, pp2);
+			bool hit[NI];
+			uint32_t key[NI];
+			uint64_t hm[NI];
+			uint32_t total = 0;
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				static_assert(K / 4 == 8, "XOR tree below is written for 8 table entries");
+				auto x3 = [](uint32_t p, uint32_t q, uint32_t r) { return (uint32_t)__builtin_amdgcn_bitop3_b32(p, q, r, 0x96); };
+				const uint32_t flo = x3(x3(tv[j][0].x, tv[j][1].x, tv[j][2].x), x3(tv[j][3].x, tv[j][4].x, tv[j][5].x), tv[j][6].x ^ tv[j][7].x);
+				const uint32_t fhi = x3(x3(tv[j][0].y, tv[j][1].y, tv[j][2].y), x3(tv[j][3].y, tv[j][4].y, tv[j][5].y), tv[j][6].y ^ tv[j][7].y);
+				const uint32_t rlo = x3(x3(tv[j][0].z, tv[j][1].z, tv[j][2].z), x3(tv[j][3].z, tv[j][4].z, tv[j][5].z), tv[j][6].z ^ tv[j][7].z);
+				const uint32_t rhi = x3(x3(tv[j][0].w, tv[j][1].w, tv[j][2].w), x3(tv[j][3].w, tv[j][4].w, tv[j][5].w), tv[j][6].w ^ tv[j][7].w);
+				const uint64_t fh = ((uint64_t)fhi << 32) | flo, rh = ((uint64_t)rhi << 32) | rlo;
+				const bool rev = rh < fh; // nthash.hpp:275-279
+				const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
+				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+				const bool c0m = (hi >> (31 - s_bits)) == 1u;
+				const uint32_t y = sm_[j];
+				// the candidate of the canonical strand only (both strands may have flagged the window)
+				bool ht = act[j] & (rev == ((y & 64u) != 0u)) & (c0m | c1);
+				if (has_partial) ht &= (y & 128u) == 0u || rr[j] < n_valid_last; // slots behind the last read of the batch
+				key[j] = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
+				// the third piece only counts when the window is not chunk-aligned
+				const uint32_t dd = (db0[j] | db1[j] | ((ww[j] & 15u) != 0u ? db2[j] : 0u)) >> mm[j];
+				const bool suspect = ht & ((dd & 1u) != 0u);
+				const uint64_t sm = ballot(suspect);
+				if (sm != 0) { // rare: the window touches a 16-byte piece with a non-ACGTU byte somewhere
+					if (suspect) sq[sq_fill + mbcnt(sm)] = make_uint2(key[j], rr[j] | (ww[j] << 11) | (((sb_[j] / C) & 15u) << 27)); // + the tile of the block the word was taken in
+					sq_fill += (uint32_t)__popcll(sm);
+				}
+#ifdef TS_DEBUG
+				if (act[j] && a.dbg) {
+					const uint32_t ix = atomicAdd(a.dbg, 1u);
+					uint32_t* o = a.dbg + 16 + 12 * (size_t)ix;
+					o[0] = rr[j]; o[1] = ww[j]; o[2] = 0; o[3] = sm_[j]; o[4] = d0[j]; o[5] = d1[j]; o[6] = d2[j]; o[7] = flo; o[8] = fhi; o[9] = rlo; o[10] = rhi;
+					o[11] = (rev ? 1u : 0u) | ((y & 64u) ? 2u : 0u) | (ht ? 4u : 0u);
+				}
+#endif
+				hit[j] = ht & !suspect;
+				hm[j] = ballot(hit[j]);
+				total += (uint32_t)__popcll(hm[j]);
+			}
+			// 4. one log append for the pass (ntComp's increment, deferred: ntc_apply.hip)
+			TS_T(pp3);
+			TS_ACC(7, pp2, pp3);
+			if (total != 0u) {
+				if (!use_log) {
+#pragma unroll
+					for (int j = 0; j < NI; ++j)
+						if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
+				} else {
+					while (lreg < a.log_regions && total > a.log_region_cap - lfill) {
+						if (lane == 0) a.log_fill[lreg] = lfill;
+						lreg += n_teams;
+						lfill = lreg < a.log_regions ? rfl(a.log_fill[lreg]) : 0u;
+					}
+					if (lreg < a.log_regions) {
+						uint32_t* dst = a.log + (uint64_t)lreg * a.log_region_cap + lfill;
+						uint32_t off = 0;
+#pragma unroll
+						for (int j = 0; j < NI; ++j) {
+							if (hit[j]) dst[off + mbcnt(hm[j])] = key[j];
+							off += (uint32_t)__popcll(hm[j]);
+						}
+						lfill += total;
 					} else {
-						drain_dirty(t, seq);
-						__builtin_amdgcn_s_sleep(1);
+#pragma unroll
+						for (int j = 0; j < NI; ++j)
+							if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
 					}
 				}
-				lds_publish(ctl + C_RESOLVED, n_res + 1u);
 			}
-			drain_dirty(t, seq); // every piece of tile t is in the queue by now (and perhaps the first of the next tile)
-			f1_add += (uint64_t)((has_partial && t == a.n_tiles - 1u) ? n_valid_last : kTile) * W;
+			if (sq_fill > kSCap - 64u * NI) {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				flush_suspects(blk / C);
+			}
+		};
+		auto slots_busy = [&]() {
+			bool any = false;
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+				any |= sh_[j] != 0u;
+			return ballot(any) != 0;
+		};
+		auto slots_from = [&](uint32_t blk) { // some slot still holds a word taken in block `blk`
+			bool any = false;
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+				any |= sh_[j] != 0u && sb_[j] == blk;
+			return ballot(any) != 0;
+		};
+		// Blocks are TAKEN in order (cur: every word of the blocks before it has left the queues) and RESOLVED in order (res: no
+		// slot holds a word of a block before it; published: A1 may reuse the ring slots those blocks read).  A word with several
+		// bits stays in its slot over several passes, also across block boundaries; whenever this wave would otherwise wait it
+		// runs a pass for the slots alone, so `res` never trails for want of new candidates.
+		uint32_t cur = 0, res = 0;
+		uint32_t t = team_g, seq = 0, c = 0;     // tile, its sequence number, chunk of block `cur`
+		bool all_taken = team_g >= a.n_tiles;     // every block of every tile of this team has left the queues
+		bool ring_ok = false, doneF = false, doneR = false;
+		uint32_t limF = 0, limR = 0;
+		while (true) { // one loop, one call site of pass() (inlined several times it spills a hundred scalar registers)
+			bool run = false;
+			uint32_t aF = 0, aR = 0;
+			if (all_taken) {
+				if (!slots_busy()) break;
+				run = true;
+			} else if (!ring_ok) {
+				TS_T(ta0);
+				ring_ok = (int32_t)(lds_peek(ctl + C_PR_READY) - (cur + 1u)) >= 0; // the packed words of this block's chunk
+				if (!ring_ok) {
+					drain_dirty(t, seq); // A1 may be waiting for room in the dirty queue
+					run = slots_busy();
+					if (!run) __builtin_amdgcn_s_sleep(1);
+				}
+				TS_T(ta1);
+				TS_ACC(1, ta0, ta1);
+			}
+			if (ring_ok) {
+				if (!(doneF & doneR) && (limF - hF) + (limR - hR) < 64u * NI) {
+					// block counters and tails in one read; a tail read together with "block complete" may already hold words of
+					// later blocks, whose chunks are not in the ring yet: then the tail noted at the end of the block counts
+					const uint4 q = lds_peek4(ctl + C_BLK_F);
+					doneF = (int32_t)(q.x - (cur + 1u)) >= 0;
+					doneR = (int32_t)(q.z - (cur + 1u)) >= 0;
+					limF = q.y;
+					limR = q.w;
+					if (doneF | doneR) {
+						const uint2 bt = lds_peek2(ctl + C_BT + 2u * (cur & 7u));
+						if (doneF) limF = bt.x;
+						if (doneR) limR = bt.y;
+					}
+				}
+				aF = limF - hF;
+				aR = limR - hR;
+				const bool complete = doneF & doneR;
+				if (aF + aR >= 64u || (complete && aF + aR != 0u)) {
+					run = true;
+				} else if (complete) { // every word of block cur has left the queues (some may still sit in slots): next block
+					++cur;
+					ring_ok = doneF = doneR = false;
+					if (++c == C) {
+						drain_dirty(t, seq); // every piece of tile t is in the queue by now (and perhaps the first of the next tile)
+						f1_add += (uint64_t)((has_partial && t == a.n_tiles - 1u) ? n_valid_last : kTile) * W;
+						c = 0;
+						++seq;
+						t += n_teams;
+						all_taken = t >= a.n_tiles;
+					}
+				} else {
+					TS_T(ti0);
+					drain_dirty(t, seq);
+					run = slots_busy();
+					if (!run) __builtin_amdgcn_s_sleep(1);
+					TS_T(ti1);
+					TS_ACC(2, ti0, ti1);
+				}
+			}
+			if (run) {
+				TS_T(tr0);
+				pass(aF, aR, cur);
+				TS_T(tr1);
+				TS_ACC(3, tr0, tr1);
+#ifdef TS_TIMERS
+				tacc[4] += 1;
+#endif
+			}
+			// blocks before `cur` are resolved once no slot holds a word of theirs
+			while (res < cur && !slots_from(res)) {
+				++res;
+				lds_publish(ctl + C_RESOLVED, res);
+			}
 		}
-		flush_suspects();
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		flush_suspects(seq);
 		if (use_log && lane == 0 && lreg < a.log_regions) a.log_fill[lreg] = lfill;
 		// F1 (ntcard.cpp:154): one per window without a non-ACGTU byte
 		uint32_t sub = f1_sub;
 		for (int o = 32; o > 0; o >>= 1)
 			sub += (uint32_t)__shfl_xor((int)sub, o);
 		if (lane == 0 && f1_add != 0) atomicAdd(a.f1, (unsigned long long)(f1_add - sub));
+		TS_FLUSH(3);
 	}
 #endif
 }

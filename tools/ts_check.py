@@ -26,7 +26,7 @@ dev = torch.device("cuda:0")
 
 def check_reads(reads, L, k=32, r_bits=18, s_bits=7, tag="", flags=0):
     tiles = torch.from_numpy(nt.tile_reads(reads, L)).to(dev)
-    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, device=0, flags=flags) as e:
+    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, device=0, flags=flags | nt.FLAG_REQUIRE_TILED) as e:
         e.submit_tiled_device(tiles.data_ptr(), len(reads), L)
         tc, ph, f1 = e.finish(counters=True)
     oc, of1 = orc.sketch_reads(reads, [k], 0, r_bits, s_bits)
@@ -85,7 +85,7 @@ if not args.no_perf:
         nt.gen_reads_tiled_device(b.data_ptr(), 1, s * R, R, L, dist, 100_000_000)
         bufs.append(b)
     torch.cuda.synchronize()
-    with nt.Engine([32], r_bits=27, s_bits=7, device=0) as e:
+    with nt.Engine([32], r_bits=27, s_bits=7, device=0, flags=nt.FLAG_REQUIRE_TILED) as e:
         for _ in range(2):
             e.submit_tiled_device(bufs[0].data_ptr(), R, L)
         e.flush()
