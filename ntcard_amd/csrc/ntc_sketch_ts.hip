@@ -127,6 +127,19 @@ __device__ __forceinline__ void pin31(uint32_t (&X)[31])
 	asm volatile("" : "+v"(X[21]), "+v"(X[22]), "+v"(X[23]), "+v"(X[24]), "+v"(X[25]), "+v"(X[26]), "+v"(X[27]), "+v"(X[28]), "+v"(X[29]), "+v"(X[30]));
 }
 
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS round trip, no scalar dependency)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
+{
+	uint32_t s = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);              // row_shr:2
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);              // row_shr:3
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, false);              // row_shr:4, banks 1-3
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, false);              // row_shr:8, banks 2-3
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false);              // row_bcast:15 -> rows 1, 3
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);              // row_bcast:31 -> rows 2, 3
+	return s;
+}
+
 template <int SB>
 __device__ __forceinline__ uint32_t ts_cand(const uint32_t (&S)[31])
 {
@@ -337,7 +350,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				issue28(more ? tn : t, more ? cn : c); // unconditional (a conditional load site makes all the registers a phi): the last one re-reads its chunk
 				__builtin_amdgcn_sched_barrier(0);
 				// the packed words overwrite chunk n - 5, which blocks <= n - 3 read: this wave is never that far ahead of A2 in practice
+#ifndef TS_EXP_A1_FREE
 				if (n >= 3u) TS_WAIT(1, ctl + C_RESOLVED, n - 2u);
+#endif
 				const uint32_t slot = n % kRing;
 				{
 					uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
@@ -360,6 +375,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #endif
 				TS_T(tt1);
 				TS_ACC(5, tt0, tt1);
+#ifndef TS_EXP_A1_FREE
 				{
 					TS_T(tk0);
 					while (true) {
@@ -370,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					TS_T(tk1);
 					TS_ACC(2, tk0, tk1);
 				}
+#endif
 				{
 					uint32_t* pl = reinterpret_cast<uint32_t*>(tb + kOffPL) + lane; // [plane][lane]: one conflict-free dword store per plane
 #pragma unroll
@@ -418,6 +435,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			uint32_t meta_tile = 0, nb0 = 0; // nb0: ring slot of chunk 0 of the current tile
 			auto push = [&](uint32_t h, uint32_t w) { // h: bit m set <=> read 64 m + lane is a candidate at window w
 				// straight-line: lanes without a candidate store to their spare slot behind the queue
+#ifdef TS_EXP_NOPUSH
+				h = 0u;
+#endif
 				h = w < W ? h : 0u;
 				const uint64_t m = ballot(h != 0u);
 				const uint32_t slot = (qtail + mbcnt(m)) & (kQCap - 1u);
@@ -620,29 +640,56 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll
 		for (int j = 0; j < NI; ++j)
 			sh_[j] = sm_[j] = sb_[j] = 0;
-		auto pass = [&](uint32_t aF, uint32_t aR, uint32_t blk) { // aF / aR: words the queues may hand out now
-			// 1. refill the empty slots, in queue order: first from F, then from R.  Straight-line: a slot that takes nothing reads
-			// the queue's spare area
-			TS_T(pp0);
-			uint32_t idx[NI], base = 0;
+		// A pass is software-pipelined over two batches of 64 NI candidates: the FRONT of batch b + 1 (refill the slots, take one
+		// candidate per slot, fetch its packed and dirty words from the ring) runs between the table-address arithmetic and the
+		// table look-ups of the BACK of batch b (closed form -> canonical hash -> ntComp -> log), so that one LDS round trip per
+		// pass is exposed instead of three.  pd*/pm*: the batch whose words are fetched and whose back is still to run.
+		uint32_t pd0[NI], pd1[NI], pd2[NI], pb0[NI], pb1[NI], pb2[NI], prr[NI], pww[NI], pmm[NI], pyy[NI], psb[NI];
+		bool pend = false; // wave-uniform: the p* batch holds candidates
 #pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const uint64_t fm = ballot(sh_[j] == 0u);
-				idx[j] = base + mbcnt(fm);
-				base += (uint32_t)__popcll(fm);
-			}
-			const uint32_t n_new = base < aF + aR ? base : aF + aR;
+		for (int j = 0; j < NI; ++j)
+			pd0[j] = pd1[j] = pd2[j] = pb0[j] = pb1[j] = pb2[j] = prr[j] = pww[j] = pmm[j] = pyy[j] = psb[j] = 0;
+		auto pass = [&](uint32_t aF, uint32_t aR, uint32_t blk) { // aF / aR: words the queues may hand out now
+			// Few scalar round trips on purpose: a lone wave pays ~20 clk for every vector compare whose mask a scalar instruction
+			// then reads (ballot, branch), so slot and log positions come from DPP prefix sums instead of ballot + mbcnt per slot.
+			// F1. refill the empty slots from the queues (first F, then R): free slot number x of the wave takes word x.  Straight-line:
+			// a slot that takes nothing reads the queue's spare area
+			uint32_t nfree = 0;
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+				nfree += sh_[j] == 0u ? 1u : 0u;
+			const uint32_t fincl = wave_scan(nfree);
+			const uint32_t n_free = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
+			const uint32_t n_new = n_free < aF + aR ? n_free : aF + aR;
 			const uint32_t nF = n_new < aF ? n_new : aF, nR = n_new - nF;
 			uint2 nw[NI];
 			bool take[NI];
+			uint32_t ix = fincl - nfree;
 #pragma unroll
 			for (int j = 0; j < NI; ++j) {
-				take[j] = sh_[j] == 0u && idx[j] < n_new;
-				const uint32_t iF = (hF + idx[j]) & (kQCap - 1u), iR = kQCap + 64u + ((hR + idx[j] - nF) & (kQCap - 1u)); // qR follows qF
-				const uint32_t i = idx[j] < nF ? iF : iR;
+				const bool fr = sh_[j] == 0u;
+				take[j] = fr && ix < n_new;
+				const uint32_t iF = (hF + ix) & (kQCap - 1u), iR = kQCap + 64u + ((hR + ix - nF) & (kQCap - 1u)); // qR follows qF
+				const uint32_t i = ix < nF ? iF : iR;
 				nw[j] = qF[take[j] ? i : kQCap + (uint32_t)lane];
+				ix += fr ? 1u : 0u;
 			}
 			__builtin_amdgcn_sched_barrier(0);
+			// B1. (previous batch) closed form, 4 bases per lookup: the table addresses
+			uint32_t toff[NI][K / 4];
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				const uint32_t sh = (pww[j] & 15u) * 2u;
+#pragma unroll
+				for (int i = 0; i < KB; ++i) {
+					const uint32_t x = i == 0 ? alignbit(pd1[j], pd0[j], sh) : alignbit(pd2[j], pd1[j], sh); // 16 bases of the window
+#pragma unroll
+					for (int g = 0; g < 4; ++g)
+						toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			// F2. the new words are here: one candidate per slot, its packed words + the dirty words of the pieces its window touches
 #pragma unroll
 			for (int j = 0; j < NI; ++j) {
 				sh_[j] = take[j] ? nw[j].x : sh_[j];
@@ -653,15 +700,12 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			hR += nR;
 			if (nF) lds_publish(ctl + C_QF_HEAD, hF); // (behind the item reads above)
 			if (nR) lds_publish(ctl + C_QR_HEAD, hR);
-			// 2. one candidate per slot: packed words + dirty words of the pieces its window touches
-			TS_T(pp1);
-			TS_ACC(5, pp0, pp1);
-			uint32_t d0[NI], d1[NI], d2[NI], db0[NI], db1[NI], db2[NI], rr[NI], ww[NI], mm[NI];
-			bool act[NI];
+			uint32_t d0[NI], d1[NI], d2[NI], b0[NI], b1[NI], b2[NI], rr[NI], ww[NI], mm[NI], yy[NI], tb_[NI];
+			uint32_t any_new = 0;
 #pragma unroll
 			for (int j = 0; j < NI; ++j) {
 				const uint32_t h = sh_[j], y = sm_[j];
-				act[j] = h != 0u;
+				any_new |= h;
 				const uint32_t m = (uint32_t)__builtin_ctz(h | 0x80000000u);
 				sh_[j] = h & (h - 1u);
 				const uint32_t l0 = y & 63u, s0 = (y >> 8) & 7u;
@@ -670,121 +714,133 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				d0[j] = pr[s0 * 2048u + col];
 				d1[j] = pr[s1 * 2048u + col];
 				d2[j] = pr[s2 * 2048u + col];
-				db0[j] = db[s0 * 64u + l0];
-				db1[j] = db[s1 * 64u + l0];
-				db2[j] = db[s2 * 64u + l0];
+				b0[j] = db[s0 * 64u + l0];
+				b1[j] = db[s1 * 64u + l0];
+				b2[j] = db[s2 * 64u + l0];
 				rr[j] = col;
 				ww[j] = y >> 11;
 				mm[j] = m;
+				yy[j] = h != 0u ? y | 0x80000000u : 0u; // bit 31: the slot holds a candidate (a window index never reaches 2^20)
+				tb_[j] = sb_[j];
 			}
 			__builtin_amdgcn_sched_barrier(0);
-			// 3. closed form, 4 bases per lookup: all table addresses, then all lookups in flight together, then the XORs
-			uint32_t toff[NI][K / 4];
+			// B2. (previous batch) all look-ups in flight together, then the XORs
+			uint32_t nhit = 0, anysus = 0;
+			uint32_t hit[NI], key[NI], sus[NI]; // 0 / 1
+			if (pend) {
+				v4u32 tv[NI][K / 4];
 #pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const uint32_t sh = (ww[j] & 15u) * 2u;
+				for (int j = 0; j < NI; ++j)
 #pragma unroll
-				for (int i = 0; i < KB; ++i) {
-					const uint32_t x = i == 0 ? alignbit(d1[j], d0[j], sh) : alignbit(d2[j], d1[j], sh); // 16 bases of the window
-#pragma unroll
-					for (int g = 0; g < 4; ++g)
-						toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
-				}
-			}
-			__builtin_amdgcn_sched_barrier(0);
-			v4u32 tv[NI][K / 4];
-#pragma unroll
-			for (int j = 0; j < NI; ++j)
-#pragma unroll
-				for (int i = 0; i < K / 4; ++i)
-					tv[j][i] = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)i * 4096u + toff[j][i]); // the group's 4 KiB rides in the offset field
-			__builtin_amdgcn_sched_barrier(0);
-			TS_T(pp2);
-			TS_ACC(6, pp1, pp2);
-			bool hit[NI];
-			uint32_t key[NI];
-			uint64_t hm[NI];
-			uint32_t total = 0;
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				static_assert(K / 4 == 8, "XOR tree below is written for 8 table entries");
-				auto x3 = [](uint32_t p, uint32_t q, uint32_t r) { return (uint32_t)__builtin_amdgcn_bitop3_b32(p, q, r, 0x96); };
-				const uint32_t flo = x3(x3(tv[j][0].x, tv[j][1].x, tv[j][2].x), x3(tv[j][3].x, tv[j][4].x, tv[j][5].x), tv[j][6].x ^ tv[j][7].x);
-				const uint32_t fhi = x3(x3(tv[j][0].y, tv[j][1].y, tv[j][2].y), x3(tv[j][3].y, tv[j][4].y, tv[j][5].y), tv[j][6].y ^ tv[j][7].y);
-				const uint32_t rlo = x3(x3(tv[j][0].z, tv[j][1].z, tv[j][2].z), x3(tv[j][3].z, tv[j][4].z, tv[j][5].z), tv[j][6].z ^ tv[j][7].z);
-				const uint32_t rhi = x3(x3(tv[j][0].w, tv[j][1].w, tv[j][2].w), x3(tv[j][3].w, tv[j][4].w, tv[j][5].w), tv[j][6].w ^ tv[j][7].w);
-				const uint64_t fh = ((uint64_t)fhi << 32) | flo, rh = ((uint64_t)rhi << 32) | rlo;
-				const bool rev = rh < fh; // nthash.hpp:275-279
-				const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
-				// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
-				const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
-				const bool c0m = (hi >> (31 - s_bits)) == 1u;
-				const uint32_t y = sm_[j];
-				// the candidate of the canonical strand only (both strands may have flagged the window)
-				bool ht = act[j] & (rev == ((y & 64u) != 0u)) & (c0m | c1);
-				if (has_partial) ht &= (y & 128u) == 0u || rr[j] < n_valid_last; // slots behind the last read of the batch
-				key[j] = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
-				// the third piece only counts when the window is not chunk-aligned
-				const uint32_t dd = (db0[j] | db1[j] | ((ww[j] & 15u) != 0u ? db2[j] : 0u)) >> mm[j];
-				const bool suspect = ht & ((dd & 1u) != 0u);
-				const uint64_t sm = ballot(suspect);
-				if (sm != 0) { // rare: the window touches a 16-byte piece with a non-ACGTU byte somewhere
-					if (suspect) sq[sq_fill + mbcnt(sm)] = make_uint2(key[j], rr[j] | (ww[j] << 11) | (((sb_[j] / C) & 15u) << 27)); // + the tile of the block the word was taken in
-					sq_fill += (uint32_t)__popcll(sm);
-				}
-#ifdef TS_DEBUG
-				if (act[j] && a.dbg) {
-					const uint32_t ix = atomicAdd(a.dbg, 1u);
-					uint32_t* o = a.dbg + 16 + 12 * (size_t)ix;
-					o[0] = rr[j]; o[1] = ww[j]; o[2] = 0; o[3] = sm_[j]; o[4] = d0[j]; o[5] = d1[j]; o[6] = d2[j]; o[7] = flo; o[8] = fhi; o[9] = rlo; o[10] = rhi;
-					o[11] = (rev ? 1u : 0u) | ((y & 64u) ? 2u : 0u) | (ht ? 4u : 0u);
-				}
+					for (int i = 0; i < K / 4; ++i)
+#ifdef TS_EXP_NOTABLE
+						tv[j][i] = v4u32{toff[j][i], pd0[j], pd1[j], pd2[j]};
+#else
+						tv[j][i] = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)i * 4096u + toff[j][i]); // the group's 4 KiB rides in the offset field
 #endif
-				hit[j] = ht & !suspect;
-				hm[j] = ballot(hit[j]);
-				total += (uint32_t)__popcll(hm[j]);
-			}
-			// 4. one log append for the pass (ntComp's increment, deferred: ntc_apply.hip)
-			TS_T(pp3);
-			TS_ACC(7, pp2, pp3);
-			if (total != 0u) {
-				if (!use_log) {
+				__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-					for (int j = 0; j < NI; ++j)
-						if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
-				} else {
-					while (lreg < a.log_regions && total > a.log_region_cap - lfill) {
-						if (lane == 0) a.log_fill[lreg] = lfill;
-						lreg += n_teams;
-						lfill = lreg < a.log_regions ? rfl(a.log_fill[lreg]) : 0u;
+				for (int j = 0; j < NI; ++j) {
+					static_assert(K / 4 == 8, "XOR tree below is written for 8 table entries");
+					auto x3 = [](uint32_t p, uint32_t q, uint32_t r) { return (uint32_t)__builtin_amdgcn_bitop3_b32(p, q, r, 0x96); };
+					const uint32_t flo = x3(x3(tv[j][0].x, tv[j][1].x, tv[j][2].x), x3(tv[j][3].x, tv[j][4].x, tv[j][5].x), tv[j][6].x ^ tv[j][7].x);
+					const uint32_t fhi = x3(x3(tv[j][0].y, tv[j][1].y, tv[j][2].y), x3(tv[j][3].y, tv[j][4].y, tv[j][5].y), tv[j][6].y ^ tv[j][7].y);
+					const uint32_t rlo = x3(x3(tv[j][0].z, tv[j][1].z, tv[j][2].z), x3(tv[j][3].z, tv[j][4].z, tv[j][5].z), tv[j][6].z ^ tv[j][7].z);
+					const uint32_t rhi = x3(x3(tv[j][0].w, tv[j][1].w, tv[j][2].w), x3(tv[j][3].w, tv[j][4].w, tv[j][5].w), tv[j][6].w ^ tv[j][7].w);
+					const uint64_t fh = ((uint64_t)fhi << 32) | flo, rh = ((uint64_t)rhi << 32) | rlo;
+					const bool rev = rh < fh; // nthash.hpp:275-279
+					const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
+					// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+					const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+					const bool c0m = (hi >> (31 - s_bits)) == 1u;
+					const uint32_t y = pyy[j];
+					// the candidate of the canonical strand only (both strands may have flagged the window)
+					bool ht = ((y >> 31) != 0u) & (rev == ((y & 64u) != 0u)) & (c0m | c1);
+					if (has_partial) ht &= (y & 128u) == 0u || prr[j] < n_valid_last; // slots behind the last read of the batch
+					key[j] = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
+					// a window that touches a 16-byte piece with a non-ACGTU byte somewhere is settled from the raw bytes (the third piece
+					// only counts when the window is not chunk-aligned)
+					const uint32_t dd = (pb0[j] | pb1[j] | ((pww[j] & 15u) != 0u ? pb2[j] : 0u)) >> pmm[j];
+					sus[j] = ht ? dd & 1u : 0u;
+					hit[j] = (ht ? 1u : 0u) & ~sus[j];
+					nhit += hit[j];
+					anysus |= sus[j];
+#ifdef TS_DEBUG
+					if ((y >> 31) && a.dbg) {
+						const uint32_t ixd = atomicAdd(a.dbg, 1u);
+						uint32_t* o = a.dbg + 16 + 12 * (size_t)ixd;
+						o[0] = prr[j]; o[1] = pww[j]; o[2] = 0; o[3] = y; o[4] = pd0[j]; o[5] = pd1[j]; o[6] = pd2[j]; o[7] = flo; o[8] = fhi; o[9] = rlo; o[10] = rhi;
+						o[11] = (rev ? 1u : 0u) | ((y & 64u) ? 2u : 0u) | (ht ? 4u : 0u);
 					}
-					if (lreg < a.log_regions) {
-						uint32_t* dst = a.log + (uint64_t)lreg * a.log_region_cap + lfill;
-						uint32_t off = 0;
-#pragma unroll
-						for (int j = 0; j < NI; ++j) {
-							if (hit[j]) dst[off + mbcnt(hm[j])] = key[j];
-							off += (uint32_t)__popcll(hm[j]);
-						}
-						lfill += total;
-					} else {
+#endif
+				}
+				// one log append for the batch (ntComp's increment, deferred: ntc_apply.hip): a lane's hits go behind those of the lanes below it
+				const uint32_t hincl = wave_scan(nhit);
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
+				if (total != 0u) {
+					if (!use_log) {
 #pragma unroll
 						for (int j = 0; j < NI; ++j)
 							if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
+					} else {
+						while (lreg < a.log_regions && total > a.log_region_cap - lfill) {
+							if (lane == 0) a.log_fill[lreg] = lfill;
+							lreg += n_teams;
+							lfill = lreg < a.log_regions ? rfl(a.log_fill[lreg]) : 0u;
+						}
+						if (lreg < a.log_regions) {
+							uint32_t* dst = a.log + (uint64_t)lreg * a.log_region_cap + lfill + (hincl - nhit);
+#pragma unroll
+							for (int j = 0; j < NI; ++j) {
+#ifndef TS_EXP_NOLOG
+								if (hit[j]) *dst = key[j];
+#endif
+								dst += hit[j];
+							}
+							lfill += total;
+						} else {
+#pragma unroll
+							for (int j = 0; j < NI; ++j)
+								if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
+						}
+					}
+				}
+				if (ballot(anysus != 0u) != 0) { // rare
+#pragma unroll
+					for (int j = 0; j < NI; ++j) {
+						const uint64_t sm = ballot(sus[j] != 0u);
+						if (sus[j]) sq[sq_fill + mbcnt(sm)] = make_uint2(key[j], prr[j] | (pww[j] << 11) | (((psb[j] / C) & 15u) << 27)); // + the tile of the block the word was taken in
+						sq_fill += (uint32_t)__popcll(sm);
+					}
+					if (sq_fill > kSCap - 64u * NI) {
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						flush_suspects(blk / C);
 					}
 				}
 			}
-			if (sq_fill > kSCap - 64u * NI) {
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				flush_suspects(blk / C);
+			// the batch fetched in this pass becomes the one whose back runs in the next
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				pd0[j] = d0[j];
+				pd1[j] = d1[j];
+				pd2[j] = d2[j];
+				pb0[j] = b0[j];
+				pb1[j] = b1[j];
+				pb2[j] = b2[j];
+				prr[j] = rr[j];
+				pww[j] = ww[j];
+				pmm[j] = mm[j];
+				pyy[j] = yy[j];
+				psb[j] = tb_[j];
 			}
+			pend = ballot(any_new != 0u) != 0;
 		};
 		auto slots_busy = [&]() {
 			bool any = false;
 #pragma unroll
 			for (int j = 0; j < NI; ++j)
 				any |= sh_[j] != 0u;
-			return ballot(any) != 0;
+			return pend || ballot(any) != 0;
 		};
 		auto slots_from = [&](uint32_t blk) { // some slot still holds a word taken in block `blk`
 			bool any = false;
