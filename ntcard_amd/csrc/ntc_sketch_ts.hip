@@ -179,12 +179,11 @@ __device__ __forceinline__ void ts_main(uint32_t (&S)[31], uint32_t i0, uint32_t
 constexpr uint32_t kTile = kTileReads;
 constexpr uint32_t kRing = 5;            // packed chunks kept: a block's candidates need chunks n-2 .. n, the walkers are one ahead, and a fifth
                                          // slot lets A1 park a chunk before the block two behind is resolved (no copy held in registers)
-constexpr uint32_t kQCap = 256;          // candidate items per strand queue (power of two)
+constexpr uint32_t kQCap = 512;          // candidate items per strand queue (power of two)
 constexpr uint32_t kSCap = 320;          // suspects (candidates next to a dirty piece) waiting for their raw bytes: up to 256 join per pass
 constexpr uint32_t kDCap = 128;          // dirty pieces (A1 -> A2)
 constexpr uint32_t kOffPR = 0;                               // packed ring  [kRing][32][64] dwords
-constexpr uint32_t kOffPL = kOffPR + kRing * 8192u;          // plane slot   [32][64] dwords
-constexpr uint32_t kOffDB = kOffPL + 8192u;                  // dirty words  [kRing][64] dwords
+constexpr uint32_t kOffDB = kOffPR + kRing * 8192u;          // dirty words  [kRing][64] dwords
 constexpr uint32_t kOffQF = kOffDB + kRing * 256u;           // F queue      [kQCap + 64] x 8 B
 constexpr uint32_t kOffQR = kOffQF + (kQCap + 64u) * 8u;     // R queue
 constexpr uint32_t kOffSQ = kOffQR + (kQCap + 64u) * 8u;     // suspects     [kSCap] x 8 B
@@ -195,7 +194,7 @@ constexpr uint32_t kOffCT = kOffXR + 2048u;                  // control words
 constexpr uint32_t kTeamBytes = kOffCT + 256u;
 // control words (all monotonic).  Words that one wave reads together sit together: {BLK_F, QF_TAIL, BLK_R, QR_TAIL} is one
 // ds_read_b128 for A2, {PL_TAKEN_F, PL_TAKEN_R} one ds_read_b64 for A1, the block-end tails are {F, R} pairs.
-enum { C_BLK_F = 0, C_QF_TAIL = 1, C_BLK_R = 2, C_QR_TAIL = 3, C_PL_TAKEN_F = 4, C_PL_TAKEN_R = 5, C_PL_READY = 6, C_PR_READY = 7, C_RESOLVED = 8,
+enum { C_BLK_F = 0, C_QF_TAIL = 1, C_BLK_R = 2, C_QR_TAIL = 3, C_PR_READY = 7, C_RESOLVED = 8,
        C_QF_HEAD = 9, C_QR_HEAD = 10, C_DQ_TAIL = 11, C_DQ_HEAD = 12,
        C_XPUB_F = 13, C_XPUB_R = 14 /* half blocks whose planes are in the exchange area */, C_XCONS_F = 15 /* half blocks of R's planes F has read */,
        C_XCONS_R = 32, C_BT = 16 /* 8 pairs: queue tails {F, R} at the end of block b & 7 */ };
@@ -296,105 +295,52 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		v4u32 raw[32];
 		const uint32_t voff = (uint32_t)lane * 16u;
 		// The chunk's 32 loads are BUFFER loads: resource descriptor of the chunk (scalar registers) + one 32-bit lane offset +
-		// scalar / immediate offsets.  As flat global loads the in-loop copy gets a 64-bit vector address per load (64 more
-		// registers, spills).  28 of them fly while the previous chunk is transposed and published, the last 4 are issued just
-		// before the chunk is packed and land while the first 28 are (16 registers less at the tightest point).
+		// scalar / immediate offsets (as flat global loads the in-loop copies get a 64-bit vector address each: 64 more registers).
+		// Software pipeline with a distance of one chunk, item by item: as soon as the 16 bytes of read group m are packed, the
+		// same registers take the load of group m of the NEXT chunk, so every load has a whole chunk period to land (issuing
+		// the next chunk's loads only after the whole pack exposed the full HBM latency once per chunk: 8.7 k clk per chunk
+		// instead of ~3 k).
 		auto chunk_rsrc = [&](uint32_t t, uint32_t c) {
 			const unsigned char* p = a.tiles + ((size_t)rfl(t) * C + rfl(c)) * (size_t)(kTile * 16u);
 			return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p), 0, (int)(kTile * 16u), 0x00020000);
 		};
-		auto issue28 = [&](uint32_t t, uint32_t c) {
-			const __amdgpu_buffer_rsrc_t r = chunk_rsrc(t, c);
-#pragma unroll
-			for (int j = 0; j < 7; ++j)
-#pragma unroll
-				for (int i = 0; i < 4; ++i)
-					raw[4 * j + i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + (uint32_t)i * 1024u, j * 4096, 2 /* slc: read once */);
-		};
-		auto issue4 = [&](uint32_t t, uint32_t c) {
-			const __amdgpu_buffer_rsrc_t r = chunk_rsrc(t, c);
-#pragma unroll
-			for (int i = 0; i < 4; ++i)
-				raw[28 + i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + (uint32_t)i * 1024u, 7 * 4096, 2);
-		};
 		uint32_t dq_tail = 0;
-		// this team's chunks as one flat sequence (one load site: two of them cost the register allocator its plan)
 		const uint32_t my_tiles = team_g < a.n_tiles ? (a.n_tiles - team_g + n_teams - 1u) / n_teams : 0u;
-		const uint32_t total = my_tiles * C;
-		if (total != 0u) issue28(team_g, 0u);
+		const uint32_t total = my_tiles * C; // this team's chunks as one flat sequence
+		if (total != 0u) {
+			const __amdgpu_buffer_rsrc_t r0 = chunk_rsrc(team_g, 0u);
+#pragma unroll
+			for (int m = 0; m < 32; ++m)
+				raw[m] = __builtin_amdgcn_raw_buffer_load_b128(r0, voff + (uint32_t)(m & 3) * 1024u, (m >> 2) * 4096, 2 /* slc: read once */);
+		}
 		{
 			uint32_t t = team_g, seq = 0, c = 0;
 			for (; n < total; ++n) {
-				uint32_t P[32];
 				uint32_t dirtyword = 0;
-				TS_T(tloop);
-				issue4(t, c); // this chunk's last four loads
-#pragma unroll
-				for (int m = 0; m < 28; ++m) {
-					uint32_t bad;
-					P[m] = pack16(raw[m], bad);
-					dirtyword |= (bad != 0u ? 1u : 0u) << m;
-				}
-				__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-				for (int m = 28; m < 32; ++m) {
-					uint32_t bad;
-					P[m] = pack16(raw[m], bad);
-					dirtyword |= (bad != 0u ? 1u : 0u) << m;
-				}
-				__builtin_amdgcn_sched_barrier(0);
-				// the next chunk's loads fly while this one is transposed and published
 				const bool last_c = c + 1u == C;
 				const uint32_t tn = last_c ? t + n_teams : t, cn = last_c ? 0u : c + 1u;
 				const bool more = n + 1u < total;
-				issue28(more ? tn : t, more ? cn : c); // unconditional (a conditional load site makes all the registers a phi): the last one re-reads its chunk
-				__builtin_amdgcn_sched_barrier(0);
-				// the packed words overwrite chunk n - 5, which blocks <= n - 3 read: this wave is never that far ahead of A2 in practice
+				const __amdgpu_buffer_rsrc_t rn = chunk_rsrc(more ? tn : t, more ? cn : c); // (the last chunk re-reads itself: one unconditional load site)
+				// the packed words overwrite chunk n - 5, which blocks <= n - 3 read
 #ifndef TS_EXP_A1_FREE
 				if (n >= 3u) TS_WAIT(1, ctl + C_RESOLVED, n - 2u);
 #endif
 				const uint32_t slot = n % kRing;
-				{
-					uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
+				uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
 #pragma unroll
-					for (int m = 0; m < 32; ++m)
-						pr[m * 64] = P[m];
-					reinterpret_cast<uint32_t*>(tb + kOffDB)[slot * 64u + lane] = dirtyword;
+				for (int m = 0; m < 32; ++m) {
+					uint32_t bad;
+					pr[m * 64] = pack16(raw[m], bad);
+					dirtyword |= (bad != 0u ? 1u : 0u) << m;
+					raw[m] = __builtin_amdgcn_raw_buffer_load_b128(rn, voff + (uint32_t)(m & 3) * 1024u, (m >> 2) * 4096, 2);
+					if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); // keep pack and reload of a group together
 				}
-				TS_T(tt0);
-				transpose32(P); // P[2 q + b] = bit b of the code of base 16 c + q, one bit per read
-#ifdef TS_TIMERS
-				__builtin_amdgcn_sched_barrier(0);
-				{
-					uint32_t keep = 0;
-#pragma unroll
-					for (int m = 0; m < 32; ++m)
-						asm volatile("" : "+v"(P[m]));
-					(void)keep;
-				}
-#endif
-				TS_T(tt1);
-				TS_ACC(5, tt0, tt1);
-#ifndef TS_EXP_A1_FREE
-				{
-					TS_T(tk0);
-					while (true) {
-						const uint2 tk = lds_peek2(ctl + C_PL_TAKEN_F);
-						if ((int32_t)(tk.x - n) >= 0 && (int32_t)(tk.y - n) >= 0) break;
-						__builtin_amdgcn_s_sleep(1);
-					}
-					TS_T(tk1);
-					TS_ACC(2, tk0, tk1);
-				}
-#endif
-				{
-					uint32_t* pl = reinterpret_cast<uint32_t*>(tb + kOffPL) + lane; // [plane][lane]: one conflict-free dword store per plane
-#pragma unroll
-					for (int j = 0; j < 32; ++j)
-						pl[j * 64] = P[j];
-				}
-				lds_publish(ctl + C_PL_READY, n + 1u);
+				reinterpret_cast<uint32_t*>(tb + kOffDB)[slot * 64u + lane] = dirtyword;
+#ifdef TS_EXP_A1_FREE
+				const uint64_t dm = 0;
+#else
 				const uint64_t dm = ballot(dirtyword != 0u);
+#endif
 				if (dm != 0) { // rare: hand the dirty pieces to A2 (F1 corrections)
 					const uint32_t cnt = (uint32_t)__popcll(dm);
 					while ((int32_t)(dq_tail + cnt - lds_peek(ctl + C_DQ_HEAD) - kDCap) > 0)
@@ -471,14 +417,15 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll 1
 				for (uint32_t c = 0; c < C; ++c, ++n) {
 					uint32_t I[32];
-					TS_WAIT(1, ctl + C_PL_READY, n + 1u);
-					{
-						const uint32_t* pl = reinterpret_cast<const uint32_t*>(tb + kOffPL) + lane;
+					TS_WAIT(1, ctl + C_PR_READY, n + 1u);
+					{ // the chunk's packed words of this lane's 32 reads -> 32 bit planes (both walkers do this: it is cheaper than a
+					  // third party publishing planes through one more LDS slot and one more hand-shake)
+						const uint32_t* pw = reinterpret_cast<const uint32_t*>(tb + kOffPR) + (n % kRing) * 2048u + lane;
 #pragma unroll
-						for (int j = 0; j < 32; ++j)
-							I[j] = pl[j * 64];
+						for (int m = 0; m < 32; ++m)
+							I[m] = pw[m * 64];
+						transpose32(I); // I[2 q + b] = bit b of the code of base 16 c + q, one bit per read
 					}
-					lds_publish(ctl + (FWD ? C_PL_TAKEN_F : C_PL_TAKEN_R), n + 1u);
 					if (c < (uint32_t)KB) { // window filling: no outgoing base; the last step completes window 0
 #pragma unroll
 						for (int q = 0; q < 16; ++q) {
