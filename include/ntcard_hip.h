@@ -72,6 +72,10 @@ typedef struct {
                                       atomics when an apply finds few distinct counters per increment: repeats)       */
 #define NTC_FLAG_PARTITION_ALWAYS 16u /* validation: apply even a small hit log through the partition + histogram passes
                                          (by default fewer than 4 M pending entries are applied with plain atomics)   */
+#define NTC_FLAG_DEFER_REDO 128u    /* ntc_submit_device only: the caller promises to keep every submitted buffer valid AND UNCHANGED until
+                                      ntc_sync / ntc_finish returns.  The reads K1b hands back to the lane-per-read kernel (a non-ACGTU byte
+                                      somewhere, the batch tail) are then hashed in ONE pass shared by several batches instead of one per
+                                      batch.  Without the flag a buffer may be reused as soon as the stream has passed the submit call. */
 #define NTC_FLAG_REQUIRE_TILED 64u  /* validation: ntc_submit_tiled_device fails instead of re-laying a batch out for the general kernel */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
@@ -104,8 +108,8 @@ int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, con
  * d_slots[i*stride, i*stride+read_len), stride % 4 == 0, d_slots 16-byte aligned.  Padding bytes
  * (read_len..stride) are never hashed; filling them with a base letter ('A') keeps the kernel on
  * its fast path (a non-ACGTU byte anywhere in a wave's 64 slots selects the dirty-window path).
- * Asynchronous on the engine's stream; the buffer must stay valid AND UNCHANGED until ntc_sync/ntc_finish returns:
- * reads with a non-ACGTU byte (and a batch's last few reads) are hashed in a deferred pass that several batches share.
+ * Asynchronous on the engine's stream: the buffer may be reused as soon as the stream has passed the call (stream-ordered,
+ * like a kernel launch) — unless the engine was created with NTC_FLAG_DEFER_REDO, see there.
  * A wave parks its 64 slots in LDS, so stride is limited to about 2.4 KB (64 * stride + tables <= 160 KiB);
  * longer sequences go through ntc_submit, which splits them into overlapping chunks.            */
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,

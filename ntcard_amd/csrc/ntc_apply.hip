@@ -160,24 +160,29 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 			seg_cnt = a.parts;
 		}
 		uint32_t* dst = a.sketch + ((uint64_t)slice << a.slice_bits);
-		uint32_t t = 0;
+		uint32_t t = 0, off = 0; // next run, and how much of it earlier passes took (a run longer than one pass is taken in pieces)
 		while (t < seg_cnt && a.in_cnt[t * seg_mul + seg_add] == 0u) // leading empty runs (an empty log costs no LDS traffic at all)
 			++t;
 		while (t < seg_cnt) {
 			for (uint32_t i = tid; i < n_words / 4; i += nt)
 				reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
 			__syncthreads();
-			uint32_t taken = 0; // keys of this pass (the same for every thread)
-			for (; t < seg_cnt; ++t) {
+			uint32_t taken = 0; // keys of this pass (the same for every thread): at most 65535, so that no 16-bit count wraps into its neighbour
+			while (t < seg_cnt && taken < 65535u) {
 				const uint32_t seg = t * seg_mul + seg_add;
 				uint32_t n = a.in_cnt[seg];
 				n = n < a.in_cap ? n : a.in_cap;
-				if (taken + n > 65535u) break; // the next run would allow a 16-bit count to wrap into its neighbour
-				taken += n;
-				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap;
-				for (uint32_t i = tid; i < n; i += nt) {
+				const uint32_t take = n - off < 65535u - taken ? n - off : 65535u - taken;
+				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap + off;
+				for (uint32_t i = tid; i < take; i += nt) {
 					const uint32_t kk = src[i] & cmask;
 					atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
+				}
+				taken += take;
+				off += take;
+				if (off == n) {
+					++t;
+					off = 0;
 				}
 			}
 			__syncthreads();

@@ -261,6 +261,7 @@ struct ntc_engine {
 	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry (NULL: neither is used by this engine)
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
+	bool defer_redo = false;        // NTC_FLAG_DEFER_REDO
 	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1c does not cover
 	size_t untile_cap = 0;
 	// K1b hands the reads with a non-ACGTU byte and the batch tails to K1 as a list of slot ADDRESSES.  For device-resident
@@ -860,6 +861,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	}
 	if (cfg->r_bits < 8 || cfg->r_bits > 30) return fail(NTC_ERR_ARG, "ntc_create: r_bits %u outside 8..30", cfg->r_bits);
 	if (cfg->s_bits < 2 || cfg->s_bits > 24) return fail(NTC_ERR_ARG, "ntc_create: s_bits %u outside 2..24", cfg->s_bits);
+	if (cfg->log_entries > (1ull << 32)) return fail(NTC_ERR_ARG, "ntc_create: log_entries %llu above 2^32", (unsigned long long)cfg->log_entries);
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
 		return fail(NTC_ERR_DEVICE, "ntc_create: no HIP device available (this library has no CPU fallback)");
@@ -944,6 +946,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	}
 	if (!e->d_t4) e->ts_ok = false;
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
+	e->defer_redo = (cfg->flags & NTC_FLAG_DEFER_REDO) != 0;
 	e->hfk.resize(e->klist.size());
 	for (size_t ki = 0; ki < e->klist.size(); ++ki)
 		fill_hfk(e->hfk[ki], e->klist[ki], e->d_sketch + ki * e->plane_elems(), e->d_f1 + ki, e->d_t1[ki], (uint32_t)(ki * e->plane_elems()));
@@ -1028,7 +1031,7 @@ int ntc_submit_device(ntc_engine* e, const void* d_slots, uint64_t n_reads, uint
 	if (read_len > 0xffffu) return fail(NTC_ERR_ARG, "ntc_submit_device: read_len %u > 65535", read_len);
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride, /*may_defer=*/true); // the caller's buffer stays valid until ntc_sync
+	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride, /*may_defer=*/e->defer_redo); // only when the caller promised to keep its buffers until ntc_sync
 }
 
 

@@ -19,9 +19,10 @@
 //   * the four walkers walk the SAME tile, each one quarter of the window positions (segment = 16*nq windows,
 //     preceded by the k-1 window-filling steps); a lane's 32 reads are 64*i + lane, i = 0..31; per 16-base chunk
 //     the lane fetches its 32 packed words from LDS and transposes the 32x32 bit matrix into 32 bit planes;
-//   * every 16 steps the walker turns its hit planes (one bit per read and window) into (read, window) pairs (DPP
-//     prefix sum, LDS queue), resolves them 64 at a time with a 4-bases-per-lookup closed-form table and sends the
-//     counter index to the hit log (ntc_apply.hip);
+//   * after every step the walker stores its hit plane (one bit per read) as ONE ballot-compacted 8-byte item
+//     (plane word, lane, window) per lane with a hit in its LDS queue; every 16 steps the queue is drained 64 items at a
+//     time: a resolve round takes the lowest set bit of every item, recomputes the full canonical hash with a
+//     4-bases-per-lookup closed-form table and sends the counter index to the hit log (ntc_apply.hip);
 //   * a read with any non-ACGTU byte is NOT handled here: it is left out of F1 and of the sketch and its slot
 //     index is appended to a device list that the lane-per-read kernel processes right after (gather mode), which
 //     keeps ntHashIterator's N semantics (ntHashIterator.hpp:59-86) in one place.
@@ -120,7 +121,7 @@ constexpr int kGroupLoads = 10;  // loads per staging group
 constexpr int kGroups = 8;       // 80 loads of 1 KiB per helper and tile: strides up to 160 B
 constexpr uint32_t kQueueCap = 1088; // queue items per walker: 63 left over from the previous block + 16 steps x 64 lanes
 
-// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS round trip)
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS round trip); used for the redo list only
 __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 {
 	uint32_t s = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
@@ -138,7 +139,7 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 template <int K, int SB>
 __global__ __launch_bounds__(512, 2) void sketch_bs_kernel(const BsArgs a)
 {
-	static_assert(K % 16 == 0 && K >= 16 && K <= 64, "K1b is instantiated for k = 16, 32, 48, 64");
+	static_assert(K == 32, "K1b step bodies are generated for k = 32 only (gen_bs.py): any other K would walk nothing");
 	constexpr int KB = K / 16; // window-filling blocks; block b consumes bases [16 b, 16 b + 16) of the segment
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;

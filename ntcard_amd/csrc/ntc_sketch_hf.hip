@@ -98,15 +98,6 @@ __device__ __forceinline__ uint32_t decode4(uint32_t w, uint32_t& badacc)
 	return code;
 }
 
-#ifndef NTC_EXP_ABL
-#define NTC_EXP_ABL 0 // ablations of the walk: 1 no record, 2 no table lookup, 3 no data reads
-#endif
-#ifndef NTC_EXP_STAGE_ONLY
-#define NTC_EXP_STAGE_ONLY 0
-#endif
-#ifndef NTC_EXP_NO_QUEUE
-#define NTC_EXP_NO_QUEUE 0
-#endif
 // wave ballot of a bool without the int round trip hipcc's ballot() goes through (saves 2 VALU ops per use)
 __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
@@ -407,7 +398,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				}
 			}
 			bool hit = false;
-			uint32_t key = 0;
+			uint32_t key = 0, rel = 0; // rel: counter index inside this k's plane pair; key: index in the engine's whole sketch (hit-log keys)
 			if (act && (dirty & 0x01010101u) == 0u) { // a window with a non-ACGTU byte yields no k-mer (ntHashIterator.hpp:59-86)
 				const bool rev = (rhi < fhi) | ((rhi == fhi) & (rlo < flo)); // nthash.hpp:275-279
 				const uint32_t hi = rev ? rhi : fhi;
@@ -432,14 +423,15 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 					const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
 					const bool c0 = (hi >> (31 - s_bits)) == 1u;
 					hit = c0 | c1;
-					key = key_base + (lo & rmask) + (c1 ? rbuck : 0u);
+					rel = (lo & rmask) + (c1 ? rbuck : 0u);
+					key = key_base + rel;
 				}
 			}
 			if constexpr (kMode != 2 && !kDump) {
 				if (use_log)
 					log_emit(hit, key); // the increment itself happens later (ntc_apply.hip)
 				else if (hit)
-					atomicAdd(a.sketch0 + key, 1u);
+					atomicAdd(sketch_k + rel, 1u); // not sketch0 + key: without a log the sketch may hold more than 2^32 counters (32-bit keys would alias)
 			}
 		};
 		// End of a 32-step block: queue the block's sampled steps as (lane, step) pairs.  The queue is ONE register
@@ -452,9 +444,6 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			if (can_prefetch) __builtin_amdgcn_s_setprio(3);
 			uint32_t cur = hmask;
 			hmask = 0;
-#if NTC_EXP_NO_QUEUE
-			cur = 0;
-#endif
 			uint32_t np = __builtin_amdgcn_readfirstlane(npend); // wave-uniform: the queue fill lives on the scalar unit
 			for (;;) {
 				const uint64_t m = ballot(cur != 0u);
@@ -485,10 +474,6 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		//   MAIN : every step has q >= k
 		constexpr int FILL = 0, MIXED = 1, MAIN = 2;
 		auto group_idx = [&](auto kind, int32_t q0, uint32_t& ain) -> uint32_t {
-#if NTC_EXP_ABL == 3
-			ain = 0x40c08000u;
-			return (uint32_t)q0 * 0x10101010u & 0xf0f0f0f0u;
-#endif
 			ain = *reinterpret_cast<const uint32_t*>(mine + q0);
 			if (kind.value == FILL) return ain & 0xc0c0c0c0u;
 			uint32_t aout = 0;
@@ -510,10 +495,6 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			uint2 t[4];
 		};
 		auto issue = [&](uint32_t idx4, Tab4& T) {
-#if NTC_EXP_ABL == 2
-			T.t[0] = T.t[1] = T.t[2] = T.t[3] = make_uint2(idx4, idx4 * 3u);
-			return;
-#endif
 			T.t[0] = *reinterpret_cast<const uint2*>(tabHb + (idx4 & 0xffu));
 			T.t[1] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> 8) & 0xffu));
 			T.t[2] = *reinterpret_cast<const uint2*>(tabHb + ((idx4 >> 16) & 0xffu));
@@ -550,10 +531,6 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				}
 			};
 			auto record = [&](int32_t q, bool emitting) {
-#if NTC_EXP_ABL == 1
-				hmask ^= fHd & rHd;
-				return;
-#endif
 				uint64_t m = 0;
 				if (emitting) {
 					uint32_t fs = fHd, rs = rHd;
@@ -759,9 +736,6 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 				f1_wave += __builtin_amdgcn_readfirstlane(v);
 			}
 		};
-#if NTC_EXP_STAGE_ONLY
-		if (mine[lane] == 0x7f && k == 9999) // A/B experiment: staging only (never true)
-#endif
 		if constexpr (kMode == 2) {
 			if (wclass == CLEAN)
 				walk(std::integral_constant<int, CLEAN>{}, std::false_type{}, std::true_type{});

@@ -18,6 +18,7 @@ FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: K1b for every equal-length
 FLAG_LANE_KERNEL = 32  # NTC_FLAG_LANE_KERNEL: never use the bit-sliced kernel K1b
 FLAG_ALWAYS_LOG = 8  # NTC_FLAG_ALWAYS_LOG: never switch from the hit log to direct atomics
 FLAG_PARTITION_ALWAYS = 16  # NTC_FLAG_PARTITION_ALWAYS: small logs go through the partition passes too (validation)
+FLAG_DEFER_REDO = 128  # NTC_FLAG_DEFER_REDO: submit_device buffers stay unchanged until sync(); the handed-back reads of several batches share one pass
 FLAG_REQUIRE_TILED = 64  # NTC_FLAG_REQUIRE_TILED: submit_tiled_device fails instead of falling back to the general kernel
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7

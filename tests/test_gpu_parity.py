@@ -246,7 +246,7 @@ def test_deferred_pass_over_several_buffers(nt):
     dropped = batch(2048 * 2 + 5, 150, 152, 0.01)
     batches = [batch(2048 * 2 + 300, 150, 152, 0.002), batch(2048 + 1, 150, 152, 0.02), batch(2048 * 3, 150, 152, 0.0),
                batch(2048 * 2 + 77, 148, 156, 0.004), batch(2048 + 900, 150, 152, 0.001)]
-    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_BITSLICE_KERNEL) as e:
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_BITSLICE_KERNEL | nt.FLAG_DEFER_REDO) as e:
         e.submit_device(dropped[1].data_ptr(), len(dropped[0]), 150, 152)
         e.reset()
         for reads, d in batches:
@@ -257,6 +257,64 @@ def test_deferred_pass_over_several_buffers(nt):
     oc, of1 = orc.sketch_reads(allreads, [32], 0, 20, 7)
     assert np.array_equal(f1, of1)
     assert np.array_equal(tc, oc)
+
+
+def test_submit_device_buffer_may_be_reused_in_stream_order(nt):
+    """ntc_submit_device's contract: the buffer belongs to the caller again as soon as the stream has passed the call.  K1b hands
+    reads (non-ACGTU byte, batch tail) to a later pass by ADDRESS; by default that pass runs before the submit returns, so
+    overwriting the buffer right behind the submit (same stream) must not change a counter.  With NTC_FLAG_DEFER_REDO the
+    caller promises to keep the buffer, and the pass is shared by several batches."""
+    rng = random.Random(7)
+    reads = [rseq(rng, 150, pn=0.01, plow=0.05) for _ in range(2048 * 2 + 333)]
+    buf, _ = to_slots(reads, stride=152)
+    buf[buf == 10] = ord("A")
+    oc, of1 = orc.sketch_reads(reads, [32], 0, 20, 7)
+    for flags in (nt.FLAG_BITSLICE_KERNEL, 0):
+        d = torch.from_numpy(buf).cuda()
+        with nt.Engine([32], r_bits=20, s_bits=7, flags=flags) as e:  # engine and torch both use the null stream here
+            e.submit_device(d.data_ptr(), len(reads), 150, 152)
+            d.fill_(ord("C"))
+            tc, ph, f1 = e.finish(counters=True)
+        assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+    d = torch.from_numpy(buf).cuda()
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_BITSLICE_KERNEL | nt.FLAG_DEFER_REDO) as e:
+        e.submit_device(d.data_ptr(), len(reads), 150, 152)
+        e.submit_device(d.data_ptr(), 2048, 150, 152)
+        tc, ph, f1 = e.finish(counters=True)
+    oc2, of2 = orc.sketch_reads(reads + reads[:2048], [32], 0, 20, 7)
+    assert np.array_equal(f1, of2) and np.array_equal(tc, oc2)
+
+
+def test_more_than_2_32_counters_do_not_alias(nt):
+    """3 values of k at rBits = 30 are 3 x 2^31 counters: beyond 32-bit hit-log keys, so the engine increments directly — through
+    every k's own plane pointer.  Each k's value histogram must equal that of a single-k engine."""
+    n, L, stride = 30_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 3, 0, n, L, stride, 1, genome_len=100_000)
+    klist = [20, 24, 28]
+    with nt.Engine(klist, r_bits=30, s_bits=4) as e:
+        e.submit_device(d.data_ptr(), n, L, stride)
+        _, ph, f1 = e.finish()
+    for i, k in enumerate(klist):
+        with nt.Engine([k], r_bits=30, s_bits=4) as e:
+            e.submit_device(d.data_ptr(), n, L, stride)
+            _, ph1, f11 = e.finish()
+        assert int(f1[i]) == int(f11[0]) and np.array_equal(ph[i], ph1[0]), k
+
+
+def test_partition_runs_longer_than_one_count_pass(nt):
+    """a large log over a small sketch: a (workgroup, digit) run of the partition holds more than 65535 keys, which the 16-bit
+    LDS histogram of the count pass has to take in pieces (it used to spin forever)"""
+    n, L, stride = 3_000_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 11, 0, n, L, stride, 0)
+    res = []
+    for flags, le in ((nt.FLAG_DIRECT_ATOMICS, 0), (nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS | nt.FLAG_LANE_KERNEL, 1 << 28)):
+        with nt.Engine([32], r_bits=17, s_bits=2, flags=flags, log_entries=le) as e:
+            e.submit_device(d.data_ptr(), n, L, stride)
+            _, ph, f1 = e.finish()
+            res.append((ph.copy(), f1.copy()))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
 
 
 @pytest.mark.parametrize("s_bits,dist,want_mode", [(7, 1, 1), (7, 0, 0), (11, 1, 1), (11, 0, 0), (9, 1, 1)])

@@ -1,0 +1,143 @@
+"""GPU parity of the TILED path (ntc_submit_tiled_device -> K1c, ntc_sketch_ts.hip): the tiled streaming kernel against the
+CPU oracle on seeded and adversarial inputs (bit-exact), and against the real reference's full-size digests.
+
+K1c handles ntHashIterator's N semantics (ntHashIterator.hpp:59-86) inside the kernel, so the inputs lean on that: reads
+with many non-ACGTU bytes, all-N reads, lower case / U, partial tiles, read lengths around the 16-base chunks.
+"""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize")
+
+
+@pytest.fixture(scope="module")
+def nt():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device (run on the MI355X box)"
+    import ntcard_amd
+    return ntcard_amd
+
+
+def gen_host(n, L, dist, genome_len=200_000, seed=1):
+    stride = (L + 3) & ~3
+    sl = orc.gen_reads(seed, 0, n, L, stride, dist, genome_len=genome_len)
+    return [sl[i * stride: i * stride + L].tobytes() for i in range(n)]
+
+
+def run_tiled(nt, reads, L, k=32, r_bits=18, s_bits=7, flags=0, pieces=1):
+    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | nt.FLAG_REQUIRE_TILED) as e:
+        step = (len(reads) + pieces - 1) // pieces
+        keep = []
+        for i in range(0, len(reads), step):
+            part = reads[i:i + step]
+            t = torch.from_numpy(nt.tile_reads(part, L)).cuda()
+            keep.append(t)
+            e.submit_tiled_device(t.data_ptr(), len(part), L)
+        return e.finish(counters=True)
+
+
+def check(nt, reads, L, **kw):
+    tc, ph, f1 = run_tiled(nt, reads, L, **kw)
+    oc, of1 = orc.sketch_reads(reads, [kw.get("k", 32)], 0, kw.get("r_bits", 18), kw.get("s_bits", 7))
+    assert np.array_equal(f1, of1), (f1, of1)
+    assert np.array_equal(tc, oc)
+    assert np.array_equal(ph[0], orc.value_hist(oc[0], kw.get("r_bits", 18)))
+
+
+def test_tiled_generator_matches_oracle(nt):
+    n, L = 5000, 150
+    t = torch.empty(nt.tiled_bytes(n, L), dtype=torch.uint8, device="cuda")
+    nt.gen_reads_tiled_device(t.data_ptr(), 1, 0, n, L, 1, genome_len=200_000)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), nt.tile_reads(gen_host(n, L, 1), L))
+
+
+@pytest.mark.parametrize("n,L,dist,s_bits", [
+    (5000, 150, 1, 7), (2048, 150, 0, 7), (4096, 100, 1, 7), (100, 159, 1, 7), (3000, 33, 1, 7), (3000, 32, 0, 7), (6000, 150, 1, 8),
+    (6000, 150, 1, 11), (2500, 250, 1, 7), (1, 150, 1, 7), (70000, 150, 1, 7), (4097, 47, 1, 9), (2049, 48, 0, 7), (3000, 49, 1, 24),
+])
+def test_tiled_kernel_matches_oracle(nt, n, L, dist, s_bits):
+    check(nt, gen_host(n, L, dist), L, s_bits=s_bits)
+
+
+@pytest.mark.parametrize("n,L,p_bad", [(3000, 150, 0.02), (2100, 150, 0.3), (2048, 64, 0.005), (500, 150, 1.0), (5000, 97, 0.001)])
+def test_tiled_kernel_non_acgt_bytes(nt, n, L, p_bad):
+    """N / IUPAC / punctuation anywhere, lower case and U as bases, all-N and poly-A reads: F1 and every counter"""
+    rng = np.random.default_rng(int(p_bad * 1000) + L)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKMBDHVSW.-*@`bf", dtype=np.uint8)  # '@', '`', 'B', 'b', 'F', 'f' differ from a base letter in one bit
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    bad = rng.random((n, L)) < p_bad
+    arr = np.where(bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    reads = [arr[i].tobytes() for i in range(n)]
+    reads[0] = b"A" * L
+    reads[1] = b"N" * L
+    reads[2] = (b"acgu" * L)[:L]
+    reads[3] = b"N" + reads[3][1:]
+    reads[4] = reads[4][:-1] + b"N"
+    reads[5] = reads[5][:31] + b"N" + reads[5][32:]
+    check(nt, reads, L)
+
+
+def test_tiled_every_lane_pushes_at_once(nt):
+    """identical reads: every lane has a candidate at the same steps (the strand queues run full and the walkers have to wait)"""
+    rng = random.Random(4)
+    one = "".join(rng.choice("ACGT") for _ in range(150)).encode()
+    check(nt, [one] * 6000, 150, s_bits=7)
+    check(nt, [b"A" * 150] * 4096, 150)
+
+
+def test_tiled_batches_and_modes(nt):
+    """several submits into one engine, direct atomics instead of the hit log, the partitioned apply"""
+    reads = gen_host(9000, 150, 1)
+    check(nt, reads, 150, pieces=3)
+    check(nt, reads, 150, flags=nt.FLAG_DIRECT_ATOMICS)
+    check(nt, reads, 150, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, pieces=2)
+
+
+def test_tiled_layout_falls_back_for_other_configurations(nt):
+    """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
+    reads = gen_host(5000, 150, 1)
+    t = torch.from_numpy(nt.tile_reads(reads, 150)).cuda()
+    for klist, gap, s_bits in (([20], 0, 7), ([32, 64], 0, 7), ([12], 2, 7), ([32], 0, 5)):
+        with nt.Engine(klist, gap=gap, r_bits=16, s_bits=s_bits) as e:
+            e.submit_tiled_device(t.data_ptr(), len(reads), 150)
+            tc, ph, f1 = e.finish(counters=True)
+        oc, of1 = orc.sketch_reads(reads, klist, gap, 16, s_bits)
+        assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+        with pytest.raises(nt.NtcError):
+            with nt.Engine(klist, gap=gap, r_bits=16, s_bits=s_bits, flags=nt.FLAG_REQUIRE_TILED) as e:
+                e.submit_tiled_device(t.data_ptr(), len(reads), 150)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg2u", "cfg3s"])
+def test_tiled_fullsize_matches_reference_goldens(nt, name, tmp_path):
+    """100 M synthetic reads through the tiled kernel against the digests of the REAL reference (see test_fullsize_gpu.py)"""
+    with open(os.path.join(GOLD, "digests.json")) as f:
+        meta = json.load(f)
+    cfg = meta["configs"][name]
+    n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
+    R = 10_000_000
+    buf = torch.empty(nt.tiled_bytes(R, L), dtype=torch.uint8, device="cuda")
+    with nt.Engine(cfg["klist"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED) as e:
+        for first in range(0, n, R):
+            m = min(R, n - first)
+            nt.gen_reads_tiled_device(buf.data_ptr(), meta["seed"], first, m, L, cfg["dist"], genome_len=100_000_000)
+            e.submit_tiled_device(buf.data_ptr(), m, L)  # the buffer is regenerated in place: stream order is all the contract asks for
+        tc, ph, f1 = e.finish(counters=True)
+    pl = cfg["planes"][0]
+    assert int(f1[0]) == pl["f1"]
+    assert hashlib.sha1(np.ascontiguousarray(tc[0]).data).hexdigest() == pl["t_counter_sha1"]
+    F0, f = nt.estimate(ph[0], rb, sb, cov)
+    out = tmp_path / f"{name}.hist"
+    nt.write_hist(out, f1[0], F0, f, cov)
+    assert out.read_bytes() == open(os.path.join(GOLD, pl["hist_file"]), "rb").read()
