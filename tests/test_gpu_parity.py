@@ -334,13 +334,14 @@ def test_adaptive_mode_probes_once(nt, s_bits, dist, want_mode):
         _, launches = e.kernel_time()
         assert e.update_mode() == want_mode
         assert 4 <= launches <= 5, launches
-    with nt.Engine([32], r_bits=27, s_bits=s_bits) as e:
-        e.set_profiling(True)
-        for _ in range(2):
-            e.submit_device(d.data_ptr(), n, L, stride)
-        e.flush()
-        _, launches = e.kernel_time()
-        assert e.update_mode() == 0 and launches == 3, (e.update_mode(), launches)  # 2 x K1b + ONE deferred K1 pass over the handed-back reads
+    for flags, want in ((nt.FLAG_DEFER_REDO, 3), (0, 4)):  # 2 x K1b + ONE deferred K1 pass over the handed-back reads / one pass per batch
+        with nt.Engine([32], r_bits=27, s_bits=s_bits, flags=flags) as e:
+            e.set_profiling(True)
+            for _ in range(2):
+                e.submit_device(d.data_ptr(), n, L, stride)
+            e.flush()
+            _, launches = e.kernel_time()
+            assert e.update_mode() == 0 and launches == want, (e.update_mode(), launches)
 
 
 @pytest.mark.parametrize("L,stride,s_bits,pn", [
