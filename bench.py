@@ -3,16 +3,18 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--reads-per-step R] [--dist g|u]
 
-A "step" is one pass of the hot path (ntc_submit_device: ntHash -> sample -> count into the
-device-resident t_Counter sketch) over one batch of synthetic reads that is already resident in HBM.
+A "step" is one pass of the hot path (ntc_submit_device / ntc_submit_tiled_device: ntHash -> sample -> count into
+the device-resident t_Counter sketch) over one batch of synthetic reads that is already resident in HBM.
 Default workload = BASELINE.json configs[1]: 100 M synthetic 150 bp reads, k=32, rBits=27, sBits=7,
-as 10 steps x 10 M reads.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank processes its own read-index range of the same size (weak scaling), then the per-GPU sketches
-are merged inside the timed region: RCCL reduce-scatter, per-rank value histograms of the summed slices, histograms to rank 0.
+as 10 steps x 10 M reads.  For N > 1 every rank (one per GPU; `--gpus N` re-launches itself under
+torch.distributed.run when it is not already running under it) processes its own read-index range of the
+same size (weak scaling), then the per-GPU sketches are merged inside the timed region: RCCL all-to-all of
+the 16-bit counter slices, wrapping local sums, per-rank value histograms of the summed slices, histograms to rank 0.
 
 One JSON line on rank 0: value = total k-mers (sum of F1 over ranks) / max-over-ranks wall time.
-Extra objects: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes) and "cpu_baseline"
-(the oracle's OpenMP restatement on a bounded sample, rank 0 / N=1 only).
+Extra objects: "roofline" (ALL kernels of a step — hash kernels and the deferred sketch update —, HIP-event timed,
+algorithmic bytes; "roofline_hash" prices the hash kernels alone against the bytes they move) and "cpu_baseline" (the
+reference's own ntRead compiled from /root/reference by oracle/Makefile, on a bounded sample, rank 0 / N=1 only).
 """
 import argparse
 import json
@@ -55,6 +57,10 @@ def parse():
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
     ap.add_argument("--bitslice", action="store_true", help="A/B: the bit-sliced kernel K1b even for small batches (it is the default for k = 32 batches of >= 128 tiles)")
     ap.add_argument("--lane-kernel", action="store_true", help="A/B: never use K1b, the lane-per-read kernel K1 takes every batch")
+    ap.add_argument("--layout", choices=["rows", "tiled"], default="rows",
+                    help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1b + K1), tiled = the tiled layout "
+                         "(ntc_submit_tiled_device: K1c, the streaming kernel with in-kernel N handling)")
+    ap.add_argument("--log-entries", type=int, default=0, help="capacity of the hit log in entries (0 = the engine's default: one per counter)")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
     return ap.parse_args()
@@ -115,11 +121,13 @@ def under_profiler():
 
 
 def live_pmc(argv_inner, n_steps):
-    """HBM traffic and VALU instruction counts of the hash kernels, measured NOW: this same command is re-run under
+    """HBM traffic and VALU instruction counts of a step's kernels, measured NOW: this same command is re-run under
     `rocprofv3 --pmc <counter>` once per counter (separate passes, as MI355X_MICROARCH.md prescribes for FETCH_SIZE /
-    WRITE_SIZE; no tracing domains), the counter is summed over every dispatch of the hash kernels and divided by the
-    number of bench steps the command ran.  Returns {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "SQ_INSTS_VALU": n} per step,
-    or None when rocprofv3 is missing or a pass fails (the committed table is the fallback then)."""
+    WRITE_SIZE; no tracing domains), the counter is summed over every dispatch of the hash kernels (sketch_*_kernel) AND
+    of the deferred sketch update (split / count / log_* kernels) and divided by the number of bench steps the command
+    ran; "<counter>_hash" is the share of the hash kernels alone.  Returns {"FETCH_SIZE": KB, "WRITE_SIZE": KB,
+    "SQ_INSTS_VALU": n, ...} per step, or None when rocprofv3 is missing or a pass fails (the committed table is the
+    fallback then)."""
     import csv
     import glob
     import shutil
@@ -137,16 +145,24 @@ def live_pmc(argv_inner, n_steps):
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return None
-            tot, seen = 0.0, 0
+            tot, tot_hash, seen = 0.0, 0.0, 0
             for f in files:
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == ctr and ("sketch_hf_kernel" in row["Kernel_Name"] or "sketch_bs_kernel" in row["Kernel_Name"]):
+                        if row["Counter_Name"] != ctr:
+                            continue
+                        kn = row["Kernel_Name"]
+                        is_hash = any(x in kn for x in ("sketch_hf_kernel", "sketch_bs_kernel", "sketch_ts_kernel", "append_slots"))
+                        is_apply = any(x in kn for x in ("split_kernel", "count_kernel", "log_atomics", "log_total", "log_probe", "log_decide"))
+                        if is_hash or is_apply:
                             tot += float(row["Counter_Value"])
                             seen += 1
+                            if is_hash:
+                                tot_hash += float(row["Counter_Value"])
             if seen == 0:
                 return None
             res[ctr] = tot / n_steps
+            res[ctr + "_hash"] = tot_hash / n_steps
         except Exception:
             return None
         finally:
@@ -157,7 +173,7 @@ def live_pmc(argv_inner, n_steps):
 def traffic_key(args, reads_per_launch):
     k = ",".join(map(str, klist_of(args)))
     return (f"dist={args.dist},L={args.read_len},k={k},gap={args.gap},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
-            + (",bitslice" if args.bitslice else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
+            + (",tiled" if args.layout == "tiled" else "") + (",bitslice" if args.bitslice else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
             + (",always-log" if args.always_log else ""))
 
 
@@ -181,9 +197,30 @@ def pmc_traffic(args, reads_per_launch):
         return None
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py <same flags>` (one rank per GPU over RCCL).  Fails loudly when the node has fewer GPUs."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but this node has {have} HIP device(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args)  # does not return
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and args.gpus != world_env and os.environ.get("RANK", "0") == "0":
+        print(f"bench.py: --gpus {args.gpus} ignored, running with WORLD_SIZE={world_env} ranks", file=sys.stderr)
     strong_total = None
     if args.config == 3:  # 1 B reads in total over the ranks, sBits = 11 (the >= 50 GB branch of ntcard.cpp:427-431)
         args.s_bits = 11
@@ -207,6 +244,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit(f"bench.py: rank {rank} wants device {local_rank} but this node has {torch.cuda.device_count()} HIP device(s)")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback"
@@ -216,6 +255,7 @@ def main():
     L, k = args.read_len, args.k
     klist = klist_of(args)
     nk = len(klist)
+    tiled = args.layout == "tiled"
     stride = (L + 3) & ~3
     if stride == L:
         stride += 4  # keep at least one separator byte between slots
@@ -223,6 +263,13 @@ def main():
     K, W = args.steps, args.warmup
     dist_id = 1 if args.dist == "g" else 0
     stream = torch.cuda.current_stream().cuda_stream
+    batch_bytes = nt.tiled_bytes(R, L) if tiled else R * stride + 16
+
+    def gen(buf, seed, first):
+        if tiled:
+            nt.gen_reads_tiled_device(buf.data_ptr(), seed, first, R, L, dist_id, 100_000_000, device=local_rank, stream=stream)
+        else:
+            nt.gen_reads_device(buf.data_ptr(), seed, first, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
 
     # ---- resident inputs: K step batches (+1 warmup batch), generated on the device (K0) ----
     reads_per_rank = R * K
@@ -231,21 +278,32 @@ def main():
         first, reads_per_rank = parallel.split_reads(K * R * world, world)[rank]
     # at most `nb` distinct batches stay resident (all K when they fit in half of the free HBM); a larger K cycles over them
     free_b, _ = torch.cuda.mem_get_info(dev)
-    nb = max(1, min(K, int(free_b * 0.5) // (R * stride + 16)))
+    nb = max(1, min(K, int(free_b * 0.5) // batch_bytes))
     batches = []
     for s in range(nb):
-        b = torch.empty(R * stride + 16, dtype=torch.uint8, device=dev)
-        nt.gen_reads_device(b.data_ptr(), args.seed, first + s * R, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
+        b = torch.empty(batch_bytes, dtype=torch.uint8, device=dev)
+        gen(b, args.seed, first + s * R)
         batches.append(b)
-    wb = torch.empty(R * stride + 16, dtype=torch.uint8, device=dev)
-    nt.gen_reads_device(wb.data_ptr(), args.seed ^ 0x5eed, 0, R, L, stride, dist_id, 100_000_000, device=local_rank, stream=stream)
+    wb = torch.empty(batch_bytes, dtype=torch.uint8, device=dev)
+    gen(wb, args.seed ^ 0x5eed, 0)
 
     # the sketch is a torch tensor so that torch.distributed (RCCL) can reduce it in place
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
-    eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream,
-                    ext_sketch=sketch, ext_f1=f1_dev, flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0) | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0)
-                    | (nt.FLAG_ALWAYS_LOG if args.always_log else 0))
+    # the resident batches stay untouched until the end of the run: the engine may share one pass over the reads K1b hands back
+    # between batches (NTC_FLAG_DEFER_REDO); the tiled path needs no such promise
+    eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream, ext_sketch=sketch, ext_f1=f1_dev,
+                    log_entries=args.log_entries,
+                    flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
+                    | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0)
+                    | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0)
+                    | (0 if tiled else nt.FLAG_DEFER_REDO))
+
+    def submit(buf):
+        if tiled:
+            eng.submit_tiled_device(buf.data_ptr(), R, L)
+        else:
+            eng.submit_device(buf.data_ptr(), R, L, stride)
 
     def barrier():
         torch.cuda.synchronize()
@@ -254,7 +312,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(W):
-        eng.submit_device(wb.data_ptr(), R, L, stride)
+        submit(wb)
     if W > 0:
         eng.flush()  # warm the deferred sketch update too (allocates its partition scratch)
     if use_dist and W > 0:  # warm the RCCL path too (same collectives as the timed merge)
@@ -267,7 +325,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for s in range(K):
-        eng.submit_device(batches[s % nb].data_ptr(), R, L, stride)
+        submit(batches[s % nb])
     eng.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter
     ph_merged = None
     if use_dist:
@@ -297,14 +355,27 @@ def main():
     if rank == 0:
         import numpy as np
         hits = int(sum((ph[ki].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum() for ki in range(nk)))
-        # --- roofline of the dominant kernel (nthash_kernel<0>), per launch, this rank ---
-        # one "launch" = the hash kernel(s) of one step (K1, or K1b + its redo pass; the first step of an adaptive engine is
-        # cut in two): HIP-event time of all of them / K
-        per_launch_kmers = total_kmers / max(world, 1) / max(K, 1)
-        per_launch_hits = hits / max(world, 1) / max(K, 1)
-        alg_bytes = R * (L + 4) + 4.0 * per_launch_hits  # bases+offset read once, 2 B r/w per sampled hit
-        avg_ms = ker_ms / max(K, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # --- roofline, per step, this rank.  A step's kernels = the hash kernels (K1 / K1b + its K1 pass / K1c) AND its share of the
+        # deferred sketch update (partition + count passes), both HIP-event timed on the engine's stream; the algorithmic bytes
+        #  are the bases + 4 B per read, read once, and 2 B read + 2 B written per sampled increment — the increments
+        # are carried out by the update kernels, so numerator and denominator cover the same work.  "roofline_hash" prices the hash
+        # kernels alone against the read stream alone.
+        per_step_kmers = total_kmers / max(world, 1) / max(K, 1)
+        per_step_hits = hits / max(world, 1) / max(K, 1)
+        read_bytes = R * (L + 4)
+        alg_bytes = read_bytes + 4.0 * per_step_hits
+        hash_ms = ker_ms / max(K, 1)
+        step_ms = (ker_ms + apply_ms) / max(K, 1)
+        achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+        achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
+        if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
+            kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"
+        elif (nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255 and not tiled
+              and (args.bitslice or (R >= 2048 * 128 and L - 31 >= 97 and not args.lane_kernel and not args.direct_atomics))):
+            kern = "sketch_bs_kernel (K1b: whole 2048-read tiles) + sketch_hf_kernel (K1: handed-back reads and tail)"
+        else:
+            kern = "sketch_hf_kernel (K1)"
+        peak_valu = 256 * 4 * 2.4e9 / 2  # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD-32 for 2 clk
         out = {
             "metric": "k-mers/s hashed+sketched (whole node) at k=32, 150 bp reads",
             "value": total_kmers / dt_max,
@@ -320,26 +391,31 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{world}x{reads_per_rank} synthetic {L} bp reads (dist={args.dist}, seed={args.seed}), "
                                    f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
-                                   f"{K} steps x {R} reads per GPU" + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
+                                   f"{K} steps x {R} reads per GPU, {'tiled' if tiled else 'row-major'} slots"
+                                   + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
                                    + (", RCCL all-to-all of 16-bit counter slices + value histograms to rank 0 inside the timed region" if world > 1 else ""),
-                       "traffic_key": traffic_key(args, R), "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank, "r_bits": args.r_bits, "s_bits": args.s_bits,
-                       "parallelism": f"read-sharded x{world}"},
+                       "traffic_key": traffic_key(args, R), "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank,
+                       "r_bits": args.r_bits, "s_bits": args.s_bits, "layout": args.layout, "parallelism": f"read-sharded x{world}",
+                       "rccl_ranks": dist.get_world_size() if use_dist else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),
-                         "kernel": ("sketch_bs_kernel (whole 2048-read tiles) + sketch_hf_kernel (handed-back reads and tail)"
-                                    if nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255
-                                    and (args.bitslice or (R >= 2048 * 128 and L - 31 >= 97 and not args.lane_kernel and not args.direct_atomics)) else "sketch_hf_kernel"),
-                         "avg_launch_ms": avg_ms, "launches": launches,
+                         "kernel": kern + " + split_kernel / count_kernel (deferred sketch update)",
+                         "avg_launch_ms": step_ms, "hash_ms": hash_ms, "apply_ms": apply_ms / max(K, 1), "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "kmers_per_launch": per_launch_kmers},
-            # deferred sketch update (ntc_apply.hip), HIP-event timed like the hash kernel; inside the timed region
+                         "kmers_per_launch": per_step_kmers},
+            # the hash kernels alone against the read stream alone (what the sketch update costs is in "roofline" above)
+            "roofline_hash": {"achieved": achieved_hash, "frac": achieved_hash / HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": hash_ms,
+                              "algorithmic_bytes_per_launch": read_bytes, "traffic": None},
+            # whole job: algorithmic bytes of a step / wall time of a step (includes launch gaps and the final flush)
+            "roofline_step": {"achieved": alg_bytes / (dt_max / K) / 1e9, "frac": alg_bytes / (dt_max / K) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"},
+            # deferred sketch update (ntc_apply.hip), HIP-event timed like the hash kernels; inside the timed region
             "sketch_apply": {"mode_at_end": "direct atomics" if update_mode else "hit log", "applies": applies, "total_ms": apply_ms, "ns_per_increment": apply_ms * 1e6 / max(hits, 1)},
-            # the kernel is VALU-issue bound, so it is also priced against the vector ALUs: wave-instructions
-            # per launch from the committed PMC pass of this workload (SQ_INSTS_VALU, profiles/traffic_pmc.json; null when
-            # this workload was not profiled), per 64-lane base step; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 clk per wave64 op.
+            # the path is VALU-issue bound, so it is also priced against the vector ALUs: wave-instructions of ALL of a
+            # step's kernels (SQ_INSTS_VALU), per 64-lane base step; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 clk per wave64 instruction
             "valu": (lambda v: {"wave_insts_per_launch": v, "per_wave_step": (v / (R * L / 64.0)) if v else None,
-                                "wave_insts_per_s": (v / (avg_ms * 1e-3)) if v and avg_ms > 0 else None,
-                                "peak_wave_insts_per_s": 256 * 4 * 2.4e9 / 2})(pmc_valu(args, R)),
+                                "wave_insts_per_s": (v / (step_ms * 1e-3)) if v and step_ms > 0 else None,
+                                "peak_wave_insts_per_s": peak_valu,
+                                "frac": (v / (step_ms * 1e-3) / peak_valu) if v and step_ms > 0 else None})(pmc_valu(args, R)),
             "f1_total": total_kmers,
             "sampled_increments": hits,
         }
@@ -356,10 +432,13 @@ def main():
                 # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KB; wide streaming reads are
                 # under-counted by half on gfx950 -> traffic = 2 * FETCH_SIZE + WRITE_SIZE (an upper bound: applied to all of FETCH)
                 out["roofline"]["traffic"] = int((2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
-                out["roofline"]["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"
+                out["roofline"]["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, hash + sketch-update kernels"
+                out["roofline_hash"]["traffic"] = int((2.0 * live["FETCH_SIZE_hash"] + live["WRITE_SIZE_hash"]) * 1024)
                 v = live["SQ_INSTS_VALU"]
                 out["valu"].update({"wave_insts_per_launch": v, "per_wave_step": v / (R * L / 64.0),
-                                    "wave_insts_per_s": (v / (avg_ms * 1e-3)) if avg_ms > 0 else None, "source": "live: rocprofv3 --pmc SQ_INSTS_VALU"})
+                                    "wave_insts_per_s": (v / (step_ms * 1e-3)) if step_ms > 0 else None,
+                                    "frac": (v / (step_ms * 1e-3) / peak_valu) if step_ms > 0 else None,
+                                    "hash_kernels_only": live["SQ_INSTS_VALU_hash"], "source": "live: rocprofv3 --pmc SQ_INSTS_VALU"})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, stride)

@@ -646,6 +646,31 @@ def test_bench_under_torchrun_single_rank(tmp_path):
     assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"] and j["n_gpus"] == 1
 
 
+def test_bench_gpus_flag_launches_real_ranks(tmp_path):
+    """`python bench.py --gpus N` (the form the driver uses) must run N RCCL ranks, not one: N = min(2, device_count) ranks through
+    bench.py's own re-launch under torch.distributed.run, the merged result compared with the sums of N one-rank runs over the same
+    read-index ranges (rank r of N hashes reads [r * R * K, (r + 1) * R * K)); more GPUs than the node has must fail loudly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = min(2, torch.cuda.device_count())
+    common = ["--steps", "2", "--warmup", "1", "--reads-per-step", "1000000", "--no-cpu-baseline", "--no-live-pmc"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert j["n_gpus"] == n and (n == 1 or j["config"]["rccl_ranks"] == n)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + ["--steps", str(2 * n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=900, cwd=root, env=env)  # one rank over the union of the N ranks' read ranges
+    k = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"]
+    too_many = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)] + common,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=root, env=env)
+    assert too_many.returncode != 0 and b"HIP device" in too_many.stderr
+
+
 def test_randomised_shapes_small():
     """a short run of the randomised sweep (tools/fuzz_parity.py: random k lists, gaps, lengths, dirt, submit patterns)"""
     import subprocess
