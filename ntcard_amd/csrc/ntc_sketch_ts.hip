@@ -187,14 +187,15 @@ constexpr uint32_t kOffDB = kOffPR + kRing * 8192u;          // dirty words  [kR
 constexpr uint32_t kOffQF = kOffDB + kRing * 256u;           // F queue      [kQCap + 64] x 8 B
 constexpr uint32_t kOffQR = kOffQF + (kQCap + 64u) * 8u;     // R queue
 constexpr uint32_t kOffSQ = kOffQR + (kQCap + 64u) * 8u;     // suspects     [kSCap] x 8 B
-constexpr uint32_t kOffDQ = kOffSQ + kSCap * 8u;             // dirty queue  [kDCap] x 8 B
+constexpr uint32_t kOffS2 = kOffSQ + kSCap * 8u;             // suspects of the second resolver
+constexpr uint32_t kOffDQ = kOffS2 + kSCap * 8u;             // dirty queue  [kDCap] x 8 B
 constexpr uint32_t kOffXF = kOffDQ + kDCap * 8u;             // F's "top bits >= 01..1" planes of half a block [8][64] dwords
 constexpr uint32_t kOffXR = kOffXF + 2048u;                  // R's
 constexpr uint32_t kOffCT = kOffXR + 2048u;                  // control words
 constexpr uint32_t kTeamBytes = kOffCT + 256u;
 // control words (all monotonic).  Words that one wave reads together sit together: {BLK_F, QF_TAIL, BLK_R, QR_TAIL} is one
 // ds_read_b128 for A2, {PL_TAKEN_F, PL_TAKEN_R} one ds_read_b64 for A1, the block-end tails are {F, R} pairs.
-enum { C_BLK_F = 0, C_QF_TAIL = 1, C_BLK_R = 2, C_QR_TAIL = 3, C_PR_READY = 7, C_RESOLVED = 8,
+enum { C_BLK_F = 0, C_QF_TAIL = 1, C_BLK_R = 2, C_QR_TAIL = 3, C_RES_R = 4, C_PR_READY = 7, C_RES_F = 8,
        C_QF_HEAD = 9, C_QR_HEAD = 10, C_DQ_TAIL = 11, C_DQ_HEAD = 12,
        C_XPUB_F = 13, C_XPUB_R = 14 /* half blocks whose planes are in the exchange area */, C_XCONS_F = 15 /* half blocks of R's planes F has read */,
        C_XCONS_R = 32, C_BT = 16 /* 8 pairs: queue tails {F, R} at the end of block b & 7 */ };
@@ -254,6 +255,345 @@ __device__ __forceinline__ void lds_wait_ge(const uint32_t* p, uint32_t v)
 #define TS_FLUSH(role)
 #endif
 
+
+// ---- the resolve stage of ONE strand's candidates (shared by the two assistant waves of a team) -----------------------------
+// Candidate words come out of the strand's LDS queue.  Every lane owns NI item SLOTS (registers): a slot holds one candidate
+// word of some walker lane and step and gives up its lowest set bit (one read) per pass; an empty slot takes the next word of
+// the queue.  One pass = up to 64 NI candidates: packed bases from the ring -> closed form, 4 bases per look-up -> canonical
+// hash (nthash.hpp:275-279) -> ntComp's patterns (ntcard.cpp:132-145) -> hit log.  The three LDS round trips of a pass (words, packed
+// bases, table entries) are each issued for all NI slots at once, and slot / log positions come from one prefix sum per pass:
+// a lone wave pays ~20 clk for every vector compare whose mask a scalar instruction then reads.
+// Blocks (= chunks) are TAKEN in order (cur: every word of the blocks before it has left the queue) and RESOLVED in order (res:
+// no slot holds a word of a block before it; published: the packer may reuse the ring slots those blocks read).  A word with
+// several bits stays in its slot over several passes, also across block boundaries; whenever the wave would otherwise wait it
+// runs a pass for the slots alone, so `res` never trails for want of new candidates.
+template <int K, int NI>
+struct TsResolver {
+	static constexpr int KB = K / 16;
+	const TsArgs* a;
+	unsigned char* tb;
+	uint32_t* ctl;
+	const unsigned char* t4;
+	const uint2* queue; // the strand's queue
+	uint2* sq;          // suspects: candidates whose window touches a 16-byte piece with a non-ACGTU byte somewhere
+	uint32_t c_pair, c_bt, c_head, c_res; // control words: {blocks walked, queue tail}, tails at block ends (stride 2), queue head, blocks resolved
+	uint32_t lane, C, n_teams, team_g, n_valid_last, rmask, rbuck, s_bits, log_stride;
+	bool has_partial, use_log;
+	// state
+	uint32_t sh[NI], sm[NI], sb[NI]; // slot: candidate word, its meta word, the block it was taken in
+	uint32_t head, sq_fill, lreg, lfill;
+	uint32_t cur, res, t, seq, c, lim;
+	bool all_taken, ring_ok, done, tile_event;
+
+	__device__ __forceinline__ void init(const TsArgs* a_, unsigned char* tb_, uint32_t* ctl_, const unsigned char* t4_, bool fwd, uint32_t lane_, uint32_t C_, uint32_t n_teams_,
+	                                     uint32_t team_g_, uint32_t log_first, uint32_t log_stride_)
+	{
+		a = a_;
+		tb = tb_;
+		ctl = ctl_;
+		t4 = t4_;
+		queue = reinterpret_cast<const uint2*>(tb + (fwd ? kOffQF : kOffQR));
+		sq = reinterpret_cast<uint2*>(tb + (fwd ? kOffS2 : kOffSQ));
+		c_pair = fwd ? C_BLK_F : C_BLK_R;
+		c_bt = C_BT + (fwd ? 0u : 1u);
+		c_head = fwd ? C_QF_HEAD : C_QR_HEAD;
+		c_res = fwd ? C_RES_F : C_RES_R;
+		lane = lane_;
+		C = C_;
+		n_teams = n_teams_;
+		team_g = team_g_;
+		has_partial = (a->n_reads & (kTile - 1u)) != 0u;
+		n_valid_last = has_partial ? (uint32_t)(a->n_reads & (kTile - 1u)) : kTile;
+		rmask = (1u << a->r_bits) - 1u;
+		rbuck = 1u << a->r_bits;
+		s_bits = a->s_bits;
+		log_stride = log_stride_;
+		use_log = a->log_regions != 0 && (a->log_mode == nullptr || rfl(*a->log_mode) == 0u);
+		lreg = log_first;
+		lfill = 0;
+		if (use_log && lreg < a->log_regions) lfill = rfl(a->log_fill[lreg]);
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+			sh[j] = sm[j] = sb[j] = 0;
+		head = sq_fill = 0;
+		cur = res = seq = c = lim = 0;
+		t = team_g;
+		all_taken = team_g >= a->n_tiles;
+		ring_ok = done = tile_event = false;
+	}
+	__device__ __forceinline__ v4u32 raw_piece(uint32_t tt, uint32_t cc, uint32_t r) const
+	{
+		return *reinterpret_cast<const v4u32*>(a->tiles + (((size_t)tt * C + cc) * kTile + r) * 16u);
+	}
+	// append the wave's hits to its hit-log region (ntComp's increment, deferred: ntc_apply.hip); cnt = hits of this lane (0 / 1 per key)
+	template <int N>
+	__device__ __forceinline__ void log_append(const uint32_t (&hit)[N], const uint32_t (&key)[N], uint32_t nhit)
+	{
+		uint32_t hincl, total;
+		if constexpr (N == 1) {
+			const uint64_t hmk = ballot(nhit != 0u);
+			hincl = mbcnt(hmk) + nhit;
+			total = (uint32_t)__popcll(hmk);
+		} else {
+			hincl = wave_scan(nhit);
+			total = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
+		}
+		if (total == 0u) return;
+		if (use_log) {
+			while (lreg < a->log_regions && total > a->log_region_cap - lfill) {
+				if (lane == 0) a->log_fill[lreg] = lfill;
+				lreg += log_stride;
+				lfill = lreg < a->log_regions ? rfl(a->log_fill[lreg]) : 0u;
+			}
+		}
+		if (use_log && lreg < a->log_regions) {
+			uint32_t* dst = a->log + (uint64_t)lreg * a->log_region_cap + lfill + (hincl - nhit); // a lane's hits go behind those of the lanes below it
+#pragma unroll
+			for (int j = 0; j < N; ++j) {
+#ifndef TS_EXP_NOLOG
+				if (hit[j]) *dst = key[j];
+#endif
+				dst += hit[j];
+			}
+			lfill += total;
+		} else { // no log, or this wave's regions are full: the literal form, one device atomic per sampled k-mer (ntcard.cpp:142-143)
+#pragma unroll
+			for (int j = 0; j < N; ++j)
+				if (hit[j]) atomicAdd(a->sketch0 + key[j], 1u);
+		}
+	}
+	// suspects: exact validity from the raw bytes.  entry: {counter index, read | window << 11 | (tile sequence number & 15) << 27}
+	__device__ __forceinline__ void flush_suspects()
+	{
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		for (uint32_t base = 0; base < sq_fill; base += 64u) {
+			const bool act = base + lane < sq_fill;
+			const uint2 s = sq[act ? base + lane : 0u];
+			const uint32_t r = s.y & 2047u, w = (s.y >> 11) & 0xffffu, c0 = w >> 4;
+			const uint32_t tt = team_g + (seq - ((seq - (s.y >> 27)) & 15u)) * n_teams; // taken at most a tile ago
+			uint32_t m0 = 0, m1 = 0, m2 = 0;
+			if (act) {
+				m0 = inv16(raw_piece(tt, c0, r));
+				m1 = inv16(raw_piece(tt, c0 + 1u, r));
+				if (c0 + 2u < C) m2 = inv16(raw_piece(tt, c0 + 2u, r));
+			}
+			const uint64_t all = (uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32);
+			const uint32_t ok[1] = {act && (uint32_t)(all >> (w & 15u)) == 0u ? 1u : 0u}; // no non-ACGTU byte among the window's 32 bases (k = 32)
+			const uint32_t ky[1] = {s.x};
+			log_append<1>(ok, ky, ok[0]);
+		}
+		sq_fill = 0;
+	}
+	__device__ __forceinline__ bool slots_busy() const
+	{
+		bool any = false;
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+			any |= sh[j] != 0u;
+		return ballot(any) != 0;
+	}
+	__device__ __forceinline__ bool slots_from(uint32_t blk) const // some slot still holds a word taken in block `blk`
+	{
+		bool any = false;
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+			any |= sh[j] != 0u && sb[j] == blk;
+		return ballot(any) != 0;
+	}
+	__device__ __forceinline__ void retire() // blocks before `cur` are resolved once no slot holds a word of theirs
+	{
+		while (res < cur && !slots_from(res)) {
+			++res;
+			lds_publish(ctl + c_res, res);
+		}
+	}
+	__device__ __forceinline__ void pass(uint32_t avail) // avail: words the queue may hand out now
+	{
+		const uint32_t* const pr = reinterpret_cast<const uint32_t*>(tb + kOffPR);
+		const uint32_t* const db = reinterpret_cast<const uint32_t*>(tb + kOffDB);
+		// 1. refill the empty slots from the queue: free slot number x of the wave takes word x.  Straight-line: a slot that takes
+		// nothing reads the queue's spare area
+		uint32_t nfree = 0;
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+			nfree += sh[j] == 0u ? 1u : 0u;
+		uint32_t fincl, n_free;
+		if constexpr (NI == 1) {
+			const uint64_t fm = ballot(nfree != 0u);
+			fincl = mbcnt(fm) + nfree;
+			n_free = (uint32_t)__popcll(fm);
+		} else {
+			fincl = wave_scan(nfree);
+			n_free = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
+		}
+		const uint32_t n_new = n_free < avail ? n_free : avail;
+		uint2 nw[NI];
+		bool take[NI];
+		uint32_t ix = fincl - nfree;
+#pragma unroll
+		for (int j = 0; j < NI; ++j) {
+			const bool fr = sh[j] == 0u;
+			take[j] = fr && ix < n_new;
+			nw[j] = queue[take[j] ? (head + ix) & (kQCap - 1u) : kQCap + lane];
+			ix += fr ? 1u : 0u;
+		}
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int j = 0; j < NI; ++j) {
+			sh[j] = take[j] ? nw[j].x : sh[j];
+			sm[j] = take[j] ? nw[j].y : sm[j];
+			sb[j] = take[j] ? cur : sb[j];
+		}
+		head += n_new;
+		if (n_new) lds_publish(ctl + c_head, head); // (behind the item reads above)
+		// 2. one candidate per slot: its packed words + the dirty words of the pieces its window touches
+		uint32_t d0[NI], d1[NI], d2[NI], b0[NI], b1[NI], b2[NI], rr[NI], ww[NI], mm[NI], yy[NI];
+#pragma unroll
+		for (int j = 0; j < NI; ++j) {
+			const uint32_t h = sh[j], y = sm[j];
+			const uint32_t m = (uint32_t)__builtin_ctz(h | 0x80000000u);
+			sh[j] = h & (h - 1u);
+			const uint32_t l0 = y & 63u, s0 = (y >> 8) & 7u;
+			const uint32_t col = m * 64u + l0;
+			const uint32_t s1 = s0 + 1u == kRing ? 0u : s0 + 1u, s2 = s1 + 1u == kRing ? 0u : s1 + 1u;
+			d0[j] = pr[s0 * 2048u + col];
+			d1[j] = pr[s1 * 2048u + col];
+			d2[j] = pr[s2 * 2048u + col];
+			b0[j] = db[s0 * 64u + l0];
+			b1[j] = db[s1 * 64u + l0];
+			b2[j] = db[s2 * 64u + l0];
+			rr[j] = col;
+			ww[j] = (y >> 11) & 0xffffu;
+			mm[j] = m;
+			yy[j] = h != 0u ? y | 0x80000000u : 0u; // bit 31: the slot holds a candidate (the walkers leave it clear)
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// 3. closed form, 4 bases per look-up: all table addresses, then all look-ups in flight together, then the XORs
+		uint32_t toff[NI][K / 4];
+#pragma unroll
+		for (int j = 0; j < NI; ++j) {
+			const uint32_t shf = (ww[j] & 15u) * 2u;
+#pragma unroll
+			for (int i = 0; i < KB; ++i) {
+				const uint32_t x = i == 0 ? alignbit(d1[j], d0[j], shf) : alignbit(d2[j], d1[j], shf); // 16 bases of the window
+#pragma unroll
+				for (int g = 0; g < 4; ++g)
+					toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		v4u32 tv[NI][K / 4];
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+#pragma unroll
+			for (int i = 0; i < K / 4; ++i)
+#ifdef TS_EXP_NOTABLE
+				tv[j][i] = v4u32{toff[j][i], d0[j], d1[j], d2[j]};
+#else
+				tv[j][i] = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)i * 4096u + toff[j][i]); // the group's 4 KiB rides in the offset field
+#endif
+		__builtin_amdgcn_sched_barrier(0);
+		uint32_t nhit = 0, anysus = 0;
+		uint32_t hit[NI], key[NI], sus[NI]; // 0 / 1
+#pragma unroll
+		for (int j = 0; j < NI; ++j) {
+			static_assert(K / 4 == 8, "XOR tree below is written for 8 table entries");
+			auto x3 = [](uint32_t p, uint32_t q, uint32_t r) { return (uint32_t)__builtin_amdgcn_bitop3_b32(p, q, r, 0x96); };
+			const uint32_t flo = x3(x3(tv[j][0].x, tv[j][1].x, tv[j][2].x), x3(tv[j][3].x, tv[j][4].x, tv[j][5].x), tv[j][6].x ^ tv[j][7].x);
+			const uint32_t fhi = x3(x3(tv[j][0].y, tv[j][1].y, tv[j][2].y), x3(tv[j][3].y, tv[j][4].y, tv[j][5].y), tv[j][6].y ^ tv[j][7].y);
+			const uint32_t rlo = x3(x3(tv[j][0].z, tv[j][1].z, tv[j][2].z), x3(tv[j][3].z, tv[j][4].z, tv[j][5].z), tv[j][6].z ^ tv[j][7].z);
+			const uint32_t rhi = x3(x3(tv[j][0].w, tv[j][1].w, tv[j][2].w), x3(tv[j][3].w, tv[j][4].w, tv[j][5].w), tv[j][6].w ^ tv[j][7].w);
+			const uint64_t fh = ((uint64_t)fhi << 32) | flo, rh = ((uint64_t)rhi << 32) | rlo;
+			const bool rev = rh < fh; // nthash.hpp:275-279
+			const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
+			// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
+			const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
+			const bool c0m = (hi >> (31 - s_bits)) == 1u;
+			const uint32_t y = yy[j];
+			// the candidate of the canonical strand only (both strands may have flagged the window)
+			bool ht = ((y >> 31) != 0u) & (rev == ((y & 64u) != 0u)) & (c0m | c1);
+			if (has_partial) ht &= (y & 128u) == 0u || rr[j] < n_valid_last; // slots behind the last read of the batch
+			key[j] = a->key_base + (lo & rmask) + (c1 ? rbuck : 0u);
+			// a window that touches a 16-byte piece with a non-ACGTU byte somewhere is settled from the raw bytes (the third piece
+			// only counts when the window is not chunk-aligned)
+			const uint32_t dd = (b0[j] | b1[j] | ((ww[j] & 15u) != 0u ? b2[j] : 0u)) >> mm[j];
+			sus[j] = ht ? dd & 1u : 0u;
+			hit[j] = (ht ? 1u : 0u) & ~sus[j];
+			nhit += hit[j];
+			anysus |= sus[j];
+#ifdef TS_DEBUG
+			if ((y >> 31) && a->dbg) {
+				const uint32_t ixd = atomicAdd(a->dbg, 1u);
+				uint32_t* o = a->dbg + 16 + 12 * (size_t)ixd;
+				o[0] = rr[j]; o[1] = ww[j]; o[2] = 0; o[3] = y; o[4] = d0[j]; o[5] = d1[j]; o[6] = d2[j]; o[7] = flo; o[8] = fhi; o[9] = rlo; o[10] = rhi;
+				o[11] = (rev ? 1u : 0u) | ((y & 64u) ? 2u : 0u) | (ht ? 4u : 0u);
+			}
+#endif
+		}
+		log_append<NI>(hit, key, nhit);
+		if (ballot(anysus != 0u) != 0) { // rare
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				const uint64_t smk = ballot(sus[j] != 0u);
+				if (sus[j]) sq[sq_fill + mbcnt(smk)] = make_uint2(key[j], rr[j] | (ww[j] << 11) | (yy[j] & 0x78000000u)); // + the walker's tile tag (bits 27..30)
+				sq_fill += (uint32_t)__popcll(smk);
+			}
+			if (sq_fill > kSCap - 64u * NI) flush_suspects();
+		}
+	}
+	// one turn of the resolver: 0 nothing to do right now, 1 worked, 2 every block of every tile is resolved
+	__device__ __forceinline__ int step()
+	{
+		bool run = false;
+		uint32_t avail = 0;
+		int rc = 0;
+		if (all_taken) {
+			if (!slots_busy()) return 2;
+			run = true;
+		} else if (!ring_ok) {
+			ring_ok = (int32_t)(lds_peek(ctl + C_PR_READY) - (cur + 1u)) >= 0; // the packed words of this block's chunk
+			if (!ring_ok) run = slots_busy();
+		}
+		if (ring_ok) {
+			if (!done && lim - head < 64u * NI) {
+				// blocks walked and queue tail in one read; a tail read together with "block walked" may already hold words of later
+				// blocks, whose chunks are not in the ring yet: then the tail noted at the end of the block counts
+				const uint2 q = lds_peek2(ctl + c_pair);
+				done = (int32_t)(q.x - (cur + 1u)) >= 0;
+				lim = done ? lds_peek(ctl + c_bt + 2u * (cur & 7u)) : q.y;
+			}
+			avail = lim - head;
+			if (avail >= 48u * NI || (done && avail != 0u)) { // a pass costs the same whether its slots are full or not: wait for 3/4 of them
+				run = true;
+			} else if (done) { // every word of block cur has left the queue (some may still sit in slots): next block
+				++cur;
+				ring_ok = done = false;
+				rc = 1;
+				if (++c == C) {
+					c = 0;
+					tile_event = true; // (the caller books the tile: F1, dirty pieces)
+					++seq;
+					t += n_teams;
+					all_taken = t >= a->n_tiles;
+				}
+			} else {
+				run = slots_busy();
+			}
+		}
+		if (run) {
+			pass(avail);
+			rc = 1;
+		}
+		retire();
+		return rc;
+	}
+	__device__ __forceinline__ void finish()
+	{
+		flush_suspects();
+		if (use_log && lane == 0 && lreg < a->log_regions) a->log_fill[lreg] = lfill;
+	}
+};
+
 } // namespace
 
 template <int K, int SB>
@@ -304,6 +644,11 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			const unsigned char* p = a.tiles + ((size_t)rfl(t) * C + rfl(c)) * (size_t)(kTile * 16u);
 			return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p), 0, (int)(kTile * 16u), 0x00020000);
 		};
+		// This wave also resolves the FORWARD strand's candidates (the other assistant takes the reverse strand's): whenever the ring
+		// has no room for the next chunk it runs resolver turns, and one turn per chunk otherwise.  NI = 2 slots per lane: the chunk
+		// in flight keeps 128 registers.
+		TsResolver<K, 2> rs;
+		rs.init(&a, tb, ctl, t4, /*fwd=*/true, (uint32_t)lane, C, n_teams, team_g, team_g * 2u + 1u, n_teams * 2u);
 		uint32_t dq_tail = 0;
 		const uint32_t my_tiles = team_g < a.n_tiles ? (a.n_tiles - team_g + n_teams - 1u) / n_teams : 0u;
 		const uint32_t total = my_tiles * C; // this team's chunks as one flat sequence
@@ -321,9 +666,28 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				const uint32_t tn = last_c ? t + n_teams : t, cn = last_c ? 0u : c + 1u;
 				const bool more = n + 1u < total;
 				const __amdgpu_buffer_rsrc_t rn = chunk_rsrc(more ? tn : t, more ? cn : c); // (the last chunk re-reads itself: one unconditional load site)
-				// the packed words overwrite chunk n - 5, which blocks <= n - 3 read
+				// One resolver turn per chunk keeps the forward queue moving while the walkers have chunks ahead of them; more of them
+				// while the ring has no room for this chunk: its packed words overwrite chunk n - 5, which blocks <= n - 3 read (both
+				// strands' resolvers).  (ONE call site inside the chunk loop: the chunk in flight keeps 128 registers.)
 #ifndef TS_EXP_A1_FREE
-				if (n >= 3u) TS_WAIT(1, ctl + C_RESOLVED, n - 2u);
+				{
+					TS_T(tg0);
+					while (true) {
+						TS_T(ts0);
+						const int rc = rs.step();
+						TS_T(ts1);
+#ifdef TS_TIMERS
+						if (rc != 0) {
+							tacc[5] += ts1 - ts0;
+							tacc[6] += 1;
+						}
+#endif
+						if (n < 3u || ((int32_t)(rs.res - (n - 2u)) >= 0 && (int32_t)(lds_peek(ctl + C_RES_R) - (n - 2u)) >= 0)) break;
+						if (rc == 0) __builtin_amdgcn_s_sleep(1);
+					}
+					TS_T(tg1);
+					TS_ACC(1, tg0, tg1);
+				}
 #endif
 				const uint32_t slot = n % kRing;
 				uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
@@ -356,6 +720,12 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				c = cn;
 			}
 		}
+		while (true) { // every chunk is packed: the rest of the forward strand's candidates
+			const int rc = rs.step();
+			if (rc == 2) break;
+			if (rc == 0) __builtin_amdgcn_s_sleep(1);
+		}
+		rs.finish();
 		TS_FLUSH(2);
 		return;
 	}
@@ -402,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				}
 			};
 			for (uint32_t t = team_g, seq = 0; t < a.n_tiles; t += n_teams, ++seq) {
-				meta_tile = (uint32_t)lane | (FWD ? 0u : 64u) | ((has_partial && t == a.n_tiles - 1u) ? 128u : 0u);
+				meta_tile = (uint32_t)lane | (FWD ? 0u : 64u) | ((has_partial && t == a.n_tiles - 1u) ? 128u : 0u) | ((seq & 15u) << 27); // bits 27..30: which tile (suspects)
 				nb0 = (seq * C) % kRing;
 				uint32_t S[31];
 #pragma unroll
@@ -488,65 +858,16 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 
 #endif
 #ifndef TS_NO_A2
-	// =============================== A2: resolve candidates, log hits, settle dirty pieces, F1 ===============================
+	// =============================== A2: resolve the reverse strand's candidates, settle dirty pieces, F1 ===============================
 	{
-		const uint32_t rmask = (1u << a.r_bits) - 1u, rbuck = 1u << a.r_bits, s_bits = a.s_bits;
-		// ---- hit log (see ntc_sketch_hf.hip): this wave's regions are team_g, team_g + n_teams, ... ----
-		const bool use_log = a.log_regions != 0 && (a.log_mode == nullptr || rfl(*a.log_mode) == 0u);
-		uint32_t lreg = team_g, lfill = 0;
-		if (use_log && lreg < a.log_regions) lfill = rfl(a.log_fill[lreg]);
-		auto log_emit = [&](bool hit, uint32_t key) {
-			const uint64_t m = ballot(hit);
-			if (m == 0) return;
-			if (!use_log) {
-				if (hit) atomicAdd(a.sketch0 + key, 1u);
-				return;
-			}
-			const uint32_t c = (uint32_t)__popcll(m);
-			while (lreg < a.log_regions && c > a.log_region_cap - lfill) {
-				if (lane == 0) a.log_fill[lreg] = lfill;
-				lreg += n_teams;
-				lfill = lreg < a.log_regions ? rfl(a.log_fill[lreg]) : 0u;
-			}
-			if (lreg < a.log_regions) {
-				if (hit) a.log[(uint64_t)lreg * a.log_region_cap + lfill + mbcnt(m)] = key;
-				lfill += c;
-			} else if (hit) {
-				atomicAdd(a.sketch0 + key, 1u);
-			}
-		};
-		const uint32_t* const pr = reinterpret_cast<const uint32_t*>(tb + kOffPR);
-		const uint32_t* const db = reinterpret_cast<const uint32_t*>(tb + kOffDB);
-		const uint2* const qF = reinterpret_cast<const uint2*>(tb + kOffQF);
-		uint2* const sq = reinterpret_cast<uint2*>(tb + kOffSQ);
+		TsResolver<K, 2> rs;
+		rs.init(&a, tb, ctl, t4, /*fwd=*/false, (uint32_t)lane, C, n_teams, team_g, team_g * 2u, n_teams * 2u);
 		const uint2* const dq = reinterpret_cast<const uint2*>(tb + kOffDQ);
-		uint32_t hF = 0, hR = 0, sq_fill = 0, dq_head = 0; // wave-uniform
+		uint32_t dq_head = 0;
 		uint64_t f1_add = 0;  // wave-uniform: reads x windows
 		uint32_t f1_sub = 0;  // per lane: windows lost to non-ACGTU bytes
-		const uint32_t n_valid_last = has_partial ? (uint32_t)(a.n_reads & (kTile - 1u)) : kTile;
-		auto raw_piece = [&](uint32_t t, uint32_t c, uint32_t r) {
-			return *reinterpret_cast<const v4u32*>(a.tiles + (((size_t)t * C + c) * kTile + r) * 16u);
-		};
-		// ---- suspects: candidates whose window touches a dirty piece; exact validity from the raw bytes ----
-		auto flush_suspects = [&](uint32_t seq_now) { // entry: {counter index, read | window << 11 | (tile sequence number & 15) << 27}
-			for (uint32_t base = 0; base < sq_fill; base += 64u) {
-				const bool act = base + (uint32_t)lane < sq_fill;
-				const uint2 s = sq[act ? base + (uint32_t)lane : 0u];
-				const uint32_t r = s.y & 2047u, w = (s.y >> 11) & 0xffffu, c0 = w >> 4;
-				const uint32_t t = team_g + (seq_now - ((seq_now - (s.y >> 27)) & 15u)) * n_teams; // taken at most a tile ago
-				uint32_t m0 = 0, m1 = 0, m2 = 0;
-				if (act) {
-					m0 = inv16(raw_piece(t, c0, r));
-					m1 = inv16(raw_piece(t, c0 + 1u, r));
-					if (c0 + 2u < C) m2 = inv16(raw_piece(t, c0 + 2u, r));
-				}
-				const uint64_t all = (uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32);
-				const bool ok = act && (uint32_t)(all >> (w & 15u)) == 0u; // no non-ACGTU byte among the window's 32 bases (k = 32)
-				log_emit(ok, s.x);
-			}
-			sq_fill = 0;
-		};
-		// ---- dirty pieces: F1 loses the windows whose RIGHTMOST non-ACGTU byte lies in the piece.  A1 is at most one tile
+		const uint32_t n_valid_last = rs.n_valid_last;
+		// ---- dirty pieces: F1 loses the windows whose RIGHTMOST non-ACGTU byte lies in the piece.  The packer is at most one tile
 		// ahead of this wave, so one bit of the tile sequence number identifies an item's tile ----
 		auto drain_dirty = [&](uint32_t t_cur, uint32_t seq_cur) {
 			const uint32_t tail = lds_peek(ctl + C_DQ_TAIL);
@@ -560,10 +881,10 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				while (word != 0u) {
 					const uint32_t r = (uint32_t)__builtin_ctz(word) * 64u + l0;
 					word &= word - 1u;
-					const uint32_t A = inv16(raw_piece(t, c, r));
+					const uint32_t A = inv16(rs.raw_piece(t, c, r));
 					uint32_t B = 0;
-					if (c + 1u < C) B = inv16(raw_piece(t, c + 1u, r));
-					if (c + 2u < C) B |= inv16(raw_piece(t, c + 2u, r)) << 16;
+					if (c + 1u < C) B = inv16(rs.raw_piece(t, c + 1u, r));
+					if (c + 2u < C) B |= inv16(rs.raw_piece(t, c + 2u, r)) << 16;
 					if (A != 0u) {
 						// window w = 16 c - (k - 1) + j ends at base 16 c + j: it holds a byte of A iff lo <= j <= hi + k - 1, and no later
 						// non-ACGTU byte iff j <= 15 + ctz(B) (k <= 32 + 1: B covers the 32 bases behind the piece); 0 <= w < W
@@ -578,308 +899,30 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				lds_publish(ctl + C_DQ_HEAD, dq_head);
 			}
 		};
-		// ---- resolve pass.  Every lane owns NI item SLOTS (registers): a slot holds one candidate word of some lane and step and
-		// gives up its lowest set bit (one read) per pass; an empty slot takes the next word from the strand queues.  One pass =
-		// up to 64 NI candidates: full canonical hash from the packed ring -> ntComp -> hit log.  The LDS round trips of a pass
-		// (items, packed words, table entries) are each issued for all NI slots at once: one wave has nobody to hide them behind ----
-		constexpr int NI = 4;
-		uint32_t sh_[NI], sm_[NI], sb_[NI]; // slot: candidate word, its meta word, the block it was taken in
-#pragma unroll
-		for (int j = 0; j < NI; ++j)
-			sh_[j] = sm_[j] = sb_[j] = 0;
-		// A pass is software-pipelined over two batches of 64 NI candidates: the FRONT of batch b + 1 (refill the slots, take one
-		// candidate per slot, fetch its packed and dirty words from the ring) runs between the table-address arithmetic and the
-		// table look-ups of the BACK of batch b (closed form -> canonical hash -> ntComp -> log), so that one LDS round trip per
-		// pass is exposed instead of three.  pd*/pm*: the batch whose words are fetched and whose back is still to run.
-		uint32_t pd0[NI], pd1[NI], pd2[NI], pb0[NI], pb1[NI], pb2[NI], prr[NI], pww[NI], pmm[NI], pyy[NI], psb[NI];
-		bool pend = false; // wave-uniform: the p* batch holds candidates
-#pragma unroll
-		for (int j = 0; j < NI; ++j)
-			pd0[j] = pd1[j] = pd2[j] = pb0[j] = pb1[j] = pb2[j] = prr[j] = pww[j] = pmm[j] = pyy[j] = psb[j] = 0;
-		auto pass = [&](uint32_t aF, uint32_t aR, uint32_t blk) { // aF / aR: words the queues may hand out now
-			// Few scalar round trips on purpose: a lone wave pays ~20 clk for every vector compare whose mask a scalar instruction
-			// then reads (ballot, branch), so slot and log positions come from DPP prefix sums instead of ballot + mbcnt per slot.
-			// F1. refill the empty slots from the queues (first F, then R): free slot number x of the wave takes word x.  Straight-line:
-			// a slot that takes nothing reads the queue's spare area
-			uint32_t nfree = 0;
-#pragma unroll
-			for (int j = 0; j < NI; ++j)
-				nfree += sh_[j] == 0u ? 1u : 0u;
-			const uint32_t fincl = wave_scan(nfree);
-			const uint32_t n_free = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63);
-			const uint32_t n_new = n_free < aF + aR ? n_free : aF + aR;
-			const uint32_t nF = n_new < aF ? n_new : aF, nR = n_new - nF;
-			uint2 nw[NI];
-			bool take[NI];
-			uint32_t ix = fincl - nfree;
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const bool fr = sh_[j] == 0u;
-				take[j] = fr && ix < n_new;
-				const uint32_t iF = (hF + ix) & (kQCap - 1u), iR = kQCap + 64u + ((hR + ix - nF) & (kQCap - 1u)); // qR follows qF
-				const uint32_t i = ix < nF ? iF : iR;
-				nw[j] = qF[take[j] ? i : kQCap + (uint32_t)lane];
-				ix += fr ? 1u : 0u;
+		while (true) {
+			const uint32_t t_now = rs.t, seq_now = rs.seq;
+			TS_T(tr0);
+			const int rc = rs.step();
+			TS_T(tr1);
+			if (rs.tile_event) { // tile t_now is walked and taken: every dirty piece of it is in the queue by now (and perhaps the first of the next tile)
+				rs.tile_event = false;
+				drain_dirty(t_now, seq_now);
+				f1_add += (uint64_t)((has_partial && t_now == a.n_tiles - 1u) ? n_valid_last : kTile) * W;
 			}
-			__builtin_amdgcn_sched_barrier(0);
-			// B1. (previous batch) closed form, 4 bases per lookup: the table addresses
-			uint32_t toff[NI][K / 4];
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const uint32_t sh = (pww[j] & 15u) * 2u;
-#pragma unroll
-				for (int i = 0; i < KB; ++i) {
-					const uint32_t x = i == 0 ? alignbit(pd1[j], pd0[j], sh) : alignbit(pd2[j], pd1[j], sh); // 16 bases of the window
-#pragma unroll
-					for (int g = 0; g < 4; ++g)
-						toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
-				}
-			}
-			__builtin_amdgcn_sched_barrier(0);
-			// F2. the new words are here: one candidate per slot, its packed words + the dirty words of the pieces its window touches
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				sh_[j] = take[j] ? nw[j].x : sh_[j];
-				sm_[j] = take[j] ? nw[j].y : sm_[j];
-				sb_[j] = take[j] ? blk : sb_[j];
-			}
-			hF += nF;
-			hR += nR;
-			if (nF) lds_publish(ctl + C_QF_HEAD, hF); // (behind the item reads above)
-			if (nR) lds_publish(ctl + C_QR_HEAD, hR);
-			uint32_t d0[NI], d1[NI], d2[NI], b0[NI], b1[NI], b2[NI], rr[NI], ww[NI], mm[NI], yy[NI], tb_[NI];
-			uint32_t any_new = 0;
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const uint32_t h = sh_[j], y = sm_[j];
-				any_new |= h;
-				const uint32_t m = (uint32_t)__builtin_ctz(h | 0x80000000u);
-				sh_[j] = h & (h - 1u);
-				const uint32_t l0 = y & 63u, s0 = (y >> 8) & 7u;
-				const uint32_t col = m * 64u + l0;
-				const uint32_t s1 = s0 + 1u == kRing ? 0u : s0 + 1u, s2 = s1 + 1u == kRing ? 0u : s1 + 1u;
-				d0[j] = pr[s0 * 2048u + col];
-				d1[j] = pr[s1 * 2048u + col];
-				d2[j] = pr[s2 * 2048u + col];
-				b0[j] = db[s0 * 64u + l0];
-				b1[j] = db[s1 * 64u + l0];
-				b2[j] = db[s2 * 64u + l0];
-				rr[j] = col;
-				ww[j] = y >> 11;
-				mm[j] = m;
-				yy[j] = h != 0u ? y | 0x80000000u : 0u; // bit 31: the slot holds a candidate (a window index never reaches 2^20)
-				tb_[j] = sb_[j];
-			}
-			__builtin_amdgcn_sched_barrier(0);
-			// B2. (previous batch) all look-ups in flight together, then the XORs
-			uint32_t nhit = 0, anysus = 0;
-			uint32_t hit[NI], key[NI], sus[NI]; // 0 / 1
-			if (pend) {
-				v4u32 tv[NI][K / 4];
-#pragma unroll
-				for (int j = 0; j < NI; ++j)
-#pragma unroll
-					for (int i = 0; i < K / 4; ++i)
-#ifdef TS_EXP_NOTABLE
-						tv[j][i] = v4u32{toff[j][i], pd0[j], pd1[j], pd2[j]};
-#else
-						tv[j][i] = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)i * 4096u + toff[j][i]); // the group's 4 KiB rides in the offset field
-#endif
-				__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-				for (int j = 0; j < NI; ++j) {
-					static_assert(K / 4 == 8, "XOR tree below is written for 8 table entries");
-					auto x3 = [](uint32_t p, uint32_t q, uint32_t r) { return (uint32_t)__builtin_amdgcn_bitop3_b32(p, q, r, 0x96); };
-					const uint32_t flo = x3(x3(tv[j][0].x, tv[j][1].x, tv[j][2].x), x3(tv[j][3].x, tv[j][4].x, tv[j][5].x), tv[j][6].x ^ tv[j][7].x);
-					const uint32_t fhi = x3(x3(tv[j][0].y, tv[j][1].y, tv[j][2].y), x3(tv[j][3].y, tv[j][4].y, tv[j][5].y), tv[j][6].y ^ tv[j][7].y);
-					const uint32_t rlo = x3(x3(tv[j][0].z, tv[j][1].z, tv[j][2].z), x3(tv[j][3].z, tv[j][4].z, tv[j][5].z), tv[j][6].z ^ tv[j][7].z);
-					const uint32_t rhi = x3(x3(tv[j][0].w, tv[j][1].w, tv[j][2].w), x3(tv[j][3].w, tv[j][4].w, tv[j][5].w), tv[j][6].w ^ tv[j][7].w);
-					const uint64_t fh = ((uint64_t)fhi << 32) | flo, rh = ((uint64_t)rhi << 32) | rlo;
-					const bool rev = rh < fh; // nthash.hpp:275-279
-					const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
-					// ntComp (ntcard.cpp:132-145) on the canonical value; sample 1 wins when both match
-					const bool c1 = (hi >> (32 - s_bits)) == ((1u << (s_bits - 1)) - 1u);
-					const bool c0m = (hi >> (31 - s_bits)) == 1u;
-					const uint32_t y = pyy[j];
-					// the candidate of the canonical strand only (both strands may have flagged the window)
-					bool ht = ((y >> 31) != 0u) & (rev == ((y & 64u) != 0u)) & (c0m | c1);
-					if (has_partial) ht &= (y & 128u) == 0u || prr[j] < n_valid_last; // slots behind the last read of the batch
-					key[j] = a.key_base + (lo & rmask) + (c1 ? rbuck : 0u);
-					// a window that touches a 16-byte piece with a non-ACGTU byte somewhere is settled from the raw bytes (the third piece
-					// only counts when the window is not chunk-aligned)
-					const uint32_t dd = (pb0[j] | pb1[j] | ((pww[j] & 15u) != 0u ? pb2[j] : 0u)) >> pmm[j];
-					sus[j] = ht ? dd & 1u : 0u;
-					hit[j] = (ht ? 1u : 0u) & ~sus[j];
-					nhit += hit[j];
-					anysus |= sus[j];
-#ifdef TS_DEBUG
-					if ((y >> 31) && a.dbg) {
-						const uint32_t ixd = atomicAdd(a.dbg, 1u);
-						uint32_t* o = a.dbg + 16 + 12 * (size_t)ixd;
-						o[0] = prr[j]; o[1] = pww[j]; o[2] = 0; o[3] = y; o[4] = pd0[j]; o[5] = pd1[j]; o[6] = pd2[j]; o[7] = flo; o[8] = fhi; o[9] = rlo; o[10] = rhi;
-						o[11] = (rev ? 1u : 0u) | ((y & 64u) ? 2u : 0u) | (ht ? 4u : 0u);
-					}
-#endif
-				}
-				// one log append for the batch (ntComp's increment, deferred: ntc_apply.hip): a lane's hits go behind those of the lanes below it
-				const uint32_t hincl = wave_scan(nhit);
-				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
-				if (total != 0u) {
-					if (!use_log) {
-#pragma unroll
-						for (int j = 0; j < NI; ++j)
-							if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
-					} else {
-						while (lreg < a.log_regions && total > a.log_region_cap - lfill) {
-							if (lane == 0) a.log_fill[lreg] = lfill;
-							lreg += n_teams;
-							lfill = lreg < a.log_regions ? rfl(a.log_fill[lreg]) : 0u;
-						}
-						if (lreg < a.log_regions) {
-							uint32_t* dst = a.log + (uint64_t)lreg * a.log_region_cap + lfill + (hincl - nhit);
-#pragma unroll
-							for (int j = 0; j < NI; ++j) {
-#ifndef TS_EXP_NOLOG
-								if (hit[j]) *dst = key[j];
-#endif
-								dst += hit[j];
-							}
-							lfill += total;
-						} else {
-#pragma unroll
-							for (int j = 0; j < NI; ++j)
-								if (hit[j]) atomicAdd(a.sketch0 + key[j], 1u);
-						}
-					}
-				}
-				if (ballot(anysus != 0u) != 0) { // rare
-#pragma unroll
-					for (int j = 0; j < NI; ++j) {
-						const uint64_t sm = ballot(sus[j] != 0u);
-						if (sus[j]) sq[sq_fill + mbcnt(sm)] = make_uint2(key[j], prr[j] | (pww[j] << 11) | (((psb[j] / C) & 15u) << 27)); // + the tile of the block the word was taken in
-						sq_fill += (uint32_t)__popcll(sm);
-					}
-					if (sq_fill > kSCap - 64u * NI) {
-						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						flush_suspects(blk / C);
-					}
-				}
-			}
-			// the batch fetched in this pass becomes the one whose back runs in the next
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				pd0[j] = d0[j];
-				pd1[j] = d1[j];
-				pd2[j] = d2[j];
-				pb0[j] = b0[j];
-				pb1[j] = b1[j];
-				pb2[j] = b2[j];
-				prr[j] = rr[j];
-				pww[j] = ww[j];
-				pmm[j] = mm[j];
-				pyy[j] = yy[j];
-				psb[j] = tb_[j];
-			}
-			pend = ballot(any_new != 0u) != 0;
-		};
-		auto slots_busy = [&]() {
-			bool any = false;
-#pragma unroll
-			for (int j = 0; j < NI; ++j)
-				any |= sh_[j] != 0u;
-			return pend || ballot(any) != 0;
-		};
-		auto slots_from = [&](uint32_t blk) { // some slot still holds a word taken in block `blk`
-			bool any = false;
-#pragma unroll
-			for (int j = 0; j < NI; ++j)
-				any |= sh_[j] != 0u && sb_[j] == blk;
-			return ballot(any) != 0;
-		};
-		// Blocks are TAKEN in order (cur: every word of the blocks before it has left the queues) and RESOLVED in order (res: no
-		// slot holds a word of a block before it; published: A1 may reuse the ring slots those blocks read).  A word with several
-		// bits stays in its slot over several passes, also across block boundaries; whenever this wave would otherwise wait it
-		// runs a pass for the slots alone, so `res` never trails for want of new candidates.
-		uint32_t cur = 0, res = 0;
-		uint32_t t = team_g, seq = 0, c = 0;     // tile, its sequence number, chunk of block `cur`
-		bool all_taken = team_g >= a.n_tiles;     // every block of every tile of this team has left the queues
-		bool ring_ok = false, doneF = false, doneR = false;
-		uint32_t limF = 0, limR = 0;
-		while (true) { // one loop, one call site of pass() (inlined several times it spills a hundred scalar registers)
-			bool run = false;
-			uint32_t aF = 0, aR = 0;
-			if (all_taken) {
-				if (!slots_busy()) break;
-				run = true;
-			} else if (!ring_ok) {
-				TS_T(ta0);
-				ring_ok = (int32_t)(lds_peek(ctl + C_PR_READY) - (cur + 1u)) >= 0; // the packed words of this block's chunk
-				if (!ring_ok) {
-					drain_dirty(t, seq); // A1 may be waiting for room in the dirty queue
-					run = slots_busy();
-					if (!run) __builtin_amdgcn_s_sleep(1);
-				}
-				TS_T(ta1);
-				TS_ACC(1, ta0, ta1);
-			}
-			if (ring_ok) {
-				if (!(doneF & doneR) && (limF - hF) + (limR - hR) < 64u * NI) {
-					// block counters and tails in one read; a tail read together with "block complete" may already hold words of
-					// later blocks, whose chunks are not in the ring yet: then the tail noted at the end of the block counts
-					const uint4 q = lds_peek4(ctl + C_BLK_F);
-					doneF = (int32_t)(q.x - (cur + 1u)) >= 0;
-					doneR = (int32_t)(q.z - (cur + 1u)) >= 0;
-					limF = q.y;
-					limR = q.w;
-					if (doneF | doneR) {
-						const uint2 bt = lds_peek2(ctl + C_BT + 2u * (cur & 7u));
-						if (doneF) limF = bt.x;
-						if (doneR) limR = bt.y;
-					}
-				}
-				aF = limF - hF;
-				aR = limR - hR;
-				const bool complete = doneF & doneR;
-				if (aF + aR >= 64u || (complete && aF + aR != 0u)) {
-					run = true;
-				} else if (complete) { // every word of block cur has left the queues (some may still sit in slots): next block
-					++cur;
-					ring_ok = doneF = doneR = false;
-					if (++c == C) {
-						drain_dirty(t, seq); // every piece of tile t is in the queue by now (and perhaps the first of the next tile)
-						f1_add += (uint64_t)((has_partial && t == a.n_tiles - 1u) ? n_valid_last : kTile) * W;
-						c = 0;
-						++seq;
-						t += n_teams;
-						all_taken = t >= a.n_tiles;
-					}
-				} else {
-					TS_T(ti0);
-					drain_dirty(t, seq);
-					run = slots_busy();
-					if (!run) __builtin_amdgcn_s_sleep(1);
-					TS_T(ti1);
-					TS_ACC(2, ti0, ti1);
-				}
-			}
-			if (run) {
-				TS_T(tr0);
-				pass(aF, aR, cur);
-				TS_T(tr1);
+			if (rc == 2) break;
+			if (rc == 0) {
+				drain_dirty(rs.t, rs.seq); // the packer may be waiting for room in the dirty queue
+				__builtin_amdgcn_s_sleep(1);
+				TS_T(ti1);
+				TS_ACC(2, tr0, ti1);
+			} else {
 				TS_ACC(3, tr0, tr1);
 #ifdef TS_TIMERS
 				tacc[4] += 1;
 #endif
 			}
-			// blocks before `cur` are resolved once no slot holds a word of theirs
-			while (res < cur && !slots_from(res)) {
-				++res;
-				lds_publish(ctl + C_RESOLVED, res);
-			}
 		}
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		flush_suspects(seq);
-		if (use_log && lane == 0 && lreg < a.log_regions) a.log_fill[lreg] = lfill;
+		rs.finish();
 		// F1 (ntcard.cpp:154): one per window without a non-ACGTU byte
 		uint32_t sub = f1_sub;
 		for (int o = 32; o > 0; o >>= 1)
