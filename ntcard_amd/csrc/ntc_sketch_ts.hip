@@ -630,7 +630,8 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 
 #ifndef TS_NO_A1
 	if (role == 2u) {
-		// =============================== A1: load, pack, transpose, publish ===============================
+		// =============================== A1: load, pack, publish; resolve the forward strand ===============================
+		__builtin_amdgcn_s_setprio(3); // the walkers run ahead of this wave anyway: when both want the SIMD, it goes first (measured: 0.87 -> 0.75 ms per 10 M reads)
 		uint32_t n = 0;
 		v4u32 raw[32];
 		const uint32_t voff = (uint32_t)lane * 16u;
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #ifndef TS_NO_A2
 	// =============================== A2: resolve the reverse strand's candidates, settle dirty pieces, F1 ===============================
 	{
+		__builtin_amdgcn_s_setprio(3);
 		TsResolver<K, 2> rs;
 		rs.init(&a, tb, ctl, t4, /*fwd=*/false, (uint32_t)lane, C, n_teams, team_g, team_g * 2u, n_teams * 2u);
 		const uint2* const dq = reinterpret_cast<const uint2*>(tb + kOffDQ);
