@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
     ap.add_argument("--bitslice", action="store_true", help="A/B: the bit-sliced kernel K1b even for small batches (it is the default for k = 32 batches of >= 128 tiles)")
     ap.add_argument("--lane-kernel", action="store_true", help="A/B: never use K1b, the lane-per-read kernel K1 takes every batch")
-    ap.add_argument("--layout", choices=["rows", "tiled"], default="rows",
+    ap.add_argument("--layout", choices=["rows", "tiled"], default="tiled",
                     help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1b + K1), tiled = the tiled layout "
                          "(ntc_submit_tiled_device: K1c, the streaming kernel with in-kernel N handling)")
     ap.add_argument("--log-entries", type=int, default=0, help="capacity of the hit log in entries (0 = the engine's default: one per counter)")

@@ -349,7 +349,9 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	ap.b1 = pb <= 8 ? pb : (pb + 1) / 2; // two passes: balanced fan-out (longer runs per digit coalesce better than 256-way + 32-way)
 	ap.b2 = pb - ap.b1;
 	ap.n_slices = (uint32_t)((counters + (1ull << ap.slice_bits) - 1) >> ap.slice_bits);
-	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(1ull << 18, counters));
+	// default: two entries per counter (2^29 at rBits = 27 and one k: the apply's sweep over the whole sketch is then paid once per
+	// ~450 M sampled k-mers; 288 GB of HBM have room for the 2 GiB log and its two partition work areas)
+	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(1ull << 18, 2 * counters));
 	cap = std::max<uint64_t>(cap, 1ull << 14);
 	e->log_region_cap = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, cap / 8192)); // <= 65535: one run fits a 16-bit count pass
 	e->log_regions = (uint32_t)std::max<uint64_t>(1, cap / e->log_region_cap);

@@ -692,6 +692,12 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #endif
 				const uint32_t slot = n % kRing;
 				uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
+#ifdef TS_TIMERS
+				uint64_t tpk0, tpk1;
+				__builtin_amdgcn_sched_barrier(0);
+				asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tpk0)::"memory");
+				__builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
 				for (int m = 0; m < 32; ++m) {
 					uint32_t bad;
@@ -701,7 +707,13 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); // keep pack and reload of a group together
 				}
 				reinterpret_cast<uint32_t*>(tb + kOffDB)[slot * 64u + lane] = dirtyword;
-#ifdef TS_EXP_A1_FREE
+#ifdef TS_TIMERS
+				__builtin_amdgcn_sched_barrier(0);
+				asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tpk1) : "v"(dirtyword) : "memory");
+				__builtin_amdgcn_sched_barrier(0);
+				tacc[3] += tpk1 - tpk0;
+#endif
+#if defined(TS_EXP_A1_FREE) || defined(TS_EXP_NODIRTY)
 				const uint64_t dm = 0;
 #else
 				const uint64_t dm = ballot(dirtyword != 0u);
@@ -912,8 +924,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				f1_add += (uint64_t)((has_partial && t_now == a.n_tiles - 1u) ? n_valid_last : kTile) * W;
 			}
 			if (rc == 2) break;
+			if (rc == 1 && lds_peek(ctl + C_DQ_TAIL) - dq_head >= kDCap / 2u) drain_dirty(rs.t, rs.seq); // busy or not: the packer must not wait for room in the dirty queue
 			if (rc == 0) {
-				drain_dirty(rs.t, rs.seq); // the packer may be waiting for room in the dirty queue
+				drain_dirty(rs.t, rs.seq);
 				__builtin_amdgcn_s_sleep(1);
 				TS_T(ti1);
 				TS_ACC(2, tr0, ti1);

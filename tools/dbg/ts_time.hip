@@ -72,7 +72,7 @@ int main(int argc, char** argv)
 		for (int r = 0; r < 4; ++r) {
 			printf("  %s per wave (kclk): total %.0f", names[r], h[r * 8] / waves / 1e3);
 			if (r < 2) printf("  wait planes %.0f  wait queue %.0f", h[r * 8 + 1] / waves / 1e3, h[r * 8 + 2] / waves / 1e3);
-			if (r == 2) printf("  gate loop %.0f (of which resolver turns %.0f kclk in %.0f turns)  pack etc %.0f", h[r * 8 + 1] / waves / 1e3, h[r * 8 + 5] / waves / 1e3, h[r * 8 + 6] / waves, (h[r * 8] - (double)h[r * 8 + 1]) / waves / 1e3);
+			if (r == 2) printf("  gate loop %.0f (of which resolver turns %.0f kclk in %.0f turns)  outside the gate loop %.0f (pack loop %.0f)", h[r * 8 + 1] / waves / 1e3, h[r * 8 + 5] / waves / 1e3, h[r * 8 + 6] / waves, (h[r * 8] - (double)h[r * 8 + 1]) / waves / 1e3, h[r * 8 + 3] / waves / 1e3);
 			if (r == 3) printf("  wait ring %.0f  idle %.0f  rounds %.0f kclk, %.0f passes, %.0f clk/pass", h[r * 8 + 1] / waves / 1e3, h[r * 8 + 2] / waves / 1e3, h[r * 8 + 3] / waves / 1e3,
 				                  h[r * 8 + 4] / waves, (double)h[r * 8 + 3] / h[r * 8 + 4]);
 			if (r == 3) printf("\n     pass phases per pass (clk): refill %.0f  ring+tables issue %.0f  xor/test %.0f  log+rest %.0f", (double)h[r * 8 + 5] / h[r * 8 + 4], (double)h[r * 8 + 6] / h[r * 8 + 4],
