@@ -572,6 +572,7 @@ struct TsResolver {
 				if (++c == C) {
 					c = 0;
 					tile_event = true; // (the caller books the tile: F1, dirty pieces)
+					if (sq_fill != 0u) flush_suspects(); // a suspect never waits longer than a tile: its tile tag stays unambiguous however many tiles a team walks
 					++seq;
 					t += n_teams;
 					all_taken = t >= a->n_tiles;

@@ -56,7 +56,7 @@ ok = np.array_equal(t.cpu().numpy(), nt.tile_reads(reads, L))
 print("ok  " if ok else "FAIL", "tiled generator == oracle generator")
 allok &= ok
 for (n, L, dist, s) in [(5000, 150, 1, 7), (2048, 150, 0, 7), (4096, 100, 1, 7), (100, 159, 1, 7), (3000, 33, 1, 7), (3000, 32, 0, 7), (6000, 150, 1, 8), (6000, 150, 1, 11),
-                        (2500, 250, 1, 7), (1, 150, 1, 7), (70000, 150, 1, 7)]:
+                        (2500, 250, 1, 7), (1, 150, 1, 7), (70000, 150, 1, 7), (1_300_000, 150, 1, 7)]:
     allok &= check_reads(gen_host(n, L, dist), L, s_bits=s, tag=f"dist={dist}")
 # adversarial: many N, IUPAC, lower case, U, poly-A, all-N reads
 rng = np.random.default_rng(5)
