@@ -159,8 +159,13 @@ int ntc_merge_counters(ntc_engine *e, const uint16_t *t_counter, const uint64_t 
  * normally one per GPU of the node, each fed with its own share of the reads.  After the call engine 0 holds the
  * element-wise SUM of all sketches and F1 values (MAX of the registers for nthll engines) — the state the
  * reference's threads build in their one shared t_Counter / totalKmers (ntcard.cpp:142-143,464-466; nthll.cpp:
- * 238-243) — and the other engines are reset to zero.  Devices are connected with RCCL (ncclCommInitAll + one grouped
- * ncclReduce over xGMI; librccl is loaded on first use); engines that share a device are folded with a kernel.   */
+ * 238-243) — and the other engines are reset to zero.  t_Counter wraps at 16 bits (ntcard.cpp:439), so the counters travel
+ * as their low halves: every engine narrows its sketch to uint16, slice j of every engine is copied to engine j's device (all
+ * N x (N-1) peer copies in flight together, one per point-to-point xGMI link; hipMemcpyPeerAsync, staged by the runtime when two
+ * devices have no peer access), engine j adds its N slices with wrapping 16-bit adds, the summed slices are gathered on engine
+ * 0's device and widened into its sketch — the same exchange bench.py runs between processes with RCCL's all-to-all.  Engine 0's
+ * counters afterwards hold their value mod 2^16 (all t_Counter ever held) and it may keep counting; F1 and nthll registers are
+ * merged at full width.  No communicator, no library beyond HIP.                                                        */
 int ntc_merge_devices(ntc_engine *const *engines, int32_t n_engines);
 
 /* Device pointers of the live sketch / F1 (for a host framework's collective); flushes the hit log first */

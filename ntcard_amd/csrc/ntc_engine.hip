@@ -5,8 +5,6 @@
 // (ntcard.cpp:147-171), ntc_finish = the state compEst reads (ntcard.cpp:237-247) + F1
 // (ntcard.cpp:464-466).  No CPU fallback exists: every entry point needs a live HIP device.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h> // types only: the library is loaded on demand (ntc_merge_devices)
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1340,44 +1338,80 @@ int ntc_flush(ntc_engine* e)
 
 // ---- multi-GPU merge in ONE host process -------------------------------------------------------
 // The reference's threads all increment one shared t_Counter (ntcard.cpp:142-143,445) and add their k-mer counts into
-// one totalKmers (ntcard.cpp:464-466); with one private sketch per GPU the same state is the element-wise SUM of the
-// sketches (MAX for nthll's registers, nthll.cpp:238-243).  RCCL does it over xGMI: one communicator per device
-// (ncclCommInitAll), one grouped ncclReduce to the root.  librccl is loaded the first time this is needed, so that
-// single-GPU users do not pay for it at start-up.
+// one totalKmers (ntcard.cpp:464-466); with one private sketch per engine the same state is the element-wise SUM of the
+// sketches (MAX for nthll's registers, nthll.cpp:238-243).  t_Counter wraps at 16 bits, so only the low halves of the
+// per-engine counters matter: (sum_e c_e) mod 2^16 == (sum_e (c_e mod 2^16)) mod 2^16.  The merge is the same exchange
+// bench.py runs between processes with RCCL's all-to-all (ntcard_amd/parallel.py), written with peer copies because here
+// all devices belong to one process: every engine narrows its counters to 16 bits, slice j of every engine goes to engine
+// j's device — all N x (N-1) copies are in flight together, each on its own point-to-point xGMI link, 2 B x counters / N
+// per link —, engine j adds its N slices with wrapping 16-bit adds, the summed slices are gathered on engine 0's device
+// (again one slice per link) and widened into engine 0's sketch.  No communicator, no library beyond HIP; devices without
+// peer access are served by hipMemcpyPeerAsync's staged path.  nthll's register file (2^nBits dwords) and F1 are tiny:
+// copied to the root device and folded there (max / sum, full width).
 namespace {
-struct Rccl {
-	void* lib = nullptr;
-	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-	ncclResult_t (*GroupStart)() = nullptr;
-	ncclResult_t (*GroupEnd)() = nullptr;
-	ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
-	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+struct MergePeer {
+	ntc_engine* e = nullptr;
+	uint16_t* narrow = nullptr; // [counters]      this engine's counters mod 2^16
+	uint16_t* recv = nullptr;   // [n][slice]      slice `me` of every engine; the sum ends up in recv[0 .. slice)
+	std::vector<hipStream_t> lanes; // one copy stream per peer: the copies into this device run side by side
+	hipEvent_t narrowed = nullptr, summed = nullptr;
+	std::vector<hipEvent_t> arrived;
 };
-int load_rccl(Rccl& r)
+hipError_t copy_between(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st)
 {
-	static std::mutex mu;
-	static Rccl cached;
-	std::lock_guard<std::mutex> lk(mu);
-	if (!cached.lib) {
-		void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-		if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (!h) return fail(NTC_ERR_DEVICE, "ntc_merge_devices: cannot load librccl (%s)", dlerror());
-		Rccl t;
-		t.lib = h;
-		t.CommInitAll = (decltype(t.CommInitAll))dlsym(h, "ncclCommInitAll");
-		t.CommDestroy = (decltype(t.CommDestroy))dlsym(h, "ncclCommDestroy");
-		t.GroupStart = (decltype(t.GroupStart))dlsym(h, "ncclGroupStart");
-		t.GroupEnd = (decltype(t.GroupEnd))dlsym(h, "ncclGroupEnd");
-		t.Reduce = (decltype(t.Reduce))dlsym(h, "ncclReduce");
-		t.GetErrorString = (decltype(t.GetErrorString))dlsym(h, "ncclGetErrorString");
-		if (!t.CommInitAll || !t.CommDestroy || !t.GroupStart || !t.GroupEnd || !t.Reduce || !t.GetErrorString)
-			return fail(NTC_ERR_DEVICE, "ntc_merge_devices: librccl lacks a required entry point");
-		cached = t;
+	if (bytes == 0) return hipSuccess;
+	return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
+void enable_peer_access(const std::vector<MergePeer>& peers)
+{
+	for (const MergePeer& a : peers)
+		for (const MergePeer& b : peers) {
+			int can = 0;
+			if (a.e->device == b.e->device || hipDeviceCanAccessPeer(&can, a.e->device, b.e->device) != hipSuccess || !can) continue;
+			(void)hipSetDevice(a.e->device);
+			(void)hipDeviceEnablePeerAccess(b.e->device, 0); // hipErrorPeerAccessAlreadyEnabled is fine
+			(void)hipGetLastError();
+		}
+}
+void release_peers(std::vector<MergePeer>& peers)
+{
+	for (MergePeer& p : peers) {
+		if (!p.e) continue;
+		(void)hipSetDevice(p.e->device);
+		for (hipStream_t s : p.lanes) {
+			if (!s) continue;
+			(void)hipStreamSynchronize(s);
+			(void)hipStreamDestroy(s);
+		}
+		(void)hipStreamSynchronize(p.e->stream);
+		for (hipEvent_t ev : p.arrived)
+			if (ev) (void)hipEventDestroy(ev);
+		if (p.narrowed) (void)hipEventDestroy(p.narrowed);
+		if (p.summed) (void)hipEventDestroy(p.summed);
+		if (p.narrow) (void)hipFree(p.narrow);
+		if (p.recv) (void)hipFree(p.recv);
 	}
-	r = cached;
-	return 0;
+}
+// full-width fold of a small array of every engine into the root's (nthll registers: max; F1: sum)
+int fold_small(ntc_engine* const* engines, int32_t n, bool regs)
+{
+	ntc_engine* root = engines[0];
+	const size_t bytes = regs ? (size_t)4 << root->hll_bits : root->klist.size() * 8;
+	void* tmp = nullptr;
+	HIP_TRY(hipSetDevice(root->device));
+	HIP_TRY(hipMalloc(&tmp, bytes));
+	int rc = 0;
+	for (int32_t i = 1; i < n && !rc; ++i) {
+		const void* src = regs ? (const void*)engines[i]->d_sketch : (const void*)engines[i]->d_f1;
+		hipError_t h = copy_between(tmp, root->device, src, engines[i]->device, bytes, root->stream);
+		if (h == hipSuccess)
+			h = regs ? ntc::launch_fold_u32(root->d_sketch, (const uint32_t*)tmp, bytes / 4, true, root->stream)
+			         : ntc::launch_fold_u64((unsigned long long*)root->d_f1, (const unsigned long long*)tmp, bytes / 8, root->stream);
+		if (h != hipSuccess) rc = fail(NTC_ERR_DEVICE, "ntc_merge_devices: folding engine %d failed: %s", i, hipGetErrorString(h));
+	}
+	(void)hipStreamSynchronize(root->stream);
+	(void)hipFree(tmp);
+	return rc;
 }
 } // namespace
 
@@ -1386,7 +1420,6 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 	if (!engines || n_engines < 1) return fail(NTC_ERR_ARG, "ntc_merge_devices: need at least one engine");
 	ntc_engine* root = engines[0];
 	if (!root) return fail(NTC_ERR_ARG, "ntc_merge_devices: null engine");
-	const uint64_t counters = root->hll_bits ? (1ull << root->hll_bits) : root->klist.size() * root->plane_elems();
 	for (int32_t i = 0; i < n_engines; ++i) {
 		ntc_engine* e = engines[i];
 		if (!e || e->klist != root->klist || e->gap != root->gap || e->r_bits != root->r_bits || e->s_bits != root->s_bits || e->hll_bits != root->hll_bits)
@@ -1401,56 +1434,81 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 		if (int rc = apply_log(engines[i])) return rc;
 		HIP_TRY(hipStreamSynchronize(engines[i]->stream));
 	}
-	// 2. engines that share a device are folded locally (RCCL wants one rank per device); `lead` = first engine per device
-	std::vector<ntc_engine*> lead;
-	for (int32_t i = 0; i < n_engines; ++i) {
-		ntc_engine* e = engines[i];
-		ntc_engine* l = nullptr;
-		for (ntc_engine* c : lead)
-			if (c->device == e->device) l = c;
-		if (!l) {
-			lead.push_back(e);
-			continue;
-		}
-		HIP_TRY(hipSetDevice(e->device));
-		HIP_TRY(ntc::launch_fold_u32(l->d_sketch, e->d_sketch, counters, root->hll_bits != 0, l->stream));
-		HIP_TRY(ntc::launch_fold_u64((unsigned long long*)l->d_f1, (unsigned long long*)e->d_f1, e->klist.size(), l->stream));
-		HIP_TRY(hipStreamSynchronize(l->stream));
-	}
-	// 3. one rank per device: grouped reduce to the root's device (with a single device the one-rank reduce is a no-op
-	//    that still walks the whole RCCL path: communicator, group, reduce)
-	if (n_engines > 1) {
-		Rccl nc;
-		if (int rc = load_rccl(nc)) return rc;
-		std::vector<int> devs;
-		for (ntc_engine* e : lead)
-			devs.push_back(e->device);
-		std::vector<ncclComm_t> comms(lead.size());
-		ncclResult_t r = nc.CommInitAll(comms.data(), (int)lead.size(), devs.data());
-		if (r != ncclSuccess) return fail(NTC_ERR_DEVICE, "ncclCommInitAll failed: %s", nc.GetErrorString(r));
-		auto run = [&]() -> ncclResult_t {
-			ncclResult_t rr = nc.GroupStart();
-			if (rr != ncclSuccess) return rr;
-			for (size_t i = 0; i < lead.size(); ++i) {
-				ntc_engine* e = lead[i];
-				(void)hipSetDevice(e->device);
-				rr = nc.Reduce(e->d_sketch, e->d_sketch, counters, ncclUint32, root->hll_bits ? ncclMax : ncclSum, 0, comms[i], e->stream);
-				if (rr != ncclSuccess) return rr;
-				rr = nc.Reduce(e->d_f1, e->d_f1, e->klist.size(), ncclUint64, ncclSum, 0, comms[i], e->stream);
-				if (rr != ncclSuccess) return rr;
+	if (n_engines == 1) return 0;
+	const uint32_t n = (uint32_t)n_engines;
+	// 2. F1 (and nthll's registers) at full width
+	if (int rc = fold_small(engines, n_engines, false)) return rc;
+	if (root->hll_bits) {
+		if (int rc = fold_small(engines, n_engines, true)) return rc;
+	} else {
+		// 3. the counters: 16-bit slices, all-to-all, wrapping sums, gather, widen
+		const uint64_t counters = root->klist.size() * root->plane_elems();
+		const uint64_t slice = ((counters + n - 1) / n + 7) & ~7ull; // elements per slice (16-byte multiples); the last one may be short or empty
+		auto len_of = [&](uint32_t j) { return (uint64_t)j * slice >= counters ? 0ull : std::min<uint64_t>(slice, counters - (uint64_t)j * slice); };
+		std::vector<MergePeer> peers(n);
+		auto run = [&]() -> int {
+			for (uint32_t i = 0; i < n; ++i) {
+				MergePeer& p = peers[i];
+				p.e = engines[i];
+				HIP_TRY(hipSetDevice(p.e->device));
+				if (hipMalloc((void**)&p.narrow, counters * 2) != hipSuccess || hipMalloc((void**)&p.recv, (size_t)n * slice * 2) != hipSuccess)
+					return fail(NTC_ERR_MEMORY, "ntc_merge_devices: cannot allocate the %llu-byte exchange buffers on device %d", (unsigned long long)((counters + n * slice) * 2), p.e->device);
+				p.lanes.assign(n, nullptr);
+				p.arrived.assign(n, nullptr);
+				for (uint32_t j = 0; j < n; ++j) {
+					HIP_TRY(hipStreamCreateWithFlags(&p.lanes[j], hipStreamNonBlocking));
+					HIP_TRY(hipEventCreateWithFlags(&p.arrived[j], hipEventDisableTiming));
+				}
+				HIP_TRY(hipEventCreateWithFlags(&p.narrowed, hipEventDisableTiming));
+				HIP_TRY(hipEventCreateWithFlags(&p.summed, hipEventDisableTiming));
 			}
-			return nc.GroupEnd();
+			enable_peer_access(peers);
+			for (MergePeer& p : peers) { // narrow
+				HIP_TRY(hipSetDevice(p.e->device));
+				HIP_TRY(ntc::launch_narrow_u16(p.e->d_sketch, p.narrow, counters, p.e->stream));
+				HIP_TRY(hipEventRecord(p.narrowed, p.e->stream));
+			}
+			for (uint32_t j = 0; j < n; ++j) { // all-to-all: slice j of engine i -> engine j, on j's lane i
+				MergePeer& dst = peers[j];
+				HIP_TRY(hipSetDevice(dst.e->device));
+				for (uint32_t t = 0; t < n; ++t) {
+					const uint32_t i = (j + t) % n; // staggered start: at every moment the devices talk to distinct partners
+					const MergePeer& src = peers[i];
+					HIP_TRY(hipStreamWaitEvent(dst.lanes[i], src.narrowed, 0));
+					HIP_TRY(copy_between(dst.recv + (uint64_t)i * slice, dst.e->device, src.narrow + (uint64_t)j * slice, src.e->device, len_of(j) * 2, dst.lanes[i]));
+					HIP_TRY(hipEventRecord(dst.arrived[i], dst.lanes[i]));
+					HIP_TRY(hipStreamWaitEvent(dst.e->stream, dst.arrived[i], 0));
+				}
+				HIP_TRY(ntc::launch_sum_slices_u16(dst.recv, slice, n, len_of(j), dst.e->stream));
+				HIP_TRY(hipEventRecord(dst.summed, dst.e->stream));
+			}
+			// gather on the root: its own `narrow` is free once every peer has taken its slice of it — simpler: the root's lanes wait for
+			// those copies (arrived events of slice 0 on every peer) before overwriting
+			MergePeer& r0 = peers[0];
+			HIP_TRY(hipSetDevice(r0.e->device));
+			for (uint32_t j = 0; j < n; ++j) {
+				for (uint32_t q = 0; q < n; ++q)
+					HIP_TRY(hipStreamWaitEvent(r0.lanes[j], peers[q].arrived[0], 0)); // engine 0's slices have left `narrow`
+				HIP_TRY(hipStreamWaitEvent(r0.lanes[j], peers[j].summed, 0));
+				HIP_TRY(copy_between(r0.narrow + (uint64_t)j * slice, r0.e->device, peers[j].recv, peers[j].e->device, len_of(j) * 2, r0.lanes[j]));
+				HIP_TRY(hipEventRecord(r0.arrived[j], r0.lanes[j])); // (re-used: slice j of the sum has arrived)
+				HIP_TRY(hipStreamWaitEvent(r0.e->stream, r0.arrived[j], 0));
+			}
+			HIP_TRY(ntc::launch_widen_u16(r0.narrow, r0.e->d_sketch, counters, r0.e->stream));
+			for (MergePeer& p : peers) {
+				HIP_TRY(hipSetDevice(p.e->device));
+				for (hipStream_t s : p.lanes)
+					HIP_TRY(hipStreamSynchronize(s));
+				HIP_TRY(hipStreamSynchronize(p.e->stream));
+			}
+			return 0;
 		};
-		r = run();
-		for (size_t i = 0; i < lead.size(); ++i) {
-			(void)hipSetDevice(lead[i]->device);
-			(void)hipStreamSynchronize(lead[i]->stream);
-		}
-		for (ncclComm_t c : comms)
-			(void)nc.CommDestroy(c);
-		if (r != ncclSuccess) return fail(NTC_ERR_DEVICE, "RCCL reduce failed: %s", nc.GetErrorString(r));
+		const int rc = run();
+		release_peers(peers);
+		if (rc) return rc;
 	}
-	// 4. everything now lives in engine 0: the others start from zero again (the sum stays what it was)
+	// 4. everything now lives in engine 0 (counters as their value mod 2^16, which is all t_Counter ever held): the others start
+	//    from zero again, the sum stays what it was
 	for (int32_t i = 1; i < n_engines; ++i)
 		if (int rc = ntc_reset(engines[i])) return rc;
 	HIP_TRY(hipSetDevice(root->device));

@@ -515,6 +515,66 @@ hipError_t launch_fold_u64(unsigned long long* dst, const unsigned long long* sr
 	return hipGetLastError();
 }
 
+// ---- multi-device merge (ntc_merge_devices): counters travel as their low 16 bits, t_Counter wraps there (ntcard.cpp:142-143,439) ----
+// dst16[i] = src32[i] mod 2^16
+__global__ __launch_bounds__(256) void narrow_u16_kernel(const uint32_t* __restrict__ src, uint16_t* __restrict__ dst, uint64_t n)
+{
+	const uint64_t n8 = n / 8, step = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint64_t i = tid; i < n8; i += step) {
+		const uint4 a = reinterpret_cast<const uint4*>(src)[2 * i], b = reinterpret_cast<const uint4*>(src)[2 * i + 1];
+		reinterpret_cast<uint4*>(dst)[i] = make_uint4((a.x & 0xffffu) | (a.y << 16), (a.z & 0xffffu) | (a.w << 16), (b.x & 0xffffu) | (b.y << 16), (b.z & 0xffffu) | (b.w << 16));
+	}
+	for (uint64_t i = n8 * 8 + tid; i < n; i += step)
+		dst[i] = (uint16_t)src[i];
+}
+// slice 0 += slices 1 .. n_slices-1 (wrapping 16-bit adds, two counters per dword lane-wise); slices lie `stride` elements apart
+__global__ __launch_bounds__(256) void sum_slices_u16_kernel(uint16_t* __restrict__ slices, uint64_t stride, uint32_t n_slices, uint64_t len)
+{
+	const uint64_t n8 = len / 8, step = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	auto add2 = [](uint32_t x, uint32_t y) { return ((x + y) & 0xffffu) | ((x & 0xffff0000u) + (y & 0xffff0000u)); };
+	for (uint64_t i = tid; i < n8; i += step) {
+		uint4 acc = reinterpret_cast<const uint4*>(slices)[i];
+		for (uint32_t r = 1; r < n_slices; ++r) {
+			const uint4 v = reinterpret_cast<const uint4*>(slices + r * stride)[i];
+			acc = make_uint4(add2(acc.x, v.x), add2(acc.y, v.y), add2(acc.z, v.z), add2(acc.w, v.w));
+		}
+		reinterpret_cast<uint4*>(slices)[i] = acc;
+	}
+	for (uint64_t i = n8 * 8 + tid; i < len; i += step) {
+		uint16_t acc = slices[i];
+		for (uint32_t r = 1; r < n_slices; ++r)
+			acc = (uint16_t)(acc + slices[r * stride + i]);
+		slices[i] = acc;
+	}
+}
+// dst32[i] = src16[i]
+__global__ __launch_bounds__(256) void widen_u16_kernel(const uint16_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n)
+{
+	const uint64_t n8 = n / 8, step = (uint64_t)gridDim.x * blockDim.x, tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint64_t i = tid; i < n8; i += step) {
+		const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+		reinterpret_cast<uint4*>(dst)[2 * i] = make_uint4(v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16);
+		reinterpret_cast<uint4*>(dst)[2 * i + 1] = make_uint4(v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16);
+	}
+	for (uint64_t i = n8 * 8 + tid; i < n; i += step)
+		dst[i] = src[i];
+}
+hipError_t launch_narrow_u16(const uint32_t* src, uint16_t* dst, uint64_t n, hipStream_t st)
+{
+	hipLaunchKernelGGL(narrow_u16_kernel, dim3(4096), dim3(256), 0, st, src, dst, n);
+	return hipGetLastError();
+}
+hipError_t launch_sum_slices_u16(uint16_t* slices, uint64_t stride, uint32_t n_slices, uint64_t len, hipStream_t st)
+{
+	hipLaunchKernelGGL(sum_slices_u16_kernel, dim3(4096), dim3(256), 0, st, slices, stride, n_slices, len);
+	return hipGetLastError();
+}
+hipError_t launch_widen_u16(const uint16_t* src, uint32_t* dst, uint64_t n, hipStream_t st)
+{
+	hipLaunchKernelGGL(widen_u16_kernel, dim3(4096), dim3(256), 0, st, src, dst, n);
+	return hipGetLastError();
+}
+
 hipError_t launch_add_counters(uint32_t* sketch, const uint16_t* add16, uint64_t n, hipStream_t st)
 {
 	hipLaunchKernelGGL(add_counters_kernel, dim3(4096), dim3(256), 0, st, sketch, add16, n);

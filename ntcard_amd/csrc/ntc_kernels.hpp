@@ -169,10 +169,13 @@ hipError_t launch_hll_threshold(const uint32_t* regs, uint32_t n_regs, uint32_t*
 hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32_t* p_hist,
                            uint16_t* out16, hipStream_t st);
 hipError_t launch_value_hist(const uint32_t* counters, uint64_t n, uint32_t* p_hist, hipStream_t st);
-// dst[i] = dst[i] + src[i] (or max for nthll registers): engines that share a device are folded before the RCCL reduce
+// dst[i] = dst[i] + src[i] (or max for nthll registers): the full-width part of ntc_merge_devices (F1, nthll register files)
 hipError_t launch_fold_u32(uint32_t* dst, const uint32_t* src, uint64_t n, bool take_max, hipStream_t st);
 hipError_t launch_fold_u64(unsigned long long* dst, const unsigned long long* src, uint64_t n, hipStream_t st);
 hipError_t launch_add_counters(uint32_t* sketch, const uint16_t* add16, uint64_t n, hipStream_t st);
+hipError_t launch_narrow_u16(const uint32_t* src, uint16_t* dst, uint64_t n, hipStream_t st);
+hipError_t launch_sum_slices_u16(uint16_t* slices, uint64_t stride, uint32_t n_slices, uint64_t len, hipStream_t st);
+hipError_t launch_widen_u16(const uint16_t* src, uint32_t* dst, uint64_t n, hipStream_t st);
 hipError_t launch_gen(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
                       uint32_t stride, uint32_t dist, uint64_t glen, hipStream_t st);
 

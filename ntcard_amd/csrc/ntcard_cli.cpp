@@ -235,7 +235,7 @@ int main(int argc, char** argv)
 	const size_t nk = opt.klist.size();
 	std::vector<uint32_t> p(nk * 2 * 65536);
 	std::vector<uint64_t> f1(nk);
-	if (engines.size() > 1) { // one sketch per GPU -> their sum on the first one (RCCL reduce over xGMI inside the library)
+	if (engines.size() > 1) { // one sketch per GPU -> their sum on the first one (16-bit slice exchange over peer copies inside the library)
 		if (ntc_merge_devices(engines.data(), (int32_t)engines.size()) != 0) die_engine();
 		for (size_t d = 1; d < engines.size(); ++d)
 			ntc_destroy(engines[d]);

@@ -177,7 +177,8 @@ def hll_estimate(regs, n_bits=16):
 
 
 def merge_devices(engines):
-    """RCCL (xGMI) sum of the engines' sketches and F1 into engines[0]; the others are reset (ntc_merge_devices)"""
+    """sum (mod 2^16, like t_Counter) of the engines' sketches and F1 into engines[0] by a 16-bit slice exchange over peer copies;
+    the others are reset (ntc_merge_devices)"""
     arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
     check(_abi.lib().ntc_merge_devices(arr, len(engines)))
 

@@ -570,7 +570,7 @@ def test_full_size_properties(nt):
 
 def test_native_merge_devices_matches_single_engine(nt):
     """ntc_merge_devices (C ABI, one host process): reads sharded over min(2, device_count) devices x 2 engines each,
-    merged by a kernel fold (same device) + one grouped RCCL reduce (distinct devices) == one engine over all reads:
+    merged by the 16-bit slice exchange (peer copies; plain copies between engines of one device) == one engine over all reads:
     identical t_Counter, value histogram, F1 and therefore .hist (config 3 at test size, sBits = 11)"""
     ndev = min(2, torch.cuda.device_count())
     n, L, stride = 48_000, 150, 152
@@ -613,6 +613,44 @@ def test_native_merge_devices_matches_single_engine(nt):
         h.submit_device(bufs[0].data_ptr(), n, L, stride)
         regs1, f11 = h.finish()
     assert f1 == f11 and np.array_equal(regs, regs1)
+
+
+@pytest.mark.parametrize("n_eng,r_bits", [(3, 8), (5, 8), (7, 13), (8, 20)])
+def test_native_merge_slices_and_wraps(nt, n_eng, r_bits):
+    """ntc_merge_devices' 16-bit slice exchange with engine counts that do not divide the counters (short and 16-byte-rounded
+    slices), and with per-engine counters and sums beyond 65535 (the exchange carries the low halves only; t_Counter wraps
+    there, ntcard.cpp:142-143,439).  All engines on device 0: the same code path as across devices except for the copy call."""
+    n, L, stride = 30_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 77, 0, n, L, stride, 0)
+    passes = 30 if r_bits <= 8 else 2
+    cuts = [n * j // n_eng // 4 * 4 for j in range(n_eng)] + [n]  # 16-byte aligned shares
+    with nt.Engine([32], r_bits=r_bits, s_bits=2) as e:
+        for _ in range(passes):
+            e.submit_device(d.data_ptr(), n, L, stride)
+        want = e.finish(counters=True)
+    if r_bits <= 8:
+        assert n * (L - 31) * passes // 2 // (2 << r_bits) > 65535  # the counters really wrap
+    engines = [nt.Engine([32], r_bits=r_bits, s_bits=2) for _ in range(n_eng)]
+    try:
+        for j, e in enumerate(engines):
+            for _ in range(passes):
+                e.submit_device(d.data_ptr() + cuts[j] * stride, cuts[j + 1] - cuts[j], L, stride)
+        nt.merge_devices(engines)
+        got = engines[0].finish(counters=True)
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # the merged engine keeps counting
+        engines[0].submit_device(d.data_ptr(), 1000, L, stride)
+        more = engines[0].finish(counters=True)
+    finally:
+        for e in engines:
+            e.close()
+    with nt.Engine([32], r_bits=r_bits, s_bits=2) as e:
+        for _ in range(passes):
+            e.submit_device(d.data_ptr(), n, L, stride)
+        e.submit_device(d.data_ptr(), 1000, L, stride)
+        want2 = e.finish(counters=True)
+    assert np.array_equal(more[0], want2[0]) and np.array_equal(more[2], want2[2])
 
 
 def test_value_hist_device_matches_numpy(nt):
