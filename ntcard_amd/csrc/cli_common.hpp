@@ -21,11 +21,13 @@ namespace cli {
 
 extern const char* const kProgram;
 
-[[noreturn]] inline void die_engine()
+[[noreturn]] inline void die_engine(const std::string& msg)
 {
-	std::cerr << kProgram << ": " << ntc_last_error() << "\n";
+	std::cerr << kProgram << ": " << msg << "\n";
 	std::exit(EXIT_FAILURE);
 }
+// ntc_last_error() is per thread: call this on the thread whose engine call failed
+[[noreturn]] inline void die_engine() { die_engine(ntc_last_error()); }
 
 // ---- input: plain file or a pipe from the decompressor the reference would have used ----------
 inline bool ends_with(const std::string& s, const char* suf)
@@ -209,7 +211,7 @@ inline void parse_fastq_blocks(LineReader& in, ntc_engine* eng)
 		std::vector<char> buf;
 		std::vector<uint64_t> starts;
 		std::vector<uint32_t> lens;
-		std::future<int> pending;
+		std::future<std::string> pending; // error text of the packing task (ntc_last_error is thread-local: the worker has to fetch it), empty = ok
 	} blk[2];
 	int cur = 0;
 	blk[0].buf.resize(kBlock);
@@ -219,7 +221,9 @@ inline void parse_fastq_blocks(LineReader& in, ntc_engine* eng)
 	size_t s_start = 0, s_len = 0;
 	bool eof = false;
 	auto wait = [&](Block& b) {
-		if (b.pending.valid() && b.pending.get() != 0) die_engine();
+		if (!b.pending.valid()) return;
+		const std::string err = b.pending.get();
+		if (!err.empty()) die_engine(err);
 	};
 	for (;;) {
 		Block& b = blk[cur];
@@ -269,7 +273,11 @@ inline void parse_fastq_blocks(LineReader& in, ntc_engine* eng)
 		o.lens.clear();
 		if (!b.starts.empty()) {
 			Block* pb = &b;
-			b.pending = std::async(std::launch::async, [eng, pb] { return ntc_submit_spans(eng, pb->buf.data(), pb->starts.data(), pb->lens.data(), pb->starts.size()); });
+			b.pending = std::async(std::launch::async, [eng, pb]() -> std::string {
+				if (ntc_submit_spans(eng, pb->buf.data(), pb->starts.data(), pb->lens.data(), pb->starts.size()) == 0) return std::string();
+				const std::string msg = ntc_last_error();
+				return msg.empty() ? std::string("ntc_submit_spans failed") : msg;
+			});
 		}
 		s_start -= keep;
 		pos -= keep;

@@ -59,7 +59,7 @@ namespace {
 			return fail(NTC_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e__));          \
 	} while (0)
 
-constexpr uint32_t kMaxK = 255;
+constexpr uint32_t kMaxK = 600; // the closed-form table (k x 128 B) and one wave of host slots (64 x ~2k B) share the 160 KiB of LDS; 600 is tested, 640 no longer fits
 constexpr uint32_t kSlotCapMin = 256; // host packing: slot capacity (bytes) for ragged batches
 
 struct DevInfo {

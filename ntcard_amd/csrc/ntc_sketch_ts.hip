@@ -629,6 +629,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 	const uint64_t t_start = __builtin_readcyclecounter();
 #endif
 
+#ifdef TS_EXP_WALK_ONLY // timing experiment: the walkers alone, over whatever the ring holds, nobody to wait for
+	if (role >= 2u) return;
+#endif
 #ifndef TS_NO_A1
 	if (role == 2u) {
 		// =============================== A1: load, pack, publish; resolve the forward strand ===============================
@@ -773,7 +776,11 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				const uint32_t slot = (qtail + mbcnt(m)) & (kQCap - 1u);
 				queue[h != 0u ? slot : kQCap + (uint32_t)lane] = make_uint2(h, meta_tile | (((nb0 + (w >> 4)) % kRing) << 8) | (w << 11)); // wave-uniform arithmetic
 				qtail = rfl(qtail + (uint32_t)__popcll(m));
+#ifdef TS_EXP_WALK_ONLY
+				if (false) {
+#else
 				if (__builtin_expect(qtail - qhead_c > kQCap - 64u, 0)) { // the next step may not fit: let A2 catch up
+#endif
 					lds_publish(c_tail, qtail);
 					TS_T(tg0);
 					do {
@@ -801,7 +808,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll 1
 				for (uint32_t c = 0; c < C; ++c, ++n) {
 					uint32_t I[32];
+#ifndef TS_EXP_WALK_ONLY
 					TS_WAIT(1, ctl + C_PR_READY, n + 1u);
+#endif
 					{ // the chunk's packed words of this lane's 32 reads -> 32 bit planes (both walkers do this: it is cheaper than a
 					  // third party publishing planes through one more LDS slot and one more hand-shake)
 						const uint32_t* pw = reinterpret_cast<const uint32_t*>(tb + kOffPR) + (n % kRing) * 2048u + lane;

@@ -615,6 +615,22 @@ def test_native_merge_devices_matches_single_engine(nt):
     assert f1 == f11 and np.array_equal(regs, regs1)
 
 
+@pytest.mark.parametrize("klist,gap", [([256], 0), ([400], 0), ([600], 0), ([64, 300, 500], 0), ([301], 101), ([255, 256, 257], 0)])
+def test_k_beyond_255(nt, klist, gap):
+    """k up to ntc_max_k() = 600 (the closed-form table stays in LDS, fewer waves per CU): ragged reads up to 1500 bp, a 20 kbp
+    sequence cut into overlapping slots by the host shim, reads shorter than k, N bytes; multi-k and gap seeds"""
+    rng = random.Random(3)
+    reads = [rseq(rng, rng.randint(200, 1500), pn=0.001) for _ in range(200)] + [rseq(rng, 20000, pn=0.0005), rseq(rng, 600), rseq(rng, 599), rseq(rng, 300), b"", rseq(rng, 5)]
+    with nt.Engine(klist, gap=gap, r_bits=14, s_bits=3) as e:
+        e.submit_reads(reads)
+        tc, ph, f1 = e.finish(counters=True)
+    oc, of1 = orc.sketch_reads(reads, klist, gap, 14, 3)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+    assert nt._abi.lib().ntc_max_k() == 600
+    with pytest.raises(nt.NtcError):
+        nt.Engine([601], r_bits=14, s_bits=3)
+
+
 @pytest.mark.parametrize("n_eng,r_bits", [(3, 8), (5, 8), (7, 13), (8, 20)])
 def test_native_merge_slices_and_wraps(nt, n_eng, r_bits):
     """ntc_merge_devices' 16-bit slice exchange with engine counts that do not divide the counters (short and 16-byte-rounded
