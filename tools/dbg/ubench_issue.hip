@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 template <int KIND>
-__global__ __launch_bounds__(512) void k(uint32_t* out, unsigned long long* clk, int iters)
+__global__ __launch_bounds__(1024) void k(uint32_t* out, unsigned long long* clk, int iters)
 {
 	uint32_t r[32];
 #pragma unroll
@@ -38,7 +38,7 @@ void run(const char* name, int waves_per_simd, int ops_per_item)
 {
 	uint32_t* out;
 	unsigned long long* clk;
-	hipMalloc(&out, 256 * 512 * 4);
+	hipMalloc(&out, 256 * 1024 * 4);
 	hipMalloc(&clk, 8);
 	const int iters = 2000, threads = 256 * waves_per_simd;
 	for (int rep = 0; rep < 2; ++rep) {
@@ -56,7 +56,7 @@ void run(const char* name, int waves_per_simd, int ops_per_item)
 }
 int main()
 {
-	for (int w = 1; w <= 2; ++w) {
+	for (int w = 1; w <= 4; ++w) {
 		run<0>("v_bitop3 (3 distinct VGPRs)", w, 1);
 		run<1>("v_bitop3 (2 distinct VGPRs)", w, 1);
 		run<7>("v_bitop3 (2 VGPRs + SGPR)", w, 1);
