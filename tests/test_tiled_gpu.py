@@ -104,6 +104,22 @@ def test_tiled_batches_and_modes(nt):
     check(nt, reads, 150, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, pieces=2)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_tiled_kernel_random_shapes(nt, seed):
+    """random read length (32 .. 400), read count (partial last tile, one read, several tiles per team), sBits and rate of
+    non-ACGTU bytes: K1c's chunk / ring / window arithmetic has no special case for 150 bp"""
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.integers(32, 401))
+    n = int(rng.choice([1, 63, 2047, 2048, 2049, 5000, 9000]))
+    s_bits = int(rng.choice([7, 8, 9, 12]))
+    p_bad = float(rng.choice([0.0, 0.001, 0.02]))
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    if p_bad:
+        arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    check(nt, [arr[i].tobytes() for i in range(n)], L, s_bits=s_bits)
+
+
 def test_tiled_layout_falls_back_for_other_configurations(nt):
     """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
     reads = gen_host(5000, 150, 1)
