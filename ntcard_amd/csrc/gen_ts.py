@@ -140,17 +140,48 @@ def emit_xplanes(name, s_bits):
     return head + "\n" + "\n".join(e.lines) + f"\n\teqA = {eqa};\n\tgeA = {gea};\n\teqB = {b};\n}}\n", len(e.lines)
 
 
-def generate(ks=(32,)):
+KS = tuple(range(16, 33))  # the k the tiled streaming kernel is instantiated for (a window of k <= 32 bases spans at most 3 chunks)
+
+
+def poly_a_state(k, strand):
+    """31-bit half of the strand's hash of a window of k 'A's: the walk starts from it and feeds 'A' (code 0) as the outgoing base
+    for the first k steps, which leaves the hash of the first k real bases behind — no separate window-filling body"""
+    h = 0
+    for t in range(k):
+        h ^= rol31(hseed("A"), k - 1 - t) if strand == "F" else rol31(hseed(COMP["A"]), t)
+    return h
+
+
+def emit_init(name, k, strand):
+    h = poly_a_state(k, strand)
+    lines = [f"__device__ __forceinline__ void {name}(uint32_t (&S)[31])", "{"]
+    lines += [f"\tS[{j}] = {'0xffffffffu' if (h >> j) & 1 else '0u'};" for j in range(31)]
+    return "\n".join(lines) + "\n}\n"
+
+
+def emit_dispatch(ks):
+    out = []
+    for fn, args, call in (("ts_main", "uint32_t (&S)[31], uint32_t i0, uint32_t i1, uint32_t o0, uint32_t o1", "S, i0, i1, o0, o1"),
+                           ("ts_init", "uint32_t (&S)[31]", "S")):
+        out.append(f"template <bool FWD, int K>\n__device__ __forceinline__ void {fn}({args})\n{{")
+        for i, k in enumerate(ks):
+            kw = "if" if i == 0 else "else if"
+            out.append(f"\t{kw} constexpr (K == {k}) {{ if constexpr (FWD) {fn}_F_k{k}({call}); else {fn}_R_k{k}({call}); }}")
+        out.append("\telse static_assert(K < 0, \"gen_ts.py emits no body for this k\");\n}\n")
+    return "\n".join(out)
+
+
+def generate(ks=KS):
     out = ["// ntc_ts_gen.inc — GENERATED by gen_ts.py (do not edit): per-strand step bodies of the tiled streaming kernel K1c.",
            "// See gen_ts.py / gen_bs.py for the derivation; tables follow from the four seeds of nthash.hpp:25-28.", ""]
     stats = {}
     for k in ks:
         for strand in "FR":
-            s, n1 = emit_strand_step(f"ts_warm_{strand}_k{k}", k, strand, False)
-            out.append(s)
             s, n2 = emit_strand_step(f"ts_main_{strand}_k{k}", k, strand, True)
             out.append(s)
-            stats[f"{strand}{k}"] = (n1, n2)
+            out.append(emit_init(f"ts_init_{strand}_k{k}", k, strand))
+            stats[f"{strand}{k}"] = n2
+    out.append(emit_dispatch(ks))
     for sb in (2, 3, 4, 5, 6, 7, 8):
         s, n = emit_cand(f"ts_cand_s{sb}", sb)
         out.append(s)
@@ -233,6 +264,41 @@ def selftest():
                     gf = sum(((S["F"][b] >> i) & 1) << b for b in range(31))
                     gr = sum(((S["R"][b] >> i) & 1) << b for b in range(31))
                     assert (gf, gr) == (fh, rh), (k, j, i)
+    # the kernel's form: start from the hash of k 'A's, main body from step 0 with 'A' (code 0) going out for the first k steps
+    for k in (16, 21, 25, 31, 32):
+        nreads, L = 32, 70
+        reads = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(nreads)]
+        full = (1 << nreads) - 1
+
+        def planes2(pos):
+            b0 = b1 = 0
+            for i, s in enumerate(reads):
+                c = CODE2[s[pos]]
+                b0 |= (c & 1) << i
+                b1 |= (c >> 1) << i
+            return b0, b1
+        S = {}
+        body = {}
+        for strand in "FR":
+            h = poly_a_state(k, strand)
+            S[strand] = [full if (h >> j) & 1 else 0 for j in range(31)]
+            assert emit_init("i", k, strand).count("0xffffffffu") == bin(h).count("1")
+            body[strand] = emit_strand_step("m", k, strand, True)[0]
+        for j in range(L):
+            i0, i1 = planes2(j)
+            o0, o1 = planes2(j - k) if j >= k else (0, 0)
+            for strand in "FR":
+                S[strand] = run_body(body[strand], S[strand], {"i0": i0, "i1": i1, "o0": o0, "o1": o1, "_full": full})
+            if j >= k - 1:
+                p = j - k + 1
+                for i, s in enumerate(reads):
+                    fh = rh = 0
+                    for t in range(k):
+                        fh ^= rol31(hseed(s[p + t]), k - 1 - t)
+                        rh ^= rol31(hseed(COMP[s[p + t]]), t)
+                    gf = sum(((S["F"][b] >> i) & 1) << b for b in range(31))
+                    gr = sum(((S["R"][b] >> i) & 1) << b for b in range(31))
+                    assert (gf, gr) == (fh, rh), ("poly-A start", k, j, i)
     for sb in (2, 3, 5, 7, 8, 11):
         src = emit_cand("c", min(sb, 8))[0]
         n = min(sb + 1, 8)

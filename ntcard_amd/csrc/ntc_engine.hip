@@ -258,6 +258,7 @@ struct ntc_engine {
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
 	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry (NULL: neither is used by this engine)
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
+	bool bs_ok = false;             // K1b (bit-sliced kernel over row slots) is
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
 	bool defer_redo = false;        // NTC_FLAG_DEFER_REDO
 	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1c does not cover
@@ -561,7 +562,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		// measured on genome-like reads, hash kernels per 10 M reads: 97 windows 0.63 vs K1's 0.74 ms, 109: 0.65 vs 0.80, 119: 0.68
 		// vs 0.87, 128: 0.72 vs 1.10; 93 windows, where the fourth walker idles: about equal); NTC_FLAG_BITSLICE_KERNEL lifts that
 		const uint32_t n_win = read_len >= k0 ? read_len - k0 + 1 : 0;
-		const bool use_bs = e->d_t4 && e->d_log && d_meta == nullptr && n_win >= (e->bs_min_tiles > 1 ? 97u : 1u) && n_win <= 255 && stride >= 128 && stride <= 160 &&
+		const bool use_bs = e->bs_ok && e->d_t4 && e->d_log && d_meta == nullptr && n_win >= (e->bs_min_tiles > 1 ? 97u : 1u) && n_win <= 255 && stride >= 128 && stride <= 160 &&
 		                    ntc::sketch_bs_smem(k0, stride) <= kMaxDynLds && n_slots >= 2048 * e->bs_min_tiles;
 		if (e->d_log && e->adaptive && !e->probed && !use_bs && d_meta == nullptr && per_slot > 0.0) {
 			const uint64_t head = (((uint64_t)(kProbeEntries / per_slot) + 2047) / 2048) * 2048;
@@ -935,8 +936,8 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
 	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
 	           ntc::sketch_ts_supports(e->klist[0], e->s_bits) && ntc::sketch_ts_smem(e->klist[0]) <= kMaxDynLds;
-	if (e->kernel_kind == KIND_HF && (bs_wanted || e->ts_ok) && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
-	    ntc::sketch_bs_supports(e->klist[0], e->s_bits)) {
+	e->bs_ok = e->kernel_kind == KIND_HF && bs_wanted && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 && ntc::sketch_bs_supports(e->klist[0], e->s_bits);
+	if (e->bs_ok || e->ts_ok) {
 		std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[0]) * 256 * 4);
 		ntc::build_t4(e->klist[0], t4.data());
 		if (hipMalloc(&e->d_t4, t4.size() * 4) != hipSuccess || hipMemcpy(e->d_t4, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -944,7 +945,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the bit-sliced kernel on device");
 		}
 	}
-	if (!e->d_t4) e->ts_ok = false;
+	if (!e->d_t4) e->ts_ok = e->bs_ok = false;
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
 	e->defer_redo = (cfg->flags & NTC_FLAG_DEFER_REDO) != 0;
 	e->hfk.resize(e->klist.size());

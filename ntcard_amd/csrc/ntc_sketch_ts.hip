@@ -141,17 +141,6 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 }
 
 template <int SB>
-__device__ __forceinline__ uint32_t ts_cand(const uint32_t (&S)[31])
-{
-	if constexpr (SB == 2) return ts_cand_s2(S);
-	else if constexpr (SB == 3) return ts_cand_s3(S);
-	else if constexpr (SB == 4) return ts_cand_s4(S);
-	else if constexpr (SB == 5) return ts_cand_s5(S);
-	else if constexpr (SB == 6) return ts_cand_s6(S);
-	else if constexpr (SB == 7) return ts_cand_s7(S);
-	else return ts_cand_s8(S);
-}
-template <int SB>
 __device__ __forceinline__ void ts_xplanes(const uint32_t (&S)[31], uint32_t& eqA, uint32_t& geA, uint32_t& eqB)
 {
 	if constexpr (SB == 2) ts_xplanes_s2(S, eqA, geA, eqB);
@@ -162,19 +151,6 @@ __device__ __forceinline__ void ts_xplanes(const uint32_t (&S)[31], uint32_t& eq
 	else if constexpr (SB == 7) ts_xplanes_s7(S, eqA, geA, eqB);
 	else ts_xplanes_s8(S, eqA, geA, eqB);
 }
-template <bool FWD>
-__device__ __forceinline__ void ts_warm(uint32_t (&S)[31], uint32_t i0, uint32_t i1)
-{
-	if constexpr (FWD) ts_warm_F_k32(S, i0, i1);
-	else ts_warm_R_k32(S, i0, i1);
-}
-template <bool FWD>
-__device__ __forceinline__ void ts_main(uint32_t (&S)[31], uint32_t i0, uint32_t i1, uint32_t o0, uint32_t o1)
-{
-	if constexpr (FWD) ts_main_F_k32(S, i0, i1, o0, o1);
-	else ts_main_R_k32(S, i0, i1, o0, o1);
-}
-
 // ---- LDS plan ------------------------------------------------------------------------------------------------
 constexpr uint32_t kTile = kTileReads;
 constexpr uint32_t kRing = 5;            // packed chunks kept: a block's candidates need chunks n-2 .. n, the walkers are one ahead, and a fifth
@@ -269,7 +245,7 @@ __device__ __forceinline__ void lds_wait_ge(const uint32_t* p, uint32_t v)
 // runs a pass for the slots alone, so `res` never trails for want of new candidates.
 template <int K, int NI>
 struct TsResolver {
-	static constexpr int KB = K / 16;
+	static constexpr int NG = (K + 3) / 4; // table groups: 4 bases per look-up (the last one is partial when k % 4 != 0: its table has no terms beyond base k - 1)
 	const TsArgs* a;
 	unsigned char* tb;
 	uint32_t* ctl;
@@ -374,11 +350,12 @@ struct TsResolver {
 			uint32_t m0 = 0, m1 = 0, m2 = 0;
 			if (act) {
 				m0 = inv16(raw_piece(tt, c0, r));
-				m1 = inv16(raw_piece(tt, c0 + 1u, r));
+				if (c0 + 1u < C) m1 = inv16(raw_piece(tt, c0 + 1u, r)); // (k <= 16 windows may end in their first piece)
 				if (c0 + 2u < C) m2 = inv16(raw_piece(tt, c0 + 2u, r));
 			}
 			const uint64_t all = (uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32);
-			const uint32_t ok[1] = {act && (uint32_t)(all >> (w & 15u)) == 0u ? 1u : 0u}; // no non-ACGTU byte among the window's 32 bases (k = 32)
+			constexpr uint32_t kWin = K == 32 ? 0xffffffffu : (1u << (K & 31)) - 1u;
+			const uint32_t ok[1] = {act && ((uint32_t)(all >> (w & 15u)) & kWin) == 0u ? 1u : 0u}; // no non-ACGTU byte among the window's k bases
 			const uint32_t ky[1] = {s.x};
 			log_append<1>(ok, ky, ok[0]);
 		}
@@ -469,24 +446,24 @@ struct TsResolver {
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		// 3. closed form, 4 bases per look-up: all table addresses, then all look-ups in flight together, then the XORs
-		uint32_t toff[NI][K / 4];
+		uint32_t toff[NI][NG];
 #pragma unroll
 		for (int j = 0; j < NI; ++j) {
 			const uint32_t shf = (ww[j] & 15u) * 2u;
 #pragma unroll
-			for (int i = 0; i < KB; ++i) {
+			for (int i = 0; i < (NG + 3) / 4; ++i) {
 				const uint32_t x = i == 0 ? alignbit(d1[j], d0[j], shf) : alignbit(d2[j], d1[j], shf); // 16 bases of the window
 #pragma unroll
 				for (int g = 0; g < 4; ++g)
-					toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
+					if (i * 4 + g < NG) toff[j][i * 4 + g] = ((x >> (8 * g)) & 0xffu) * 16u;
 			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		v4u32 tv[NI][K / 4];
+		v4u32 tv[NI][NG];
 #pragma unroll
 		for (int j = 0; j < NI; ++j)
 #pragma unroll
-			for (int i = 0; i < K / 4; ++i)
+			for (int i = 0; i < NG; ++i)
 #ifdef TS_EXP_NOTABLE
 				tv[j][i] = v4u32{toff[j][i], d0[j], d1[j], d2[j]};
 #else
@@ -497,12 +474,22 @@ struct TsResolver {
 		uint32_t hit[NI], key[NI], sus[NI]; // 0 / 1
 #pragma unroll
 		for (int j = 0; j < NI; ++j) {
-			static_assert(K / 4 == 8, "XOR tree below is written for 8 table entries");
-			auto x3 = [](uint32_t p, uint32_t q, uint32_t r) { return (uint32_t)__builtin_amdgcn_bitop3_b32(p, q, r, 0x96); };
-			const uint32_t flo = x3(x3(tv[j][0].x, tv[j][1].x, tv[j][2].x), x3(tv[j][3].x, tv[j][4].x, tv[j][5].x), tv[j][6].x ^ tv[j][7].x);
-			const uint32_t fhi = x3(x3(tv[j][0].y, tv[j][1].y, tv[j][2].y), x3(tv[j][3].y, tv[j][4].y, tv[j][5].y), tv[j][6].y ^ tv[j][7].y);
-			const uint32_t rlo = x3(x3(tv[j][0].z, tv[j][1].z, tv[j][2].z), x3(tv[j][3].z, tv[j][4].z, tv[j][5].z), tv[j][6].z ^ tv[j][7].z);
-			const uint32_t rhi = x3(x3(tv[j][0].w, tv[j][1].w, tv[j][2].w), x3(tv[j][3].w, tv[j][4].w, tv[j][5].w), tv[j][6].w ^ tv[j][7].w);
+			// XOR of the NG table entries, three inputs per instruction
+			v4u32 acc = tv[j][0];
+#pragma unroll
+			for (int i = 1; i + 1 < NG; i += 2) {
+				acc.x = (uint32_t)__builtin_amdgcn_bitop3_b32(acc.x, tv[j][i].x, tv[j][i + 1].x, 0x96);
+				acc.y = (uint32_t)__builtin_amdgcn_bitop3_b32(acc.y, tv[j][i].y, tv[j][i + 1].y, 0x96);
+				acc.z = (uint32_t)__builtin_amdgcn_bitop3_b32(acc.z, tv[j][i].z, tv[j][i + 1].z, 0x96);
+				acc.w = (uint32_t)__builtin_amdgcn_bitop3_b32(acc.w, tv[j][i].w, tv[j][i + 1].w, 0x96);
+			}
+			if constexpr (NG % 2 == 0) {
+				acc.x ^= tv[j][NG - 1].x;
+				acc.y ^= tv[j][NG - 1].y;
+				acc.z ^= tv[j][NG - 1].z;
+				acc.w ^= tv[j][NG - 1].w;
+			}
+			const uint32_t flo = acc.x, fhi = acc.y, rlo = acc.z, rhi = acc.w;
 			const uint64_t fh = ((uint64_t)fhi << 32) | flo, rh = ((uint64_t)rhi << 32) | rlo;
 			const bool rev = rh < fh; // nthash.hpp:275-279
 			const uint32_t hi = rev ? rhi : fhi, lo = rev ? rlo : flo;
@@ -516,7 +503,7 @@ struct TsResolver {
 			key[j] = a->key_base + (lo & rmask) + (c1 ? rbuck : 0u);
 			// a window that touches a 16-byte piece with a non-ACGTU byte somewhere is settled from the raw bytes (the third piece
 			// only counts when the window is not chunk-aligned)
-			const uint32_t dd = (b0[j] | b1[j] | ((ww[j] & 15u) != 0u ? b2[j] : 0u)) >> mm[j];
+			const uint32_t dd = (b0[j] | ((ww[j] & 15u) + (uint32_t)K > 16u ? b1[j] : 0u) | ((ww[j] & 15u) + (uint32_t)K > 32u ? b2[j] : 0u)) >> mm[j];
 			sus[j] = ht ? dd & 1u : 0u;
 			hit[j] = (ht ? 1u : 0u) & ~sus[j];
 			nhit += hit[j];
@@ -600,15 +587,14 @@ struct TsResolver {
 template <int K, int SB>
 __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 {
-	static_assert(K == 32, "K1c step bodies are generated for k = 32 (gen_ts.py)");
-	constexpr int KB = K / 16; // chunks between a base entering and leaving the window
+	static_assert(K >= 16 && K <= 32, "K1c: a window spans at most 3 chunks and leaves at most 2 chunks behind the one being walked (gen_ts.py emits k = 16 .. 32)");
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const uint32_t wave = rfl((uint32_t)tid >> 6);
 	// wave w and w + 4 share a SIMD: a walker of one team sits next to an assistant of the other
 	const uint32_t team = wave < 4u ? wave >> 1 : ((wave >> 1) & 1u) ^ 1u;
 	const uint32_t role = wave < 4u ? (wave & 1u) : 2u + (wave & 1u); // 0 F, 1 R, 2 A1, 3 A2
-	const uint32_t t4_bytes = (uint32_t)(K / 4) * 4096u;
+	const uint32_t t4_bytes = (uint32_t)((K + 3) / 4) * 4096u;
 	unsigned char* const t4 = smem;
 	unsigned char* const tb = smem + t4_bytes + team * kTeamBytes;
 	uint32_t* const ctl = reinterpret_cast<uint32_t*>(tb + kOffCT);
@@ -795,13 +781,14 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			for (uint32_t t = team_g, seq = 0; t < a.n_tiles; t += n_teams, ++seq) {
 				meta_tile = (uint32_t)lane | (FWD ? 0u : 64u) | ((has_partial && t == a.n_tiles - 1u) ? 128u : 0u) | ((seq & 15u) << 27); // bits 27..30: which tile (suspects)
 				nb0 = (seq * C) % kRing;
+				// The walk starts from the hash of k 'A's and feeds 'A' (code 0: the zeroed history planes) as the outgoing base of the
+				// first k steps: what is left after step k - 1 is the hash of the first k real bases (gen_ts.py, poly_a_state), and
+				// every step of every block is the same generated body.
 				uint32_t S[31];
+				ts_init<FWD, K>(S);
+				uint32_t H[2][32]; // the planes of the two chunks before the one being walked: the outgoing base is k <= 32 bases back
 #pragma unroll
-				for (int j = 0; j < 31; ++j)
-					S[j] = 0;
-				uint32_t H[KB][32];
-#pragma unroll
-				for (int b = 0; b < KB; ++b)
+				for (int b = 0; b < 2; ++b)
 #pragma unroll
 					for (int i = 0; i < 32; ++i)
 						H[b][i] = 0;
@@ -819,53 +806,45 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 							I[m] = pw[m * 64];
 						transpose32(I); // I[2 q + b] = bit b of the code of base 16 c + q, one bit per read
 					}
-					if (c < (uint32_t)KB) { // window filling: no outgoing base; the last step completes window 0
+					// step q of this block takes base 16 c + q in and base 16 c + q - k out (planes 2 o, 2 o + 1 of the history, o = q + 32 - k)
+					// and completes window 16 c + q - (k - 1) (none while that is negative: the unsigned value fails push()'s w < W)
+					const uint32_t w0 = 16u * c - (uint32_t)K + 1u;
 #pragma unroll
-						for (int q = 0; q < 16; ++q) {
-							ts_warm<FWD>(S, I[2 * q], I[2 * q + 1]);
-							pin31(S);
-						}
-						if (c == (uint32_t)KB - 1u) push(ts_cand<SB>(S), 0u);
-					} else {
+					for (int hb = 0; hb < 2; ++hb) {
 						// Candidates with the other strand's help: a window is sampled through THIS strand iff its top bits carry a pattern and
 						// the other strand's are not smaller (gen_ts.py, emit_xplanes).  Each walker posts one plane per step (its top bits
 						// >= 01..1) and, every half block, combines its own equality planes with the other walker's: a third fewer
 						// candidates for the resolve stage than either strand's pattern alone.
-						const uint32_t w0 = 16u * c - (uint32_t)K + 1u;
+						uint32_t eqA[8], eqB[8];
+						if (xhalf != 0u) lds_wait_ge(x_cons_other, xhalf); // the other walker has read my planes of the previous half block
 #pragma unroll
-						for (int hb = 0; hb < 2; ++hb) {
-							uint32_t eqA[8], eqB[8];
-							if (xhalf != 0u) lds_wait_ge(x_cons_other, xhalf); // the other walker has read my planes of the previous half block
+						for (int q8 = 0; q8 < 8; ++q8) {
+							const int q = hb * 8 + q8, o = q + 32 - K;
+							ts_main<FWD, K>(S, I[2 * q], I[2 * q + 1], o < 16 ? H[0][2 * (o & 15)] : H[1][2 * (o & 15)], o < 16 ? H[0][2 * (o & 15) + 1] : H[1][2 * (o & 15) + 1]);
+							pin31(S);
+							uint32_t ge;
+							ts_xplanes<SB>(S, eqA[q8], ge, eqB[q8]);
+							x_mine[q8 * 64] = ge;
+						}
+						++xhalf;
+						lds_publish(x_pub_mine, xhalf);
+						TS_WAIT(3, x_pub_other, xhalf);
+						uint32_t og[8];
 #pragma unroll
-							for (int q8 = 0; q8 < 8; ++q8) {
-								const int q = hb * 8 + q8;
-								ts_main<FWD>(S, I[2 * q], I[2 * q + 1], H[0][2 * q], H[0][2 * q + 1]);
-								pin31(S);
-								uint32_t ge;
-								ts_xplanes<SB>(S, eqA[q8], ge, eqB[q8]);
-								x_mine[q8 * 64] = ge;
-							}
-							++xhalf;
-							lds_publish(x_pub_mine, xhalf);
-							TS_WAIT(3, x_pub_other, xhalf);
-							uint32_t og[8];
-#pragma unroll
-							for (int q8 = 0; q8 < 8; ++q8)
-								og[q8] = x_other[q8 * 64];
-							lds_publish(x_cons_mine, xhalf); // (behind the reads above)
+						for (int q8 = 0; q8 < 8; ++q8)
+							og[q8] = x_other[q8 * 64];
+						lds_publish(x_cons_mine, xhalf); // (behind the reads above)
+						if ((int32_t)(16u * c) + 8 * hb + 7 >= K - 1) { // (no window ends in the first k - 1 steps of a tile)
 #pragma unroll
 							for (int q8 = 0; q8 < 8; ++q8)
 								push((eqA[q8] & og[q8]) | eqB[q8], w0 + (uint32_t)(hb * 8 + q8));
 						}
 					}
 #pragma unroll
-					for (int hh = 0; hh + 1 < KB; ++hh)
-#pragma unroll
-						for (int i = 0; i < 32; ++i)
-							H[hh][i] = H[hh + 1][i];
-#pragma unroll
-					for (int i = 0; i < 32; ++i)
-						H[KB - 1][i] = I[i];
+					for (int i = 0; i < 32; ++i) {
+						H[0][i] = H[1][i];
+						H[1][i] = I[i];
+					}
 					// block n is complete: its items end at qtail
 					lds_publish(ctl + C_BT + 2u * (n & 7u) + (FWD ? 0u : 1u), qtail);
 					lds_publish(c_tail, qtail);
@@ -958,35 +937,111 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #endif
 }
 
+// ---- instantiations -------------------------------------------------------------------------------------------
+// One kernel per (k, sBits class); the object files ntc_sketch_ts_p{0..3}.o each carry the k with (k - 16) % 4 == part
+// (Makefile: -DTS_PART=n, built in parallel); -DTS_ONLY_K=k (tools/dbg) builds a single k.
+#ifndef TS_PART
+#define TS_PART 0
+#define TS_ALL_PARTS 1
+#endif
+#ifdef TS_ONLY_K
+#define TS_MINE(k) ((k) == TS_ONLY_K)
+#elif defined(TS_ALL_PARTS)
+#define TS_MINE(k) true
+#else
+#define TS_MINE(k) ((((k) - 16) & 3) == TS_PART)
+#endif
+#define TS_FOR_K(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+
 namespace {
 template <int K, int SB>
 hipError_t launch_one(const TsArgs& a, unsigned grid, size_t smem, hipStream_t st)
 {
-	hipLaunchKernelGGL((sketch_ts_kernel<K, SB>), dim3(grid), dim3(512), smem, st, a);
-	return hipGetLastError();
+	if constexpr (TS_MINE(K)) {
+		hipLaunchKernelGGL((sketch_ts_kernel<K, SB>), dim3(grid), dim3(512), smem, st, a);
+		return hipGetLastError();
+	} else {
+		return hipErrorInvalidValue;
+	}
+}
+template <int K>
+hipError_t set_limit_one(size_t smem)
+{
+	if constexpr (TS_MINE(K)) {
+		hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_ts_kernel<K, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		if (rc == hipSuccess) rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_ts_kernel<K, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		return rc;
+	} else {
+		return hipSuccess;
+	}
 }
 } // namespace
 
-bool sketch_ts_supports(uint32_t k, uint32_t s_bits) { return k == 32 && s_bits >= 7; }
+#define TS_CAT2(a, b) a##b
+#define TS_CAT(a, b) TS_CAT2(a, b)
+// this object's share: launch (false: k belongs to another part) and the LDS attribute of its kernels
+bool TS_CAT(sketch_ts_launch_part, TS_PART)(const TsArgs& a, unsigned grid, size_t smem, hipStream_t st, hipError_t* rc)
+{
+	switch (a.k) {
+#define X(k)                                                                                                     \
+	case k:                                                                                                      \
+		if (!TS_MINE(k)) return false;                                                                           \
+		*rc = a.s_bits == 7 ? launch_one<k, 7>(a, grid, smem, st) : launch_one<k, 8>(a, grid, smem, st);         \
+		return true;
+		TS_FOR_K(X)
+#undef X
+	default:
+		return false;
+	}
+}
+hipError_t TS_CAT(sketch_ts_limit_part, TS_PART)(size_t smem)
+{
+	hipError_t rc = hipSuccess;
+#define X(k) \
+	if (rc == hipSuccess) rc = set_limit_one<k>(smem);
+	TS_FOR_K(X)
+#undef X
+	return rc;
+}
 
-size_t sketch_ts_smem(uint32_t k) { return (size_t)(k / 4) * 4096 + 2 * (size_t)kTeamBytes; }
+#if TS_PART == 0
+#ifndef TS_ALL_PARTS
+bool sketch_ts_launch_part1(const TsArgs&, unsigned, size_t, hipStream_t, hipError_t*);
+bool sketch_ts_launch_part2(const TsArgs&, unsigned, size_t, hipStream_t, hipError_t*);
+bool sketch_ts_launch_part3(const TsArgs&, unsigned, size_t, hipStream_t, hipError_t*);
+hipError_t sketch_ts_limit_part1(size_t);
+hipError_t sketch_ts_limit_part2(size_t);
+hipError_t sketch_ts_limit_part3(size_t);
+#endif
+
+bool sketch_ts_supports(uint32_t k, uint32_t s_bits) { return k >= 16 && k <= 32 && s_bits >= 7; }
+
+size_t sketch_ts_smem(uint32_t k) { return (size_t)((k + 3) / 4) * 4096 + 2 * (size_t)kTeamBytes; }
 
 hipError_t launch_sketch_ts(const TsArgs& a, unsigned grid, hipStream_t st)
 {
+	if (!sketch_ts_supports(a.k, a.s_bits)) return hipErrorInvalidValue;
 	const size_t smem = sketch_ts_smem(a.k);
-	if (a.k != 32) return hipErrorInvalidValue;
-	if (a.s_bits < 7) return hipErrorInvalidValue;
-	return a.s_bits == 7 ? launch_one<32, 7>(a, grid, smem, st) : launch_one<32, 8>(a, grid, smem, st);
+	hipError_t rc = hipErrorInvalidValue;
+	if (sketch_ts_launch_part0(a, grid, smem, st, &rc)) return rc;
+#ifndef TS_ALL_PARTS
+	if (sketch_ts_launch_part1(a, grid, smem, st, &rc)) return rc;
+	if (sketch_ts_launch_part2(a, grid, smem, st, &rc)) return rc;
+	if (sketch_ts_launch_part3(a, grid, smem, st, &rc)) return rc;
+#endif
+	return hipErrorInvalidValue;
 }
 
 hipError_t set_sketch_ts_smem_limit(size_t smem)
 {
-	const void* fns[] = { reinterpret_cast<const void*>(&sketch_ts_kernel<32, 7>), reinterpret_cast<const void*>(&sketch_ts_kernel<32, 8>) };
-	for (const void* f : fns) {
-		const hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-		if (rc != hipSuccess) return rc;
-	}
-	return hipSuccess;
+	hipError_t rc = sketch_ts_limit_part0(smem);
+#ifndef TS_ALL_PARTS
+	if (rc == hipSuccess) rc = sketch_ts_limit_part1(smem);
+	if (rc == hipSuccess) rc = sketch_ts_limit_part2(smem);
+	if (rc == hipSuccess) rc = sketch_ts_limit_part3(smem);
+#endif
+	return rc;
 }
+#endif
 
 } // namespace ntc

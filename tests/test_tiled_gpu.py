@@ -104,12 +104,26 @@ def test_tiled_batches_and_modes(nt):
     check(nt, reads, 150, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, pieces=2)
 
 
+@pytest.mark.parametrize("k", list(range(16, 32)))
+def test_tiled_kernel_every_k(nt, k):
+    """K1c is instantiated for k = 16 .. 32 (one generated step body per k, the walk starts from the hash of k 'A's): reads of
+    exactly k and k + 1 bases, 97 and 150 bp, non-ACGTU bytes, sBits 7 / 8 / 11"""
+    rng = np.random.default_rng(k)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    for n, L, s_bits, p_bad in ((3000, 150, 7, 0.002), (2100, k, 7, 0.0), (2500, k + 1, 8, 0.01), (2049, 97, 11, 0.0)):
+        arr = alpha[rng.integers(0, 4, size=(n, L))]
+        if p_bad:
+            arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+        check(nt, [arr[i].tobytes() for i in range(n)], L, k=k, s_bits=s_bits)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_tiled_kernel_random_shapes(nt, seed):
     """random read length (32 .. 400), read count (partial last tile, one read, several tiles per team), sBits and rate of
     non-ACGTU bytes: K1c's chunk / ring / window arithmetic has no special case for 150 bp"""
     rng = np.random.default_rng(1000 + seed)
-    L = int(rng.integers(32, 401))
+    k = int(rng.integers(16, 33))
+    L = int(rng.integers(k, 401))
     n = int(rng.choice([1, 63, 2047, 2048, 2049, 5000, 9000]))
     s_bits = int(rng.choice([7, 8, 9, 12]))
     p_bad = float(rng.choice([0.0, 0.001, 0.02]))
@@ -117,14 +131,14 @@ def test_tiled_kernel_random_shapes(nt, seed):
     arr = alpha[rng.integers(0, 4, size=(n, L))]
     if p_bad:
         arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
-    check(nt, [arr[i].tobytes() for i in range(n)], L, s_bits=s_bits)
+    check(nt, [arr[i].tobytes() for i in range(n)], L, k=k, s_bits=s_bits)
 
 
 def test_tiled_layout_falls_back_for_other_configurations(nt):
     """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
     reads = gen_host(5000, 150, 1)
     t = torch.from_numpy(nt.tile_reads(reads, 150)).cuda()
-    for klist, gap, s_bits in (([20], 0, 7), ([32, 64], 0, 7), ([12], 2, 7), ([32], 0, 5)):
+    for klist, gap, s_bits in (([40], 0, 7), ([15], 0, 7), ([32, 64], 0, 7), ([12], 2, 7), ([32], 0, 5)):
         with nt.Engine(klist, gap=gap, r_bits=16, s_bits=s_bits) as e:
             e.submit_tiled_device(t.data_ptr(), len(reads), 150)
             tc, ph, f1 = e.finish(counters=True)

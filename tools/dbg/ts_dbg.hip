@@ -1,5 +1,6 @@
 // debugging harness for K1c: runs the kernel on tiles.bin and prints what the resolve stage saw per candidate
 #define TS_DEBUG 1
+#define TS_ONLY_K 32
 #include "../../ntcard_amd/csrc/ntc_sketch_ts.hip"
 #include <cstdio>
 #include <vector>

@@ -1,5 +1,6 @@
 // timing harness for K1c: generates tiles on the device, runs the kernel a few times, prints per-role cycle counters (TS_TIMERS)
 #define TS_TIMERS 1
+#define TS_ONLY_K 32
 #include "../../ntcard_amd/csrc/ntc_sketch_ts.hip"
 #include <cstdio>
 #include <vector>
