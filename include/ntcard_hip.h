@@ -125,7 +125,7 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
  * bytes as the parsers produce them (any case, N / IUPAC); bytes behind a read's end and the slots behind the batch's last
  * read must hold a base letter ('A').  All reads of a batch have the same length.  Asynchronous on the engine's stream; the
  * buffer may be reused as soon as the stream has passed the call (nothing refers to it afterwards).  Configurations the
- * tiled kernel is not built for (k != 32, several k, spaced seeds, nthll, sBits < 7) are re-laid out on the device and
+ * tiled kernel is not built for (k outside 16 .. 32, several k, spaced seeds, nthll, sBits < 7) are re-laid out on the device and
  * take the general kernel: same results, not the fast path.                                                           */
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);

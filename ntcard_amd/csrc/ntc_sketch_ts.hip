@@ -1,17 +1,18 @@
 // ntc_sketch_ts.hip — K1c "tiled streaming" kernel: ntHash -> sample -> count for equal-length batches in the TILED
 // slot layout (include/ntcard_hip.h, ntc_submit_tiled_device) on gfx950.
 //
-// What it computes is ntRead + ntComp (ntcard.cpp:132-158) for one k: for every window of k consecutive ACGTU bases
-// the canonical ntHash (nthash.hpp:242-257,275-279), the two sampling patterns on its top bits, and one increment
-// of t_Counter[sample][hash & (rBuck - 1)] per sampled window (as a hit-log entry, ntc_apply.hip), plus F1 = the
-// number of such windows.  ntHashIterator's N semantics (ntHashIterator.hpp:59-86: a window that contains a
+// What it computes is ntRead + ntComp (ntcard.cpp:132-158) for one k of 16 .. 32: for every window of k consecutive
+// ACGTU bases the canonical ntHash (nthash.hpp:242-257,275-279), the two sampling patterns on its top bits, and one
+// increment of t_Counter[sample][hash & (rBuck - 1)] per sampled window (as a hit-log entry, ntc_apply.hip), plus F1 =
+// the number of such windows.  ntHashIterator's N semantics (ntHashIterator.hpp:59-86: a window that contains a
 // non-ACGTU byte yields nothing) are handled here, exactly, without a second kernel.
 //
 // Formulation (see gen_ts.py): the sampling decision only needs the top sBits + 1 bits of min(fh, rh), and those
 // live in the 31-bit rotating half of the hash (nthash.hpp:186-217).  That half is walked BIT-SLICED — one VGPR
 // holds one bit of it for 32 reads, a wave carries a tile of 2048 reads, a rotate is a renaming of registers —
 // and the ~2^(1-sBits) candidate windows are re-derived exactly (full 64-bit fh and rh, canonical min, ntComp's
-// patterns, counter index) from the packed bases by a resolve stage.
+// patterns, counter index) from the packed bases by a resolve stage.  The walk of a read starts from the hash of k
+// 'A's with 'A' going out for the first k steps, so one generated step body per (k, strand) serves every step.
 //
 // Data layout: tile t = reads [2048 t, 2048 t + 2048); chunk c = bases [16 c, 16 c + 16) of every read of the tile;
 // the 16 raw bytes of (t, c, read r) sit at ((t C + c) 2048 + r) 16.  A chunk of a tile is 32 KiB of contiguous HBM
@@ -19,16 +20,20 @@
 // order the bit-sliced walk consumes, so a tile STREAMS through the CU chunk by chunk (any read length, no 78 KB
 // tile image, no window re-filling).
 //
-// Work decomposition: one 512-thread workgroup per CU = two TEAMS of four waves, each team streaming its own tile:
-//   A1  loads a chunk (32 x 1 KiB), packs it to 2 bits per base + a dirty flag per 16 bytes, transposes the
-//       32 x 32 bit matrix into 32 bit planes (registers only) and publishes the planes (8 KiB slot) and the packed
-//       words (ring of 4 x 8 KiB) in LDS;
-//   F,R walk one strand each: 31 state registers, one three-input v_bitop3_b32 per hash bit and base step + the
-//       function planes of the incoming / outgoing base + a candidate test on the strand's own top bits; a step's
-//       candidate plane goes to the strand's LDS queue as one ballot-compacted 8-byte item per lane;
-//   A2  drains both queues 64 candidates at a time: closed-form fh / rh from the packed ring with a
-//       4-bases-per-lookup table, keeps the candidate of the canonical strand only, applies ntComp, logs the counter
-//       index; windows that touch a dirty 16-byte piece and F1's corrections are settled exactly from the raw bytes.
+// Work decomposition: one 512-thread workgroup per CU = two TEAMS of four waves, each team streaming its own tiles:
+//   A1  loads a chunk (32 x 1 KiB, buffer loads one chunk ahead), packs it to 2 bits per base + a dirty flag per 16
+//       bytes into a ring of 5 x 8 KiB packed chunks in LDS, and between chunks resolves the FORWARD strand's
+//       candidates;
+//   F,R walk one strand each: read the chunk's packed words, transpose the 32 x 32 bit matrix into bit planes
+//       (registers), then per base step one generated body (31 state registers, function planes of the incoming and
+//       outgoing base) and a candidate test that uses the other walker's ">= pattern" plane, exchanged through LDS
+//       every half block; a step's candidate plane goes to the strand's LDS queue as one ballot-compacted 8-byte
+//       item per lane;
+//   A2  resolves the REVERSE strand's candidates and does the bookkeeping of non-ACGTU bytes (F1 corrections, dirty
+//       pieces handed over by A1).
+//   A resolver takes candidates out of its queue into per-lane slots, recomputes fh / rh from the packed ring with a
+//   4-bases-per-lookup closed-form table, keeps the candidate of the canonical strand only, applies ntComp and logs
+//   the counter index; windows that touch a dirty 16-byte piece are settled exactly from the raw bytes.
 // The waves of a team only meet through monotonic LDS counters (no workgroup barrier after start-up).  On every SIMD
 // a walker of one team shares the issue slots with an assistant of the other.
 #include <hip/hip_runtime.h>
