@@ -115,18 +115,19 @@ int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, con
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
                       uint32_t stride);
 
-/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernel (K1c) streams, and the
- * one ntc_submit / ntc_submit_spans pack equal-length host batches into:
+/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernel (K1c) streams:
  *     tile t   = reads [2048 t, 2048 t + 2048) of the batch,       n_chunks = ceil(read_len / 16)
  *     piece    = the 16 raw bytes of bases [16 c, 16 c + 16) of read i, at byte offset
  *                ((i / 2048 * n_chunks + c) * 2048 + i % 2048) * 16          (ntc_tiled_bytes() bytes in all)
  * i.e. the pieces of one base range of a tile's 2048 reads are contiguous (32 KiB): one coalesced load hands every lane
  * the next 16 bases of "its" read, in the position-major order the bit-sliced hash walk consumes.  Bytes are raw sequence
- * bytes as the parsers produce them (any case, N / IUPAC); bytes behind a read's end and the slots behind the batch's last
- * read must hold a base letter ('A').  All reads of a batch have the same length.  Asynchronous on the engine's stream; the
- * buffer may be reused as soon as the stream has passed the call (nothing refers to it afterwards).  Configurations the
- * tiled kernel is not built for (k outside 16 .. 32, several k, spaced seeds, nthll, sBits < 7) are re-laid out on the device and
- * take the general kernel: same results, not the fast path.                                                           */
+ * bytes as the parsers produce them (any case, N / IUPAC); bytes behind a read's end (inside its last piece) must hold a base
+ * letter ('A'); the slots behind the batch's last read (the rest of the last tile) are ignored whatever they hold, so any
+ * prefix of a tiled buffer is a valid batch.  All reads of a batch have the same length.  Asynchronous on the engine's
+ * stream; the buffer may be reused as soon as the stream has passed the call (nothing refers to it afterwards).  A list of k is
+ * served by one launch per k.  Configurations the tiled kernel is not built for (a k outside 16 .. 32, spaced seeds, nthll,
+ * sBits < 7) are re-laid out on the device and take the general kernel: same results, not the fast path.  Host batches
+ * (ntc_submit, ntc_submit_spans) use row slots.                                                                          */
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
 

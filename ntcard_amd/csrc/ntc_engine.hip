@@ -256,7 +256,8 @@ struct ntc_engine {
 		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
 	} ap;
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
-	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry (NULL: neither is used by this engine)
+	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry, of klist[0] (NULL: neither is used by this engine)
+	std::vector<void*> d_t4s;       // K1c: one table per k of the list (d_t4s[0] == d_t4)
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
 	bool bs_ok = false;             // K1b (bit-sliced kernel over row slots) is
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
@@ -769,8 +770,6 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len)
 {
 	if (n_reads == 0) return 0;
-	const uint32_t k0 = e->klist[0];
-	if (read_len < k0) return 0; // no window (ntHashIterator.hpp:61-64)
 	if (!e->ts_ok && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
 	if (!e->ts_ok) {
 		// this configuration is served by K1 only: re-lay the batch out as row-major slots (exact; not a fast path)
@@ -789,46 +788,51 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 	}
 	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
 	if (n_tiles > 0xffffffffull / 64) return fail(NTC_ERR_ARG, "tiled batch of %llu reads is too large for one submit", (unsigned long long)n_reads);
-	if (e->d_log) {
-		// candidates of this batch (both samples ~2^-sBits of the windows each) + what every logging wave may leave unused at the end of a region
-		const double per_read = (double)(read_len - k0 + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
-		const double est = 64.0 * 4096 + (double)n_reads * per_read;
-		if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
-			if (int rc = apply_log(e)) return rc;
-		e->log_est += est;
-		e->log_pending = true;
-	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
-	ntc::TsArgs a;
-	std::memset(&a, 0, sizeof a);
-	a.tiles = d_tiles;
-	a.n_reads = n_reads;
-	a.n_tiles = (uint32_t)n_tiles;
-	a.n_chunks = (read_len + 15u) / 16u;
-	a.read_len = read_len;
-	a.k = k0;
-	a.r_bits = e->r_bits;
-	a.s_bits = e->s_bits;
-	a.key_base = 0;
-	if (e->d_log) {
-		a.log = e->d_log;
-		a.log_fill = e->d_logfill;
-		a.log_regions = e->log_regions;
-		a.log_region_cap = e->log_region_cap;
-		a.log_mode = nullptr; // K1c logs whenever the engine has a log
-	}
-	a.sketch0 = e->d_sketch;
-	a.f1 = e->d_f1;
-	a.t4 = e->d_t4;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (e->profiling) {
 		HIP_TRY(hipEventCreate(&ev0));
 		HIP_TRY(hipEventCreate(&ev1));
 		HIP_TRY(hipEventRecord(ev0, e->stream));
 	}
-	const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 1) / 2, (uint64_t)di.cus);
-	HIP_TRY(ntc::launch_sketch_ts(a, grid, e->stream));
+	// ntRead's loop over kList (ntcard.cpp:147-158): one launch per k over the same resident batch
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		const uint32_t k = e->klist[ki];
+		if (read_len < k) continue; // no window of this k (ntHashIterator.hpp:61-64)
+		if (e->d_log) {
+			// candidates of this batch (both samples ~2^-sBits of the windows each) + what every logging wave may leave unused at the end of a region
+			const double per_read = (double)(read_len - k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+			const double est = 64.0 * 4096 + (double)n_reads * per_read;
+			if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
+				if (int rc = apply_log(e)) return rc;
+			e->log_est += est;
+			e->log_pending = true;
+		}
+		ntc::TsArgs a;
+		std::memset(&a, 0, sizeof a);
+		a.tiles = d_tiles;
+		a.n_reads = n_reads;
+		a.n_tiles = (uint32_t)n_tiles;
+		a.n_chunks = (read_len + 15u) / 16u;
+		a.read_len = read_len;
+		a.k = k;
+		a.r_bits = e->r_bits;
+		a.s_bits = e->s_bits;
+		a.key_base = (uint32_t)(ki * e->plane_elems()); // (an engine that gets here has at most 2^32 counters)
+		if (e->d_log) {
+			a.log = e->d_log;
+			a.log_fill = e->d_logfill;
+			a.log_regions = e->log_regions;
+			a.log_region_cap = e->log_region_cap;
+			a.log_mode = nullptr; // K1c logs whenever the engine has a log
+		}
+		a.sketch0 = e->d_sketch;
+		a.f1 = e->d_f1 + ki;
+		a.t4 = e->d_t4s[ki];
+		const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 1) / 2, (uint64_t)di.cus);
+		HIP_TRY(ntc::launch_sketch_ts(a, grid, e->stream));
+	}
 	if (e->profiling) {
 		HIP_TRY(hipEventRecord(ev1, e->stream));
 		e->pending.emplace_back(ev0, ev1);
@@ -934,16 +938,26 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	// takes (ragged, short or long slots, small) keep the adaptive choice
 	const bool bs_wanted = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) || (!(cfg->flags & (NTC_FLAG_LANE_KERNEL | NTC_FLAG_DIRECT_ATOMICS)) && e->d_log != nullptr);
 	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
-	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 &&
-	           ntc::sketch_ts_supports(e->klist[0], e->s_bits) && ntc::sketch_ts_smem(e->klist[0]) <= kMaxDynLds;
+	// K1c (tiled streaming kernel): every k of the list must have an instantiation (k = 16 .. 32); a list is served by one launch
+	// per k over the same resident tiles.  Its hit-log keys and its direct-atomics fallback are 32-bit counter indices.
+	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->gap == 0 && e->hll_bits == 0 &&
+	           e->klist.size() * e->plane_elems() <= (1ull << 32);
+	for (uint32_t k : e->klist)
+		e->ts_ok = e->ts_ok && ntc::sketch_ts_supports(k, e->s_bits) && ntc::sketch_ts_smem(k) <= 160 * 1024;
 	e->bs_ok = e->kernel_kind == KIND_HF && bs_wanted && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 && ntc::sketch_bs_supports(e->klist[0], e->s_bits);
 	if (e->bs_ok || e->ts_ok) {
-		std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[0]) * 256 * 4);
-		ntc::build_t4(e->klist[0], t4.data());
-		if (hipMalloc(&e->d_t4, t4.size() * 4) != hipSuccess || hipMemcpy(e->d_t4, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-			ntc_destroy(e);
-			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the bit-sliced kernel on device");
+		for (size_t ki = 0; ki < (e->ts_ok ? e->klist.size() : 1); ++ki) {
+			std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[ki]) * 256 * 4);
+			ntc::build_t4(e->klist[ki], t4.data());
+			void* d = nullptr;
+			if (hipMalloc(&d, t4.size() * 4) != hipSuccess || hipMemcpy(d, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+				if (d) (void)hipFree(d);
+				ntc_destroy(e);
+				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the bit-sliced kernels on device");
+			}
+			e->d_t4s.push_back(d);
 		}
+		e->d_t4 = e->d_t4s[0];
 	}
 	if (!e->d_t4) e->ts_ok = e->bs_ok = false;
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
@@ -974,12 +988,14 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_untile) (void)hipFree(e->d_untile);
-	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, e->d_t4, (void*)e->d_redo, (void*)e->d_redo_count, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
+	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, (void*)e->d_redo, (void*)e->d_redo_count, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
 		(void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
+	for (void* d : e->d_t4s)
+		if (d) (void)hipFree(d);
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);

@@ -708,6 +708,10 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				__builtin_amdgcn_sched_barrier(0);
 				tacc[3] += tpk1 - tpk0;
 #endif
+				if (has_partial && t == a.n_tiles - 1u) { // slots behind the batch's last read: whatever they hold, it is not a read
+					const uint32_t nv = rs.n_valid_last, groups = nv > (uint32_t)lane ? (nv - (uint32_t)lane + 63u) >> 6 : 0u; // read groups m with 64 m + lane < nv
+					dirtyword &= groups >= 32u ? 0xffffffffu : (1u << groups) - 1u;
+				}
 #if defined(TS_EXP_A1_FREE) || defined(TS_EXP_NODIRTY)
 				const uint64_t dm = 0;
 #else

@@ -134,6 +134,20 @@ def test_tiled_kernel_random_shapes(nt, seed):
     check(nt, [arr[i].tobytes() for i in range(n)], L, k=k, s_bits=s_bits)
 
 
+def test_tiled_kernel_k_lists(nt):
+    """a list of k within 16 .. 32 is one K1c launch per k over the same tiles (ntRead's loop over kList, ntcard.cpp:147-158): planes and
+    F1 per k as the oracle's; reads shorter than some of the k"""
+    for klist, L, n in (([21, 25, 31], 150, 5000), ([32, 16, 24], 100, 2100), ([17, 29], 20, 3000), ([20, 32], 19, 100)):
+        reads = gen_host(n, L, 1)
+        t = torch.from_numpy(nt.tile_reads(reads, L)).cuda()
+        with nt.Engine(klist, r_bits=16, s_bits=7, flags=nt.FLAG_REQUIRE_TILED) as e:
+            e.submit_tiled_device(t.data_ptr(), n, L)
+            e.submit_tiled_device(t.data_ptr(), n // 2, L)  # a prefix of a tiled buffer is a batch: the slots behind its last read are ignored
+            tc, ph, f1 = e.finish(counters=True)
+        oc, of1 = orc.sketch_reads(reads + reads[: n // 2], klist, 0, 16, 7)
+        assert np.array_equal(f1, of1) and np.array_equal(tc, oc), klist
+
+
 def test_tiled_layout_falls_back_for_other_configurations(nt):
     """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
     reads = gen_host(5000, 150, 1)
