@@ -152,17 +152,53 @@ def poly_a_state(k, strand):
     return h
 
 
-def emit_init(name, k, strand):
+def fill_blocks(k):
+    """blocks (16 steps) of a read that only fill the first window: steps 0 .. 16 n - 1 with 16 n - 1 <= k - 1"""
+    return k // 16
+
+
+def fix_constant(k, strand):
+    """The walk of a tile runs its first fill_blocks(k) blocks with the window-filling body (state 0, nothing goes out) and
+    every later step with the main body, whose first k steps expect the virtual 'A's of poly_a_state to go out.  After step s the
+    two states differ by a constant that depends on s alone: what is left of the k 'A's, rotated along.  XOR-ing it in once, at
+    s = 16 fill_blocks(k) - 1, moves the filling state onto the main body's track (0 when s = k - 1: no 'A' is left)."""
+    s = 16 * fill_blocks(k) - 1
+    # run the two EMITTED bodies on a few arbitrary reads (the reads cancel): every state bit differs by the same constant in all reads
+    import random
+    rng = random.Random(k)
+    nreads = 8
+    full = (1 << nreads) - 1
+    reads = ["".join(rng.choice("ACGT") for _ in range(s + 1)) for _ in range(nreads)]
     h = poly_a_state(k, strand)
+    A = [full if (h >> j) & 1 else 0 for j in range(31)]
+    Z = [0] * 31
+    warm = emit_strand_step("w", k, strand, False)[0]
+    main = emit_strand_step("m", k, strand, True)[0]
+    for j in range(s + 1):
+        i0 = sum((CODE2[r[j]] & 1) << i for i, r in enumerate(reads))
+        i1 = sum((CODE2[r[j]] >> 1) << i for i, r in enumerate(reads))
+        A = run_body(main, A, {"i0": i0, "i1": i1, "o0": 0, "o1": 0, "_full": full})
+        Z = run_body(warm, Z, {"i0": i0, "i1": i1, "_full": full})
+    c = 0
+    for j in range(31):
+        d = (A[j] ^ Z[j]) & full
+        assert d in (0, full), (k, strand, j)
+        c |= (1 if d else 0) << j
+    return c
+
+
+def emit_fix(name, k, strand):
+    h = fix_constant(k, strand)
     lines = [f"__device__ __forceinline__ void {name}(uint32_t (&S)[31])", "{"]
-    lines += [f"\tS[{j}] = {'0xffffffffu' if (h >> j) & 1 else '0u'};" for j in range(31)]
+    lines += [f"\tS[{j}] = ~S[{j}];" for j in range(31) if (h >> j) & 1]
     return "\n".join(lines) + "\n}\n"
 
 
 def emit_dispatch(ks):
     out = []
     for fn, args, call in (("ts_main", "uint32_t (&S)[31], uint32_t i0, uint32_t i1, uint32_t o0, uint32_t o1", "S, i0, i1, o0, o1"),
-                           ("ts_init", "uint32_t (&S)[31]", "S")):
+                           ("ts_warm", "uint32_t (&S)[31], uint32_t i0, uint32_t i1", "S, i0, i1"),
+                           ("ts_fix", "uint32_t (&S)[31]", "S")):
         out.append(f"template <bool FWD, int K>\n__device__ __forceinline__ void {fn}({args})\n{{")
         for i, k in enumerate(ks):
             kw = "if" if i == 0 else "else if"
@@ -179,7 +215,8 @@ def generate(ks=KS):
         for strand in "FR":
             s, n2 = emit_strand_step(f"ts_main_{strand}_k{k}", k, strand, True)
             out.append(s)
-            out.append(emit_init(f"ts_init_{strand}_k{k}", k, strand))
+            out.append(emit_fix(f"ts_fix_{strand}_k{k}", k, strand))
+            out.append(emit_strand_step(f"ts_warm_{strand}_k{k}", k, strand, False)[0])  # (the reverse strand's incoming seed enters rotated by k)
             stats[f"{strand}{k}"] = n2
     out.append(emit_dispatch(ks))
     for sb in (2, 3, 4, 5, 6, 7, 8):
@@ -282,7 +319,6 @@ def selftest():
         for strand in "FR":
             h = poly_a_state(k, strand)
             S[strand] = [full if (h >> j) & 1 else 0 for j in range(31)]
-            assert emit_init("i", k, strand).count("0xffffffffu") == bin(h).count("1")
             body[strand] = emit_strand_step("m", k, strand, True)[0]
         for j in range(L):
             i0, i1 = planes2(j)
@@ -299,6 +335,36 @@ def selftest():
                     gf = sum(((S["F"][b] >> i) & 1) << b for b in range(31))
                     gr = sum(((S["R"][b] >> i) & 1) << b for b in range(31))
                     assert (gf, gr) == (fh, rh), ("poly-A start", k, j, i)
+    # ... and what the kernel really does: fill_blocks(k) blocks of the filling body from state 0, the fix-up constant, main body after
+    for k in KS:
+        nreads, L = 16, 60
+        reads = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(nreads)]
+        full = (1 << nreads) - 1
+        nf = 16 * fill_blocks(k)
+        for strand in "FR":
+            S = [0] * 31
+            warm = emit_strand_step("w", k, strand, False)[0]
+            main = emit_strand_step("m", k, strand, True)[0]
+            fixc = fix_constant(k, strand)
+            for j in range(L):
+                i0 = sum((CODE2[r[j]] & 1) << i for i, r in enumerate(reads))
+                i1 = sum((CODE2[r[j]] >> 1) << i for i, r in enumerate(reads))
+                if j < nf:
+                    S = run_body(warm, S, {"i0": i0, "i1": i1, "_full": full})
+                    if j == nf - 1:
+                        S = [x ^ (full if (fixc >> b) & 1 else 0) for b, x in enumerate(S)]
+                else:
+                    o0 = sum((CODE2[r[j - k]] & 1) << i for i, r in enumerate(reads)) if j >= k else 0
+                    o1 = sum((CODE2[r[j - k]] >> 1) << i for i, r in enumerate(reads)) if j >= k else 0
+                    S = run_body(main, S, {"i0": i0, "i1": i1, "o0": o0, "o1": o1, "_full": full})
+                if j >= k - 1:
+                    p = j - k + 1
+                    for i, r in enumerate(reads):
+                        want = 0
+                        for t in range(k):
+                            want ^= rol31(hseed(r[p + t]), k - 1 - t) if strand == "F" else rol31(hseed(COMP[r[p + t]]), t)
+                        got = sum(((S[b] >> i) & 1) << b for b in range(31))
+                        assert got == want, ("fill + fix + main", k, strand, j, i)
     for sb in (2, 3, 5, 7, 8, 11):
         src = emit_cand("c", min(sb, 8))[0]
         n = min(sb + 1, 8)

@@ -349,9 +349,9 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	ap.b1 = pb <= 8 ? pb : (pb + 1) / 2; // two passes: balanced fan-out (longer runs per digit coalesce better than 256-way + 32-way)
 	ap.b2 = pb - ap.b1;
 	ap.n_slices = (uint32_t)((counters + (1ull << ap.slice_bits) - 1) >> ap.slice_bits);
-	// default: two entries per counter (2^29 at rBits = 27 and one k: the apply's sweep over the whole sketch is then paid once per
-	// ~450 M sampled k-mers; 288 GB of HBM have room for the 2 GiB log and its two partition work areas)
-	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(1ull << 18, 2 * counters));
+	// default: four entries per counter, at most 2^30 (4 GiB at rBits = 27 and one k: the apply's sweep over the whole sketch is then
+	// paid once per ~900 M sampled k-mers; 288 GB of HBM have room for the log and its two partition work areas, 12 GiB in all)
+	uint64_t cap = want_entries ? want_entries : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(1ull << 18, 4 * counters));
 	cap = std::max<uint64_t>(cap, 1ull << 14);
 	e->log_region_cap = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, cap / 8192)); // <= 65535: one run fits a 16-bit count pass
 	e->log_regions = (uint32_t)std::max<uint64_t>(1, cap / e->log_region_cap);
@@ -790,6 +790,17 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 	if (n_tiles > 0xffffffffull / 64) return fail(NTC_ERR_ARG, "tiled batch of %llu reads is too large for one submit", (unsigned long long)n_reads);
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
+	if (e->d_log) {
+		// candidates of this batch (both samples ~2^-sBits of the windows each, every k) + what every logging wave may leave unused at the
+		// end of a region; a log that could overflow is applied first (outside the hash kernels' timing events)
+		double est = 0;
+		for (uint32_t k : e->klist)
+			if (read_len >= k) est += 64.0 * 4096 + (double)n_reads * (double)(read_len - k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+		if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
+			if (int rc = apply_log(e)) return rc;
+		e->log_est += est;
+		e->log_pending = true;
+	}
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (e->profiling) {
 		HIP_TRY(hipEventCreate(&ev0));
@@ -800,15 +811,6 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
 		if (read_len < k) continue; // no window of this k (ntHashIterator.hpp:61-64)
-		if (e->d_log) {
-			// candidates of this batch (both samples ~2^-sBits of the windows each) + what every logging wave may leave unused at the end of a region
-			const double per_read = (double)(read_len - k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
-			const double est = 64.0 * 4096 + (double)n_reads * per_read;
-			if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
-				if (int rc = apply_log(e)) return rc;
-			e->log_est += est;
-			e->log_pending = true;
-		}
 		ntc::TsArgs a;
 		std::memset(&a, 0, sizeof a);
 		a.tiles = d_tiles;

@@ -146,6 +146,17 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 }
 
 template <int SB>
+__device__ __forceinline__ uint32_t ts_cand(const uint32_t (&S)[31])
+{
+	if constexpr (SB == 2) return ts_cand_s2(S);
+	else if constexpr (SB == 3) return ts_cand_s3(S);
+	else if constexpr (SB == 4) return ts_cand_s4(S);
+	else if constexpr (SB == 5) return ts_cand_s5(S);
+	else if constexpr (SB == 6) return ts_cand_s6(S);
+	else if constexpr (SB == 7) return ts_cand_s7(S);
+	else return ts_cand_s8(S);
+}
+template <int SB>
 __device__ __forceinline__ void ts_xplanes(const uint32_t (&S)[31], uint32_t& eqA, uint32_t& geA, uint32_t& eqB)
 {
 	if constexpr (SB == 2) ts_xplanes_s2(S, eqA, geA, eqB);
@@ -790,11 +801,14 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			for (uint32_t t = team_g, seq = 0; t < a.n_tiles; t += n_teams, ++seq) {
 				meta_tile = (uint32_t)lane | (FWD ? 0u : 64u) | ((has_partial && t == a.n_tiles - 1u) ? 128u : 0u) | ((seq & 15u) << 27); // bits 27..30: which tile (suspects)
 				nb0 = (seq * C) % kRing;
-				// The walk starts from the hash of k 'A's and feeds 'A' (code 0: the zeroed history planes) as the outgoing base of the
-				// first k steps: what is left after step k - 1 is the hash of the first k real bases (gen_ts.py, poly_a_state), and
-				// every step of every block is the same generated body.
+				// The first k / 16 blocks of a tile only fill the window: state 0, the filling body (nothing goes out).  From then on every
+				// step is the main body, which for the rest of the first k steps sees 'A' (code 0: the zeroed history planes) go out — it
+				// runs on the track of a walk started from the hash of k 'A's (gen_ts.py, poly_a_state), and one XOR with a constant
+				// (ts_fix) moves the filling state onto that track.  After step k - 1 the state is the hash of the first k real bases.
 				uint32_t S[31];
-				ts_init<FWD, K>(S);
+#pragma unroll
+				for (int j = 0; j < 31; ++j)
+					S[j] = 0;
 				uint32_t H[2][32]; // the planes of the two chunks before the one being walked: the outgoing base is k <= 32 bases back
 #pragma unroll
 				for (int b = 0; b < 2; ++b)
@@ -818,6 +832,18 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					// step q of this block takes base 16 c + q in and base 16 c + q - k out (planes 2 o, 2 o + 1 of the history, o = q + 32 - k)
 					// and completes window 16 c + q - (k - 1) (none while that is negative: the unsigned value fails push()'s w < W)
 					const uint32_t w0 = 16u * c - (uint32_t)K + 1u;
+					if ((int32_t)(16u * c) + 15 <= K - 1) {
+						// a block of nothing but window filling (the first k / 16 blocks of a tile): no outgoing base, no exchange, no queue;
+						// when its last step completes window 0 (k = 16, 32) that window's candidates come from this strand's own patterns —
+						// a superset the resolver narrows to the canonical strand like every other candidate
+#pragma unroll
+						for (int q = 0; q < 16; ++q) {
+							ts_warm<FWD, K>(S, I[2 * q], I[2 * q + 1]);
+							pin31(S);
+						}
+						if (c + 1u == (uint32_t)(K / 16)) ts_fix<FWD, K>(S); // the last filling block: onto the main body's track
+						if ((int32_t)(16u * c) + 15 == K - 1) push(ts_cand<SB>(S), 0u);
+					} else
 #pragma unroll
 					for (int hb = 0; hb < 2; ++hb) {
 						// Candidates with the other strand's help: a window is sampled through THIS strand iff its top bits carry a pattern and
