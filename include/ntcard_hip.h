@@ -55,8 +55,8 @@ typedef struct {
                                   (lets a host framework own/merge the buffer, e.g. RCCL reduce) */
     void *ext_f1;              /* optional caller-owned DEVICE uint64_t [n_k]; NULL -> engine    */
     uint32_t flags;            /* NTC_FLAG_*                                                      */
-    uint64_t log_entries;      /* capacity of the hit log in 4-byte entries, 0 = default (two per
-                                  counter: 2^29 at rBits = 27 and one k; at most 2^30).  ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is
+    uint64_t log_entries;      /* capacity of the hit log in 4-byte entries, 0 = default (four per
+                                  counter, at most 2^30: 4 GiB at rBits = 27 and one k).  ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is
                                   deferred: the kernels log the counter index of every sampled k-mer
                                   and the log is applied to the sketch when it fills up and whenever
                                   the counters are needed (ntc_finish, ntc_flush, ...)              */

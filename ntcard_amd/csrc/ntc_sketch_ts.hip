@@ -11,8 +11,9 @@
 // live in the 31-bit rotating half of the hash (nthash.hpp:186-217).  That half is walked BIT-SLICED — one VGPR
 // holds one bit of it for 32 reads, a wave carries a tile of 2048 reads, a rotate is a renaming of registers —
 // and the ~2^(1-sBits) candidate windows are re-derived exactly (full 64-bit fh and rh, canonical min, ntComp's
-// patterns, counter index) from the packed bases by a resolve stage.  The walk of a read starts from the hash of k
-// 'A's with 'A' going out for the first k steps, so one generated step body per (k, strand) serves every step.
+// patterns, counter index) from the packed bases by a resolve stage.  The first k / 16 blocks of a read run a filling body
+// (nothing goes out), one XOR with a generated constant then puts the state on the track of a walk that started from the hash
+// of k 'A's, and every later step is the one main body per (k, strand).
 //
 // Data layout: tile t = reads [2048 t, 2048 t + 2048); chunk c = bases [16 c, 16 c + 16) of every read of the tile;
 // the 16 raw bytes of (t, c, read r) sit at ((t C + c) 2048 + r) 16.  A chunk of a tile is 32 KiB of contiguous HBM
