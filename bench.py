@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--layout", choices=["auto", "rows", "tiled"], default="auto",
                     help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1b + K1), tiled = the tiled layout "
                          "(ntc_submit_tiled_device: K1c, the streaming kernel with in-kernel N handling); auto = tiled where K1c is built "
-                         "for the configuration (every k of the list within 16..32, no gap, sBits >= 7), rows otherwise (a tiled batch would only be re-laid out)")
+                         "for the configuration (every k of the list within 12..32, no gap, sBits >= 7), rows otherwise (a tiled batch would only be re-laid out)")
     ap.add_argument("--log-entries", type=int, default=0, help="capacity of the hit log in entries (0 = the engine's default: one per counter)")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
@@ -233,7 +233,7 @@ def main():
         args.k, args.gap = 12, 2
     if args.layout == "auto":
         kl = klist_of(args)
-        args.layout = "tiled" if (all(16 <= k <= 32 for k in kl) and args.gap == 0 and args.s_bits >= 7 and not args.lane_kernel and not args.bitslice) else "rows"
+        args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and args.gap == 0 and args.s_bits >= 7 and not args.lane_kernel and not args.bitslice) else "rows"
     import torch
     import torch.distributed as dist
     import ntcard_amd as nt

@@ -125,7 +125,7 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
  * letter ('A'); the slots behind the batch's last read (the rest of the last tile) are ignored whatever they hold, so any
  * prefix of a tiled buffer is a valid batch.  All reads of a batch have the same length.  Asynchronous on the engine's
  * stream; the buffer may be reused as soon as the stream has passed the call (nothing refers to it afterwards).  A list of k is
- * served by one launch per k.  Configurations the tiled kernel is not built for (a k outside 16 .. 32, spaced seeds, nthll,
+ * served by one launch per k.  Configurations the tiled kernel is not built for (a k outside 12 .. 32, spaced seeds, nthll,
  * sBits < 7) are re-laid out on the device and take the general kernel: same results, not the fast path.  Host batches
  * (ntc_submit, ntc_submit_spans) use row slots.                                                                          */
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);

@@ -140,7 +140,7 @@ def emit_xplanes(name, s_bits):
     return head + "\n" + "\n".join(e.lines) + f"\n\teqA = {eqa};\n\tgeA = {gea};\n\teqB = {b};\n}}\n", len(e.lines)
 
 
-KS = tuple(range(16, 33))  # the k the tiled streaming kernel is instantiated for (a window of k <= 32 bases spans at most 3 chunks)
+KS = tuple(range(12, 33))  # the k the tiled streaming kernel is instantiated for (a window of k <= 32 bases spans at most 3 chunks)
 
 
 def poly_a_state(k, strand):
@@ -346,6 +346,8 @@ def selftest():
             warm = emit_strand_step("w", k, strand, False)[0]
             main = emit_strand_step("m", k, strand, True)[0]
             fixc = fix_constant(k, strand)
+            if nf == 0:  # k < 16: no filling block, the constant (= the hash of k 'A's) goes in before the first step
+                S = [x ^ (full if (fixc >> b) & 1 else 0) for b, x in enumerate(S)]
             for j in range(L):
                 i0 = sum((CODE2[r[j]] & 1) << i for i, r in enumerate(reads))
                 i1 = sum((CODE2[r[j]] >> 1) << i for i, r in enumerate(reads))

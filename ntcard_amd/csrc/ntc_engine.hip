@@ -940,7 +940,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	// takes (ragged, short or long slots, small) keep the adaptive choice
 	const bool bs_wanted = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) || (!(cfg->flags & (NTC_FLAG_LANE_KERNEL | NTC_FLAG_DIRECT_ATOMICS)) && e->d_log != nullptr);
 	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
-	// K1c (tiled streaming kernel): every k of the list must have an instantiation (k = 16 .. 32); a list is served by one launch
+	// K1c (tiled streaming kernel): every k of the list must have an instantiation (k = 12 .. 32); a list is served by one launch
 	// per k over the same resident tiles.  Its hit-log keys and its direct-atomics fallback are 32-bit counter indices.
 	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->gap == 0 && e->hll_bits == 0 &&
 	           e->klist.size() * e->plane_elems() <= (1ull << 32);

@@ -1,7 +1,7 @@
 // ntc_sketch_ts.hip — K1c "tiled streaming" kernel: ntHash -> sample -> count for equal-length batches in the TILED
 // slot layout (include/ntcard_hip.h, ntc_submit_tiled_device) on gfx950.
 //
-// What it computes is ntRead + ntComp (ntcard.cpp:132-158) for one k of 16 .. 32: for every window of k consecutive
+// What it computes is ntRead + ntComp (ntcard.cpp:132-158) for one k of 12 .. 32: for every window of k consecutive
 // ACGTU bases the canonical ntHash (nthash.hpp:242-257,275-279), the two sampling patterns on its top bits, and one
 // increment of t_Counter[sample][hash & (rBuck - 1)] per sampled window (as a hit-log entry, ntc_apply.hip), plus F1 =
 // the number of such windows.  ntHashIterator's N semantics (ntHashIterator.hpp:59-86: a window that contains a
@@ -604,7 +604,7 @@ struct TsResolver {
 template <int K, int SB>
 __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 {
-	static_assert(K >= 16 && K <= 32, "K1c: a window spans at most 3 chunks and leaves at most 2 chunks behind the one being walked (gen_ts.py emits k = 16 .. 32)");
+	static_assert(K >= 12 && K <= 32, "K1c: a window spans at most 3 chunks and leaves at most 2 chunks behind the one being walked (gen_ts.py emits k = 12 .. 32)");
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const uint32_t wave = rfl((uint32_t)tid >> 6);
@@ -810,6 +810,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll
 				for (int j = 0; j < 31; ++j)
 					S[j] = 0;
+				if constexpr (K / 16 == 0) ts_fix<FWD, K>(S); // k < 16: no filling block, the main body runs from the first step
 				uint32_t H[2][32]; // the planes of the two chunks before the one being walked: the outgoing base is k <= 32 bases back
 #pragma unroll
 				for (int b = 0; b < 2; ++b)
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll
 						for (int q8 = 0; q8 < 8; ++q8) {
 							const int q = hb * 8 + q8, o = q + 32 - K;
-							ts_main<FWD, K>(S, I[2 * q], I[2 * q + 1], o < 16 ? H[0][2 * (o & 15)] : H[1][2 * (o & 15)], o < 16 ? H[0][2 * (o & 15) + 1] : H[1][2 * (o & 15) + 1]);
+							ts_main<FWD, K>(S, I[2 * q], I[2 * q + 1], o < 16 ? H[0][2 * (o & 15)] : o < 32 ? H[1][2 * (o & 15)] : I[2 * (o & 15)], o < 16 ? H[0][2 * (o & 15) + 1] : o < 32 ? H[1][2 * (o & 15) + 1] : I[2 * (o & 15) + 1]); // (k < 16: the outgoing base may lie in this chunk)
 							pin31(S);
 							uint32_t ge;
 							ts_xplanes<SB>(S, eqA[q8], ge, eqB[q8]);
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 }
 
 // ---- instantiations -------------------------------------------------------------------------------------------
-// One kernel per (k, sBits class); the object files ntc_sketch_ts_p{0..3}.o each carry the k with (k - 16) % 4 == part
+// One kernel per (k, sBits class); the object files ntc_sketch_ts_p{0..3}.o each carry the k with k % 4 == part
 // (Makefile: -DTS_PART=n, built in parallel); -DTS_ONLY_K=k (tools/dbg) builds a single k.
 #ifndef TS_PART
 #define TS_PART 0
@@ -985,9 +986,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #elif defined(TS_ALL_PARTS)
 #define TS_MINE(k) true
 #else
-#define TS_MINE(k) ((((k) - 16) & 3) == TS_PART)
+#define TS_MINE(k) (((k) & 3) == TS_PART)
 #endif
-#define TS_FOR_K(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#define TS_FOR_K(X) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 namespace {
 template <int K, int SB>
@@ -1050,7 +1051,7 @@ hipError_t sketch_ts_limit_part2(size_t);
 hipError_t sketch_ts_limit_part3(size_t);
 #endif
 
-bool sketch_ts_supports(uint32_t k, uint32_t s_bits) { return k >= 16 && k <= 32 && s_bits >= 7; }
+bool sketch_ts_supports(uint32_t k, uint32_t s_bits) { return k >= 12 && k <= 32 && s_bits >= 7; }
 
 size_t sketch_ts_smem(uint32_t k) { return (size_t)((k + 3) / 4) * 4096 + 2 * (size_t)kTeamBytes; }
 

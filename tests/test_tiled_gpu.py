@@ -104,9 +104,9 @@ def test_tiled_batches_and_modes(nt):
     check(nt, reads, 150, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, pieces=2)
 
 
-@pytest.mark.parametrize("k", list(range(16, 32)))
+@pytest.mark.parametrize("k", list(range(12, 32)))
 def test_tiled_kernel_every_k(nt, k):
-    """K1c is instantiated for k = 16 .. 32 (one generated step body per k, the walk starts from the hash of k 'A's): reads of
+    """K1c is instantiated for k = 12 .. 32 (generated step bodies per k): reads of
     exactly k and k + 1 bases, 97 and 150 bp, non-ACGTU bytes, sBits 7 / 8 / 11"""
     rng = np.random.default_rng(k)
     alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
@@ -122,7 +122,7 @@ def test_tiled_kernel_random_shapes(nt, seed):
     """random read length (32 .. 400), read count (partial last tile, one read, several tiles per team), sBits and rate of
     non-ACGTU bytes: K1c's chunk / ring / window arithmetic has no special case for 150 bp"""
     rng = np.random.default_rng(1000 + seed)
-    k = int(rng.integers(16, 33))
+    k = int(rng.integers(12, 33))
     L = int(rng.integers(k, 401))
     n = int(rng.choice([1, 63, 2047, 2048, 2049, 5000, 9000]))
     s_bits = int(rng.choice([7, 8, 9, 12]))
@@ -137,7 +137,7 @@ def test_tiled_kernel_random_shapes(nt, seed):
 def test_tiled_kernel_k_lists(nt):
     """a list of k within 16 .. 32 is one K1c launch per k over the same tiles (ntRead's loop over kList, ntcard.cpp:147-158): planes and
     F1 per k as the oracle's; reads shorter than some of the k"""
-    for klist, L, n in (([21, 25, 31], 150, 5000), ([32, 16, 24], 100, 2100), ([17, 29], 20, 3000), ([20, 32], 19, 100)):
+    for klist, L, n in (([21, 25, 31], 150, 5000), ([32, 16, 24], 100, 2100), ([17, 29], 20, 3000), ([20, 32], 19, 100), ([12, 15, 13], 14, 2500)):
         reads = gen_host(n, L, 1)
         t = torch.from_numpy(nt.tile_reads(reads, L)).cuda()
         with nt.Engine(klist, r_bits=16, s_bits=7, flags=nt.FLAG_REQUIRE_TILED) as e:
@@ -152,7 +152,7 @@ def test_tiled_layout_falls_back_for_other_configurations(nt):
     """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
     reads = gen_host(5000, 150, 1)
     t = torch.from_numpy(nt.tile_reads(reads, 150)).cuda()
-    for klist, gap, s_bits in (([40], 0, 7), ([15], 0, 7), ([32, 64], 0, 7), ([12], 2, 7), ([32], 0, 5)):
+    for klist, gap, s_bits in (([40], 0, 7), ([11], 0, 7), ([32, 64], 0, 7), ([12], 2, 7), ([32], 0, 5)):
         with nt.Engine(klist, gap=gap, r_bits=16, s_bits=s_bits) as e:
             e.submit_tiled_device(t.data_ptr(), len(reads), 150)
             tc, ph, f1 = e.finish(counters=True)

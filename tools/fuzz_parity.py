@@ -30,7 +30,7 @@ for case in range(n_cases):
         if gap >= k or gap % 2 != k % 2: gap = 0
         klist = [k]
     else:
-        klist = sorted(set(rng.choice([rng.randint(1, 40), rng.randint(16, 32), rng.randint(1, 200), rng.choice([12, 16, 31, 32, 33, 64, 96, 128])]) for _ in range(rng.choice([1, 1, 2, 4, 6]))))
+        klist = sorted(set(rng.choice([rng.randint(1, 40), rng.randint(12, 32), rng.randint(1, 200), rng.choice([12, 16, 31, 32, 33, 64, 96, 128])]) for _ in range(rng.choice([1, 1, 2, 4, 6]))))
     s_bits, r_bits = rng.choice([2, 3, 5, 7, 7, 8, 11]), rng.choice([12, 16, 18])
     mode = rng.choice(["equal", "equal", "two", "ragged", "long"])
     L = rng.choice([rng.randint(1, 300), 100, 150, 151, 250])
@@ -53,9 +53,9 @@ for case in range(n_cases):
     oc, of1 = orc.sketch_reads(reads, klist, gap, r_bits, s_bits)
     ok = np.array_equal(f1, of1) and np.array_equal(tc, oc)
     if ok and mode == "equal" and L >= 1 and gap == 0:
-        # the same reads in the tiled layout: the streaming kernel K1c where it is built (every k of the list in 16 .. 32, sBits >= 7:
+        # the same reads in the tiled layout: the streaming kernel K1c where it is built (every k of the list in 12 .. 32, sBits >= 7:
         # then a fallback would be an error), the device-side re-layout + K1 otherwise; batches cut at the same places
-        k1c = all(16 <= k <= 32 for k in klist) and s_bits >= 7 and (len(klist) << (r_bits + 1)) <= (1 << 32)
+        k1c = all(12 <= k <= 32 for k in klist) and s_bits >= 7 and (len(klist) << (r_bits + 1)) <= (1 << 32)
         with nt.Engine(klist, gap=gap, r_bits=r_bits, s_bits=s_bits, flags=flags | (nt.FLAG_REQUIRE_TILED if k1c else 0), log_entries=log_entries) as e:
             prev, keep = 0, []
             for c in cuts + [len(reads)]:

@@ -55,7 +55,7 @@ reads = gen_host(n, L, 1)
 ok = np.array_equal(t.cpu().numpy(), nt.tile_reads(reads, L))
 print("ok  " if ok else "FAIL", "tiled generator == oracle generator")
 allok &= ok
-for k in (16, 17, 20, 21, 24, 25, 27, 29, 31):
+for k in (12, 13, 15, 16, 17, 20, 21, 24, 25, 27, 29, 31):
     for (n, L, dist, s) in ((5000, 150, 1, 7), (3000, k, 0, 7), (2500, k + 1, 1, 8), (2100, 97, 1, 11)):
         allok &= check_reads(gen_host(n, L, dist), L, k=k, s_bits=s, tag=f"k={k} dist={dist}")
 for (n, L, dist, s) in [(5000, 150, 1, 7), (2048, 150, 0, 7), (4096, 100, 1, 7), (100, 159, 1, 7), (3000, 33, 1, 7), (3000, 32, 0, 7), (6000, 150, 1, 8), (6000, 150, 1, 11),
