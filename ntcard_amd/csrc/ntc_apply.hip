@@ -176,7 +176,15 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap + off;
 				for (uint32_t i = tid; i < take; i += nt) {
 					const uint32_t kk = src[i] & cmask;
-					atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
+					// hot counters (a few thousand distinct k-mers sampled at huge coverage: every key of a run is the same) would put all 64
+					// lanes on one LDS word, 64 serialised atomics per instruction: a wave whose keys are all equal adds their number once
+					const uint64_t act = __ballot(true);
+					const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kk);
+					if (__ballot(kk == first) == act) {
+						if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&cnt[kk >> 1], (uint32_t)__popcll(act) << ((kk & 1u) * 16u));
+					} else {
+						atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
+					}
 				}
 				taken += take;
 				off += take;
