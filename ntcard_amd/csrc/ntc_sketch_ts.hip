@@ -734,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					while ((int32_t)(dq_tail + cnt - lds_peek(ctl + C_DQ_HEAD) - kDCap) > 0)
 						__builtin_amdgcn_s_sleep(1);
 					if (dirtyword != 0u)
-						reinterpret_cast<uint2*>(tb + kOffDQ)[(dq_tail + mbcnt(dm)) & (kDCap - 1u)] = make_uint2(dirtyword, (uint32_t)lane | ((seq & 1u) << 6) | (c << 7));
+						reinterpret_cast<uint2*>(tb + kOffDQ)[(dq_tail + mbcnt(dm)) & (kDCap - 1u)] = make_uint2(dirtyword, (uint32_t)lane | ((seq & 15u) << 6) | (c << 10));
 					dq_tail += cnt;
 					lds_publish(ctl + C_DQ_TAIL, dq_tail);
 				}
@@ -907,8 +907,9 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		uint64_t f1_add = 0;  // wave-uniform: reads x windows
 		uint32_t f1_sub = 0;  // per lane: windows lost to non-ACGTU bytes
 		const uint32_t n_valid_last = rs.n_valid_last;
-		// ---- dirty pieces: F1 loses the windows whose RIGHTMOST non-ACGTU byte lies in the piece.  The packer is at most one tile
-		// ahead of this wave, so one bit of the tile sequence number identifies an item's tile ----
+		// ---- dirty pieces: F1 loses the windows whose RIGHTMOST non-ACGTU byte lies in the piece.  The packer is gated on BLOCKS (it may be
+		// three blocks ahead of the resolvers), and with reads of one chunk a block is a tile: items carry four bits of the tile sequence
+		// number (round 3 carried one: F1 came out too high for reads of <= 16 bp on teams that walk three tiles or more) ----
 		auto drain_dirty = [&](uint32_t t_cur, uint32_t seq_cur) {
 			const uint32_t tail = lds_peek(ctl + C_DQ_TAIL);
 			while (dq_head != tail) {
@@ -916,8 +917,8 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				uint2 it = make_uint2(0u, 0u);
 				if ((uint32_t)lane < cnt) it = dq[(dq_head + (uint32_t)lane) & (kDCap - 1u)];
 				uint32_t word = it.x;
-				const uint32_t l0 = it.y & 63u, c = it.y >> 7;
-				const uint32_t t = ((it.y >> 6) & 1u) == (seq_cur & 1u) ? t_cur : t_cur + n_teams;
+				const uint32_t l0 = it.y & 63u, c = it.y >> 10;
+				const uint32_t t = t_cur + ((((it.y >> 6) & 15u) - seq_cur) & 15u) * n_teams; // the item's tile: this one or one of the next few
 				while (word != 0u) {
 					const uint32_t r = (uint32_t)__builtin_ctz(word) * 64u + l0;
 					word &= word - 1u;
@@ -926,13 +927,23 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					if (c + 1u < C) B = inv16(rs.raw_piece(t, c + 1u, r));
 					if (c + 2u < C) B |= inv16(rs.raw_piece(t, c + 2u, r)) << 16;
 					if (A != 0u) {
-						// window w = 16 c - (k - 1) + j ends at base 16 c + j: it holds a byte of A iff lo <= j <= hi + k - 1, and no later
-						// non-ACGTU byte iff j <= 15 + ctz(B) (k <= 32 + 1: B covers the 32 bases behind the piece); 0 <= w < W
-						const int lo = __builtin_ctz(A), hi = 31 - __builtin_clz(A);
+						// window w = 16 c - (k - 1) + j ends at base 16 c + j: it holds a byte of A iff some bit of A lies in [j - k + 1, j] (bit j
+						// of A smeared over k positions: with k < 16 a window fits BETWEEN two non-ACGTU bytes of one piece, so lo .. hi + k - 1
+						// is not the answer), and no later non-ACGTU byte iff j <= 15 + ctz(B) (k <= 32 + 1: B covers the 32 bases behind the
+						// piece); 0 <= w < W
+						uint64_t E = A;
+						int cov = 1;
+#pragma unroll
+						for (int i = 0; i < 5; ++i)
+							if (cov * 2 <= K) {
+								E |= E << cov;
+								cov *= 2;
+							}
+						if (cov < K) E |= E << (K - cov);
 						const int tzb = B ? __builtin_ctz(B) : 32;
-						const int jmin = max(lo, (int)K - 1 - 16 * (int)c);
-						const int jmax = min(min(hi + (int)K - 1, 15 + tzb), (int)W + (int)K - 2 - 16 * (int)c);
-						if (jmax >= jmin) f1_sub += (uint32_t)(jmax - jmin + 1);
+						const int jmin = max(0, (int)K - 1 - 16 * (int)c);
+						const int jmax = min(min(46, 15 + tzb), (int)W + (int)K - 2 - 16 * (int)c);
+						if (jmax >= jmin) f1_sub += (uint32_t)__popcll((E >> jmin) & ((2ull << (jmax - jmin)) - 1ull));
 					}
 				}
 				dq_head += cnt;

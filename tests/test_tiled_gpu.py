@@ -148,6 +148,36 @@ def test_tiled_kernel_k_lists(nt):
         assert np.array_equal(f1, of1) and np.array_equal(tc, oc), klist
 
 
+def tile_array(arr):
+    """(n, L) uint8 array of reads -> tiled layout (numpy only: millions of reads)"""
+    n, L = arr.shape
+    C16, ntl = (L + 15) // 16, (n + 2047) // 2048
+    a = np.full((ntl * 2048, C16 * 16), ord("A"), dtype=np.uint8)
+    a[:n, :L] = arr
+    return np.ascontiguousarray(a.reshape(ntl, 2048, C16, 16).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+@pytest.mark.parametrize("L,k", [(12, 12), (14, 12), (16, 16), (16, 12), (20, 16), (33, 16), (47, 12), (32, 32), (40, 25)])
+def test_tiled_many_tiles_per_team_short_reads(nt, L, k):
+    """3.2 M reads of 1 .. 3 chunks with 1.5 % non-ACGTU bytes: every team of waves walks >= 3 tiles whose blocks are (nearly) whole
+    tiles, so the packer runs several TILES ahead of the resolvers — the dirty-piece queue's tile tags, the suspects' tile tags
+    and the ring-slot phase (seq * C) % 5 all wrap within one launch.  F1 and every counter vs the oracle."""
+    n = 3_200_000
+    rng = np.random.default_rng(L * 100 + k)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    arr = np.where(rng.random((n, L)) < 0.015, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    t = torch.from_numpy(tile_array(arr)).cuda()
+    with nt.Engine([k], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED) as e:
+        e.submit_tiled_device(t.data_ptr(), n, L)
+        tc, ph, f1 = e.finish(counters=True)
+    counters = np.zeros((1, 2, 1 << 20), dtype=np.uint16)
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    of1 = orc.sketch_update(counters, np.ascontiguousarray(arr).reshape(-1), offs, [k], 0, 20, 7)
+    assert np.array_equal(f1, of1), (f1, of1)
+    assert np.array_equal(tc, counters)
+
+
 def test_tiled_layout_falls_back_for_other_configurations(nt):
     """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
     reads = gen_host(5000, 150, 1)
