@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
     ap.add_argument("--bitslice", action="store_true", help="A/B: the bit-sliced kernel K1b even for small batches (it is the default for k = 32 batches of >= 128 tiles)")
     ap.add_argument("--lane-kernel", action="store_true", help="A/B: never use K1b, the lane-per-read kernel K1 takes every batch")
+    ap.add_argument("--k1h-timers", action="store_true", help="print the section clocks a K1H_EXP=timers build of K1h left behind F1 (stderr)")
+    ap.add_argument("--teams", action="store_true", help="A/B: tiled batches through K1c (teams of four waves, round 3) instead of K1h (one wave per tile)")
     ap.add_argument("--layout", choices=["auto", "rows", "tiled"], default="auto",
                     help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1b + K1), tiled = the tiled layout "
                          "(ntc_submit_tiled_device: K1c, the streaming kernel with in-kernel N handling); auto = tiled where K1c is built "
@@ -293,13 +295,14 @@ def main():
 
     # the sketch is a torch tensor so that torch.distributed (RCCL) can reduce it in place
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
-    f1_dev = torch.zeros(nk, dtype=torch.int64, device=dev)
+    f1_big = torch.zeros(nk + 8, dtype=torch.int64, device=dev)  # (a K1h timing build adds its section clocks behind F1: tools/k1h_variant.sh)
+    f1_dev = f1_big[:nk]
     # the resident batches stay untouched until the end of the run: the engine may share one pass over the reads K1b hands back
     # between batches (NTC_FLAG_DEFER_REDO); the tiled path needs no such promise
     eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream, ext_sketch=sketch, ext_f1=f1_dev,
                     log_entries=args.log_entries,
                     flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
-                    | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0)
+                    | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0) | (nt.FLAG_TILED_TEAMS if args.teams else 0)
                     | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0)
                     | (0 if tiled else nt.FLAG_DEFER_REDO))
 
@@ -355,6 +358,11 @@ def main():
     else:
         _, ph, f1 = eng.finish(counters=False, p_hist=True)
     total_kmers = int(sum(int(x) for x in f1))  # after the reduce rank 0 holds the sum over ranks (and over the k list)
+    if args.k1h_timers:
+        tm = [int(x) for x in f1_big.cpu().numpy()[nk:nk + 4]]
+        tot = max(sum(tm), 1)
+        print("k1h timers (clk summed over waves and launches): walk+test+push %d (%.1f%%), pack %d (%.1f%%), passes %d (%.1f%%), block end %d (%.1f%%)"
+              % (tm[0], 100 * tm[0] / tot, tm[1], 100 * tm[1] / tot, tm[2], 100 * tm[2] / tot, tm[3], 100 * tm[3] / tot), file=sys.stderr)
 
     if rank == 0:
         import numpy as np

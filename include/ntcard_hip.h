@@ -77,6 +77,8 @@ typedef struct {
                                       somewhere, the batch tail) are then hashed in ONE pass shared by several batches instead of one per
                                       batch.  Without the flag a buffer may be reused as soon as the stream has passed the submit call. */
 #define NTC_FLAG_REQUIRE_TILED 64u  /* validation: ntc_submit_tiled_device fails instead of re-laying a batch out for the general kernel */
+#define NTC_FLAG_TILED_TEAMS 256u   /* tiled batches: use K1c (teams of four specialised waves, round 3) instead of K1h (one wave per tile,
+                                     * round 4) where both are built for the configuration (cross-check, A/B runs) */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 

@@ -1,0 +1,937 @@
+#!/usr/bin/env python3
+"""gen_k1h.py — emits the K1h kernel body (ntc_sketch_k1h.hip): ONE wave per 2048-read tile does everything.
+
+What it computes is ntRead + ntComp (ntcard.cpp:132-158) for one k of 12 .. 32 over a batch in the TILED slot layout
+(include/ntcard_hip.h, ntc_submit_tiled_device): canonical ntHash of every window of k ACGTU bases (nthash.hpp:242-257,275-279),
+ntComp's two sampling patterns on its top bits, one hit-log entry (= deferred ++t_Counter[...]) per sampled window, F1.
+
+Why a second tiled kernel (round 4): K1c (ntc_sketch_ts.hip) splits a tile over four specialised waves; 36 % of its wave-cycles are
+hand-shake waits and every role is a lone wave on its SIMD (one instruction per ~5 clk).  K1h removes the hand-shakes: a wave owns
+a tile, streams it chunk by chunk (16 bases x 2048 reads), and nothing it does waits for another wave.  The price is a live set the
+compiler cannot hold (62 state planes + 96 base planes + 32 registers of loads in flight), hence this generator: explicit physical
+registers, the kernel body as one assembly string, and an emulator (k1h_asm.py) that runs the very same instruction list on the CPU.
+
+Per chunk iteration (flat over the wave's tiles; block n of a tile = the 16 window ENDS e in [16 n - 16 + phi, 16 n + phi), phi =
+(k - 1) mod 16, so that the 16 windows of a block all START in one chunk: the resolve pass then reads wave-uniform ring slots):
+  * 16 walk steps, both strands bit-sliced (gen_bs.py: one VGPR = one bit of the 31-bit hash half for 32 reads).  Per step: function
+    planes of the incoming / outgoing base, 62 in-place state updates, then — only for steps that complete a window — the sample
+    test.  With both strands in one wave the test is EXACT per strand: cf = this window is sampled and the forward strand is
+    canonical, cr = ... reverse; cf & cr = the top bits tie (settled by K1f from the bytes).  Candidates go to an LDS queue as
+    (32-read hit word, lane | strand | window offset).
+  * interleaved with the walk: the NEXT chunk's raw bytes (8 x buffer_load_dwordx4 in flight) are packed to 2 bits per base into the
+    registers of planes that have just left the window, validity (non-ACGTU bytes) per 16-byte piece -> one dirty bit per read.
+  * resolve passes (subroutine, whenever the queue holds 64 items, and to empty it at the end of a block): lowest set bit of each
+    item -> the read's packed words of three ring slots -> 64-bit window code -> 3 bases per look-up in a 32-bit closed-form table
+    of the candidate's own strand (the canonical one): low rBits bits of the hash + the bit that tells the two samples apart ->
+    counter index -> hit log (coalesced) or, without a log, the literal device atomic (ntcard.cpp:142-143).
+  * end of block: packed words -> LDS ring, 32 x 32 bit transpose in place, register rotation by v_swap.
+Reads with non-ACGTU bytes and top-bit ties are NOT resolved here: every candidate of a block whose three chunks hold a dirty piece
+of that read is dropped, the dirty bits and the tie bits go to two arrays at fixed positions, and K1f (ntc_sketch_k1h.hip,
+fixup_kernel) recomputes exactly those (read, block) pairs from the raw bytes with ntHashIterator's semantics
+(ntHashIterator.hpp:59-86).  F1 here counts every window; K1f takes the invalid ones back.
+
+Nothing is copied from the reference: the four seeds are its constants (nthash.hpp:25-28), everything else is derived (gen_bs.py).
+"""
+import os
+import sys
+
+from gen_bs import step_terms, ttbl, g_of, hseed, rol31, COMP, CODE2  # noqa: F401
+from k1h_asm import Prog, v, s, vr, sr, schedule
+
+WAVES = 6                    # waves per workgroup = tiles in flight per CU
+RING_BYTES = 3 * 8192        # three packed chunks
+QCAP = 128                   # queue items (8 bytes)
+WAREA = RING_BYTES + QCAP * 8  # 25600 = 25 KiB per wave, 1 KiB aligned
+TABLE_OFF = WAVES * WAREA    # 153600: [2 strands][NG][64] dwords
+LDS_BYTES = 160 * 1024
+
+
+def n_groups(k):
+    return (k + 2) // 3
+
+
+def table_bytes(k):
+    return 2 * n_groups(k) * 256
+
+
+# ---- register map ------------------------------------------------------------------------------------------
+# VGPRs
+V_LANE4, V_LANE16, V_LANE8, V_QBASE, V_SPARE0, V_ONE, V_EXP1, V_VMASK = range(0, 8)
+V_D0, V_D1, V_D2, V_DN, V_CMASK, V_TACC, V_CARRY0, V_CARRY1, V_SPARE1 = range(8, 17)
+V_F = 18           # F[31]   (register tuples — loads, 64-bit LDS items — must start at even registers on gfx90a+)
+V_R = 49           # R[31]
+V_H0 = 80          # chunk n-2 planes / P_next
+V_H1 = 112
+V_I = 144
+V_RAW = 176        # 8 slots x 4
+V_T = 208          # temps 208 .. 252
+V_PX = V_T         # forward candidate item (x, y)
+V_RX = V_T + 2     # reverse candidate item
+V_T0 = V_T + 4     # scratch: V_T0 .. V_T0 + 29 (walk, pack, pass); the transpose uses V_T .. V_T + 31
+# constants that VOP3 instructions cannot take as literals (gfx9: one SGPR or inline constant per instruction, no 32-bit literal)
+V_CMUL, V_CPERMLO, V_CPERMHI, V_CP16A, V_CP16B, V_CP8A, V_CP8B, V_CM4, V_CM2, V_CM1, V_CQMASK8 = [V_T0 + 30 + i for i in range(11)]
+assert V_CQMASK8 <= 254
+VCONST = ((V_CMUL, 0x00820820), (V_CPERMLO, 0x0c0c0703), (V_CPERMHI, 0x07030c0c), (V_CP16A, 0x05040100), (V_CP16B, 0x07060302),
+          (V_CP8A, 0x06020400), (V_CP8B, 0x07030501), (V_CM4, 0x0f0f0f0f), (V_CM2, 0x33333333), (V_CM1, 0x55555555), (V_CQMASK8, (QCAP - 1) * 8))
+N_VGPRS = 255
+
+# SGPRs: s0 .. S_BASE - 1 are left to the compiler (the asm statement's few inputs live there)
+S_BASE = 34
+_sn = [S_BASE]
+
+
+def _salloc(n=1, align=1):
+    while _sn[0] % align:
+        _sn[0] += 1
+    r = _sn[0]
+    _sn[0] += n
+    return r
+
+
+S_EXP0 = _salloc()
+S_CHUNKB = _salloc()         # bytes of one tile's slots = C * 32768 (the product with the tile index is 64-bit)
+S_DESC = _salloc(4, 4)       # tile being loaded
+S_TILES = _salloc(2, 2)
+S_LOG = _salloc(2, 2)
+S_LOGFILL = _salloc(2, 2)
+S_SK = _salloc(2, 2)
+S_F1P = _salloc(2, 2)
+S_DIRTY = _salloc(2, 2)
+S_TIE = _salloc(2, 2)
+S_LOGBASE = _salloc(2, 2)    # current log region
+S_RET = _salloc(2, 2)
+S_F1ACC = _salloc(2, 2)
+S_TMP = _salloc(2, 2)        # 64-bit scratch
+S_KARG = _salloc(2, 2)
+S_F0, S_S0 = S_KARG, S_KARG + 1   # (the kernel-argument pointer is dead once the arguments are loaded) first block this wave owns / walks
+S_NTILES, S_C, S_L, S_NVLAST, S_KEYBASE, S_RMASK2, S_LOGREG, S_LOGCAP4 = [_salloc() for _ in range(8)]  # (loaded in this order)
+S_NB, S_FEND = _salloc(), _salloc()
+S_WF = _salloc()             # flat index (tile * NB + block) of the block being walked
+S_LREG, S_LFILL4, S_USELOG = [_salloc() for _ in range(3)]
+S_NWAVES = _salloc()
+S_WT, S_WN = _salloc(), _salloc()      # block being walked
+S_PT, S_PN, S_PREAL = _salloc(), _salloc(), _salloc()  # chunk being packed
+S_QT, S_QN, S_QREAL = _salloc(), _salloc(), _salloc()  # chunk being loaded next
+S_PSOFF, S_QSOFF = _salloc(), _salloc()
+S_STEPMASK = _salloc()
+S_B0, S_B1, S_B2 = _salloc(), _salloc(), _salloc()
+S_QHEAD8, S_QTAIL8 = _salloc(), _salloc()
+S_N, S_A, S_B, S_CC = _salloc(), _salloc(), _salloc(), _salloc()  # scalar scratch
+S_SPARE = _salloc()
+S_END = _sn[0]
+assert S_END <= 100, S_END
+
+S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_F1P)  # timing build only (S_F1P + 1 = the last time stamp, the pointer itself waits in two VGPRs): no F1
+
+# the asm statement's "s" operands, in order
+INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase"]
+# byte offsets in struct K1hArgs (ntc_kernels.hpp); the kernel reads them with scalar loads
+KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_tiles=56, n_chunks=60, read_len=64, nv_last=68, key_base=72,
+            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108)
+
+
+class Gen:
+    def __init__(self, k, sb_class=7):
+        assert 12 <= k <= 32
+        self.k = k
+        self.sb = sb_class
+        self.phi = (k - 1) % 16
+        self.j = (k - 1) // 16      # window start chunk = n - 1 - j
+        self.ng = n_groups(k)
+        self.p = Prog()
+        self.uid = 0
+        self.f_terms, self.r_terms = step_terms(k)
+        self.exp = set(x for x in os.environ.get("K1H_EXP", "").split(",") if x)  # timing experiments (tools/k1h_variant.sh): WRONG results
+
+    def lbl(self, base):
+        self.uid += 1
+        return f"{base}{self.uid}"
+
+    # ---- small helpers ----
+    def bitop3(self, d, a, b, c, fn):
+        self.p.i("v_bitop3_b32", d, a, b, c, mods=f"bitop3:0x{ttbl(fn):02x}")
+
+    def call(self, target):
+        """subroutine call: target returns with ret + 4"""
+        self.p.i("s_getpc_b64", sr(S_RET, 2))
+        self.p.i("s_branch", "@" + target)
+
+    def ret(self):
+        self.p.i("s_add_u32", s(S_RET), s(S_RET), 4)
+        self.p.i("s_addc_u32", s(S_RET + 1), s(S_RET + 1), 0)
+        self.p.i("s_setpc_b64", sr(S_RET, 2))
+
+    def probe(self, sec):
+        """timing build (K1H_EXP=timers): the clocks since the last probe go to section `sec` (0 walk + test + push, 1 pack, 2 resolve
+        passes, 3 end of block); the four sums are added to f1[1 .. 4] at the end (bench.py --k1h-timers).  F1 itself is not kept."""
+        if "timers" not in self.exp:
+            return
+        p = self.p
+        p.i("s_memtime", sr(S_TMP, 2))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_sub_u32", s(S_N), s(S_TMP), s(S_F1P + 1))
+        p.i("s_add_u32", s(S_TACC[sec]), s(S_TACC[sec]), s(S_N))
+        p.i("s_mov_b32", s(S_F1P + 1), s(S_TMP))
+
+    # ---- poly-A start state (gen_ts.poly_a_state) ----
+    def poly_a(self, strand):
+        h = 0
+        for t in range(self.k):
+            h ^= rol31(hseed("A"), self.k - 1 - t) if strand == "F" else rol31(hseed(COMP["A"]), t)
+        return h
+
+    # ---- one walk step -------------------------------------------------------------------------------------
+    def planes_of_step(self, a):
+        """registers of the incoming / outgoing base planes of step a"""
+        pos = self.phi + a
+        i0 = (V_H1 + 2 * pos) if pos < 16 else (V_I + 2 * (pos - 16))
+        if self.j == 1:
+            o0 = V_CARRY0 if a == 0 else V_H0 + 2 * (a - 1)
+        else:
+            o0 = V_H0 + 30 if a == 0 else V_H1 + 2 * (a - 1)
+        return i0, i0 + 1, o0, (V_CARRY1 if (self.j == 1 and a == 0) else o0 + 1)
+
+    def fn_plane(self, cache, t4, b0, b1, tpool):
+        """function plane of a 4-bit truth table over (b0, b1): -> (register or None, invert)"""
+        if t4 == 0x0:
+            return None, 0
+        if t4 == 0xf:
+            return None, 1
+        if t4 == 0b1010:
+            return b0, 0
+        if t4 == 0b0101:
+            return b0, 1
+        if t4 == 0b1100:
+            return b1, 0
+        if t4 == 0b0011:
+            return b1, 1
+        inv = 0
+        if t4 & 1:
+            t4 ^= 0xf
+            inv = 1
+        if t4 not in cache:
+            r = tpool.pop()
+            if t4 == 0b1000:
+                self.p.i("v_and_b32", v(r), v(b0), v(b1))
+            elif t4 == 0b1110:
+                self.p.i("v_or_b32", v(r), v(b0), v(b1))
+            elif t4 == 0b0110:
+                self.p.i("v_xor_b32", v(r), v(b0), v(b1))
+            else:
+                g = g_of(t4)
+                self.bitop3(v(r), v(b0), v(b1), v(b1), lambda x, y, z: g(x, y))
+            cache[t4] = r
+        return cache[t4], inv
+
+    def emit_update(self, dst, prev, x, y, inv):
+        if x is None and y is None:
+            if inv:
+                self.p.i("v_not_b32", v(dst), v(prev))
+            elif dst != prev:
+                self.p.i("v_mov_b32", v(dst), v(prev))
+        elif x is None or y is None:
+            z = x if y is None else y
+            if inv:
+                self.bitop3(v(dst), v(prev), v(z), v(z), lambda a, b, c: 1 ^ a ^ b)
+            else:
+                self.p.i("v_xor_b32", v(dst), v(prev), v(z))
+        else:
+            self.bitop3(v(dst), v(prev), v(x), v(y), (lambda a, b, c: 1 ^ a ^ b ^ c) if inv else (lambda a, b, c: a ^ b ^ c))
+
+    def walk_step(self, a):
+        i0, i1, o0, o1 = self.planes_of_step(a)
+        tpool = list(range(V_T0 + 13, V_T0 - 1 + 1, -1))  # temps V_T0+1 .. V_T0+13; V_T0 = the wrap-around copy
+        tpool = [V_T0 + 1 + i for i in range(12)][::-1]
+        cin, cout = {}, {}
+        tmp = V_T0
+        # forward: F'[j] = F[j-1] ^ in ^ out, in place from the top (F[30]'s old value feeds F[0])
+        plan = []
+        for strand, terms in (("F", self.f_terms), ("R", self.r_terms)):
+            for jj in range(31):
+                tin, tout = terms[jj]
+                x, xi = self.fn_plane(cin, tin, i0, i1, tpool)
+                y, yi = self.fn_plane(cout, tout, o0, o1, tpool)
+                plan.append((strand, jj, x, y, xi ^ yi))
+        fplan = {jj: (x, y, inv) for st, jj, x, y, inv in plan if st == "F"}
+        rplan = {jj: (x, y, inv) for st, jj, x, y, inv in plan if st == "R"}
+        self.p.i("v_mov_b32", v(tmp), v(V_F + 30))
+        for jj in range(30, 0, -1):
+            x, y, inv = fplan[jj]
+            self.emit_update(V_F + jj, V_F + jj - 1, x, y, inv)
+        x, y, inv = fplan[0]
+        self.emit_update(V_F + 0, tmp, x, y, inv)
+        # reverse: R'[j] = R[j+1] ^ in ^ out, in place from the bottom
+        self.p.i("v_mov_b32", v(tmp), v(V_R + 0))
+        for jj in range(0, 30):
+            x, y, inv = rplan[jj]
+            self.emit_update(V_R + jj, V_R + jj + 1, x, y, inv)
+        x, y, inv = rplan[30]
+        self.emit_update(V_R + 30, tmp, x, y, inv)
+
+    # ---- sample test of one strand: planes a (top bits == sample-1 pattern), g (>=), b (== sample-0 pattern), nz ----
+    def strand_flags(self, base, out):
+        """base: first register of the strand's state; out: dict of result registers a, g, b, nz; temps t1, t2"""
+        t7, b6, b5, b4, b3, b2, b1, b0 = [v(base + 30 - i) for i in range(8)]
+        ra, rg, rb, rnz, t1, t2 = [v(out[x]) for x in ("a", "g", "b", "nz", "t1", "t2")]
+        if self.sb == 7:
+            self.bitop3(t1, b6, b5, b4, lambda x, y, z: x & y & z)
+            self.bitop3(t1, t1, b3, b2, lambda x, y, z: x & y & z)          # bits 6..2 all set
+            self.bitop3(ra, t7, t1, b1, lambda x, y, z: (1 ^ x) & y & z)     # top 7 bits == 0111111
+            self.bitop3(rg, t7, t1, b1, lambda x, y, z: x | (y & z))         # top 7 bits >= 0111111
+            self.bitop3(t1, t7, b6, b5, lambda x, y, z: x | y | z)
+            self.bitop3(t2, b4, b3, b2, lambda x, y, z: x | y | z)
+            self.bitop3(t1, t1, t2, b1, lambda x, y, z: 1 ^ (x | y | z))     # top 7 bits == 0
+            self.p.i("v_and_b32", rb, t1, b0)                                # top 8 bits == 00000001
+            self.bitop3(rnz, t1, b0, b0, lambda x, y, z: (1 ^ x) | y)        # top 8 bits >= 1
+        else:
+            # s_bits >= 8: 8-bit prefixes of the patterns: 0x7f (sample 1) and 0x00 (sample 0); the pass checks the rest
+            self.bitop3(t1, b6, b5, b4, lambda x, y, z: x & y & z)
+            self.bitop3(t1, t1, b3, b2, lambda x, y, z: x & y & z)
+            self.bitop3(t1, t1, b1, b0, lambda x, y, z: x & y & z)          # low 7 of the 8 all set
+            self.bitop3(ra, t7, t1, t1, lambda x, y, z: (1 ^ x) & y)         # == 0x7f
+            self.p.i("v_or_b32", rg, t7, t1)                                 # >= 0x7f
+            self.bitop3(t1, t7, b6, b5, lambda x, y, z: x | y | z)
+            self.bitop3(t2, b4, b3, b2, lambda x, y, z: x | y | z)
+            self.bitop3(t1, t1, t2, b1, lambda x, y, z: x | y | z)
+            self.bitop3(rb, t1, b0, b0, lambda x, y, z: 1 ^ (x | y))         # == 0x00
+            # nz: any value is >= 0 — handled by the caller (cf = (a & g') | b)
+
+    def flags_and_push(self, a):
+        """candidate planes of step a (exact per strand), tie plane, then the two pushes"""
+        p = self.p
+        T = V_T0
+        fo = dict(a=T + 1, g=T + 2, b=T + 3, nz=T + 4, t1=T + 9, t2=T + 10)
+        ro = dict(a=T + 5, g=T + 6, b=T + 7, nz=T + 8, t1=T + 9, t2=T + 10)
+        self.strand_flags(V_F, fo)
+        self.strand_flags(V_R, ro)
+        cf, cr, tie = T + 11, T + 12, T + 13
+        if self.sb == 7:
+            p.i("v_and_b32", v(T + 9), v(fo["b"]), v(ro["nz"]))
+            self.bitop3(v(cf), v(fo["a"]), v(ro["g"]), v(T + 9), lambda x, y, z: (x & y) | z)
+            p.i("v_and_b32", v(T + 9), v(ro["b"]), v(fo["nz"]))
+            self.bitop3(v(cr), v(ro["a"]), v(fo["g"]), v(T + 9), lambda x, y, z: (x & y) | z)
+        else:
+            self.bitop3(v(cf), v(fo["a"]), v(ro["g"]), v(fo["b"]), lambda x, y, z: (x & y) | z)
+            self.bitop3(v(cr), v(ro["a"]), v(fo["g"]), v(ro["b"]), lambda x, y, z: (x & y) | z)
+        p.i("v_and_b32", v(tie), v(cf), v(cr))
+        self.bitop3(v(V_PX), v(cf), v(V_CMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
+        self.bitop3(v(V_RX), v(cr), v(V_CMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
+        self.bitop3(v(V_TACC), v(V_TACC), v(tie), v(V_CMASK), lambda x, y, z: x | (y & z))
+        # room for the new items?  (count + nF + nR <= QCAP, else resolve passes first; a pass keeps PX / RX and nothing else)
+        chk, go = self.lbl("chk"), self.lbl("go")
+        p.label(chk)
+        p.i("v_cmp_ne_u32_e64", sr(S_TMP, 2), 0, v(V_PX))
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(V_RX))
+        p.i("s_bcnt1_i32_b64", s(S_A), sr(S_TMP, 2))
+        p.i("s_bcnt1_i32_b64", s(S_B), "vcc")
+        p.i("s_sub_u32", s(S_N), s(S_QTAIL8), s(S_QHEAD8))
+        p.i("s_lshr_b32", s(S_N), s(S_N), 3)
+        p.i("s_add_u32", s(S_N), s(S_N), s(S_A))
+        p.i("s_add_u32", s(S_N), s(S_N), s(S_B))
+        p.i("s_cmp_le_u32", s(S_N), QCAP)
+        p.i("s_cbranch_scc1", "@" + go)
+        self.call("pass")
+        p.i("s_branch", "@" + chk)
+        p.label(go)
+        meta_f = (0 << 8) | ((2 * a) << 9)
+        meta_r = (1 << 8) | ((2 * a) << 9)
+        for strand, px, meta, msk, cnt in (("F", V_PX, meta_f, sr(S_TMP, 2), S_A), ("R", V_RX, meta_r, "vcc", S_B)):
+            lo = f"s{S_TMP}" if strand == "F" else "vcc_lo"
+            hi = f"s{S_TMP + 1}" if strand == "F" else "vcc_hi"
+            p.i("v_mbcnt_lo_u32_b32", v(T + 1), lo, 0)
+            p.i("v_mbcnt_hi_u32_b32", v(T + 1), hi, v(T + 1))
+            p.i("v_lshl_add_u32", v(T + 1), v(T + 1), 3, s(S_QTAIL8))
+            p.i("v_and_or_b32", v(T + 1), v(T + 1), v(V_CQMASK8), v(V_QBASE))
+            p.i("v_or_b32", v(px + 1), hex(meta), v(V_LANE4))
+            p.i("s_mov_b64", "exec", msk)
+            p.i("ds_write_b64", v(T + 1), vr(px, 2))
+            p.i("s_mov_b64", "exec", -1)
+            p.i("s_lshl3_add_u32", s(S_QTAIL8), s(cnt), s(S_QTAIL8))
+
+    # ---- pack one group of 64 pieces: RAW slot i -> packed word in register dst; then reload the slot ----
+    def pack_group(self, i, dst, reload):
+        p = self.p
+        r = V_RAW + 4 * i
+        t = [V_T0 + 12 + 6 * (i % 3) + x for x in range(6)]  # three sets of scratch registers: the scheduler interleaves neighbouring groups
+        for q in range(4):
+            p.i("v_and_b32", v(t[q]), "0x06060606", v(r + q))
+        for q in range(4):
+            if "nomul" in self.exp:
+                p.i("v_lshlrev_b32", v(t[q]), 3, v(t[q]))
+            else:
+                p.i("v_mul_lo_u32", v(t[q]), v(t[q]), v(V_CMUL))
+        p.i("v_perm_b32", v(t[0]), v(t[1]), v(t[0]), v(V_CPERMLO))
+        p.i("v_perm_b32", v(t[2]), v(t[3]), v(t[2]), v(V_CPERMHI))
+        p.i("v_or_b32", v(dst), v(t[0]), v(t[2]))
+        # validity: the letter (byte & 7) may stand for, XORed with the byte (zero or the case bit for a base letter)
+        x = t[4]
+        for q in range(4):
+            p.i("v_and_b32", v(t[q]), "0x07070707", v(r + q))
+            if "noperm" in self.exp:
+                p.i("v_xor_b32", v(t[q]), v(V_EXP1), v(t[q]))
+            else:
+                p.i("v_perm_b32", v(t[q]), s(S_EXP0), v(V_EXP1), v(t[q]))
+            if q == 0:
+                p.i("v_xor_b32", v(x), v(t[q]), v(r + q))
+            else:
+                self.bitop3(v(x), v(t[q]), v(r + q), v(x), lambda a, b, c: (a ^ b) | c)
+        p.i("v_and_b32", v(x), "0xdfdfdfdf", v(x))
+        if "nocarry" in self.exp:
+            p.i("v_or_b32", v(V_DN), v(V_DN), v(x))
+        else:
+            p.i("v_add_co_u32", v(t[5]), "vcc", -1, v(x))          # carry = (x != 0)
+            p.i("v_addc_co_u32", v(V_DN), "vcc", v(V_DN), v(V_DN), "vcc")  # dirty bits, group m ends up at bit 31 - m
+        if reload is not None and "noload" not in self.exp:
+            soff, imm = reload
+            p.i("buffer_load_dwordx4", vr(r, 4), v(V_LANE16), sr(S_DESC, 4), s(soff), mods=f"offen offset:{imm} nt")
+
+    def issue_batch(self, b, soff_base):
+        """loads of batch b (groups 8 b .. 8 b + 7) of the chunk at soffset soff_base: S_A / S_B as scratch soffsets"""
+        p = self.p
+        p.i("s_add_u32", s(S_A), s(soff_base), b * 8192)
+        p.i("s_add_u32", s(S_B), s(soff_base), b * 8192 + 4096)
+        for i in range(8):
+            if "noload" not in self.exp:
+                p.i("buffer_load_dwordx4", vr(V_RAW + 4 * i, 4), v(V_LANE16), sr(S_DESC, 4), s(S_A if i < 4 else S_B), mods=f"offen offset:{(i & 3) * 1024} nt")
+
+    def pack_batch(self, b):
+        """pack batch b of the chunk P into H0[8 b ..]; reload every slot with batch b + 1 of P, or — behind batch 3 — with batch 0 of
+        the chunk Q (S_A / S_B hold the two soffsets: the caller of batch 3 has pointed S_DESC / S_CC at Q, or at any valid chunk)"""
+        p = self.p
+        skip, real = self.lbl("pk_skip"), self.lbl("pk_real")
+        self.probe(0)
+        if b < 3:
+            p.i("s_add_u32", s(S_A), s(S_PSOFF), (b + 1) * 8192)
+        else:
+            p.i("s_mov_b32", s(S_A), s(S_CC))
+        p.i("s_add_u32", s(S_B), s(S_A), 4096)
+        p.i("s_cmp_eq_u32", s(S_PREAL), 1)
+        p.i("s_cbranch_scc1", "@" + real)
+        for i in range(8):  # a chunk that does not exist: 'A's
+            p.i("v_mov_b32", v(V_H0 + 8 * b + i), 0)
+        if b == 3 and "noload" not in self.exp:          # the next chunk's first loads all the same
+            for i in range(8):
+                p.i("buffer_load_dwordx4", vr(V_RAW + 4 * i, 4), v(V_LANE16), sr(S_DESC, 4), s(S_A if i < 4 else S_B), mods=f"offen offset:{(i & 3) * 1024} nt")
+        p.i("s_branch", "@" + skip)
+        p.label(real)
+        p.i("s_waitcnt", "vmcnt(0)")
+        if "nopack" in self.exp:
+            p.i("s_branch", "@" + skip)
+        for i in range(8):
+            self.pack_group(i, V_H0 + 8 * b + i, (S_A if i < 4 else S_B, (i & 3) * 1024))
+        p.label(skip)
+        self.probe(1)
+
+    # ---- 32 x 32 bit transpose of H0 in place (temps: 32 registers from V_T) ----
+    def transpose(self):
+        p = self.p
+        A = [V_H0 + i for i in range(32)]
+        B = [V_T + i for i in range(32)]
+        for kk in range(32):  # J = 16: A -> B
+            if kk & 16 == 0:
+                p.i("v_perm_b32", v(B[kk]), v(A[kk + 16]), v(A[kk]), v(V_CP16A))
+                p.i("v_perm_b32", v(B[kk + 16]), v(A[kk + 16]), v(A[kk]), v(V_CP16B))
+        for kk in range(32):  # J = 8: B -> A
+            if kk & 8 == 0:
+                p.i("v_perm_b32", v(A[kk]), v(B[kk + 8]), v(B[kk]), v(V_CP8A))
+                p.i("v_perm_b32", v(A[kk + 8]), v(B[kk + 8]), v(B[kk]), v(V_CP8B))
+        for J, msk in ((4, V_CM4), (2, V_CM2), (1, V_CM1)):  # in place: A[k] = bfi(m, x, y << J), A[k+J] = bfi(m, x >> J, y)
+            for kk in range(32):
+                if kk & J == 0:
+                    x, y = A[kk], A[kk + J]
+                    p.i("v_lshlrev_b32", v(B[0]), J, v(y))
+                    p.i("v_lshrrev_b32", v(B[1]), J, v(x))
+                    p.i("v_bfi_b32", v(x), v(msk), v(x), v(B[0]))
+                    p.i("v_bfi_b32", v(y), v(msk), v(B[1]), v(y))
+
+    # ---- the resolve pass (subroutine) ----------------------------------------------------------------------
+    def emit_pass(self):
+        p = self.p
+        T = V_T0
+        item = T            # (x, y)
+        m, rest, col, a0, a1, a2 = T + 2, T + 3, T + 4, T + 5, T + 6, T + 7
+        lo, hi, mid, tb, key, key1, acc = T + 8, T + 9, T + 10, T + 11, T + 12, T + 13, T + 14
+        fld = [T + 15 + g for g in range(11)]
+        t1 = T + 26
+        p.label("pass")
+        self.probe(0)
+        if "nopass" in self.exp:
+            p.i("s_mov_b32", s(S_QHEAD8), s(S_QTAIL8))
+            self.ret()
+        # active lanes: items head .. head + n - 1, n = min(64, count)
+        p.i("s_sub_u32", s(S_N), s(S_QTAIL8), s(S_QHEAD8))
+        p.i("s_lshr_b32", s(S_N), s(S_N), 3)
+        p.i("s_min_u32", s(S_N), s(S_N), 64)
+        p.i("s_bfm_b64", "exec", s(S_N), 0)
+        p.i("s_cmp_eq_u32", s(S_N), 64)
+        p.i("s_cselect_b64", "exec", -1, "exec")
+        p.i("v_add_u32", v(t1), s(S_QHEAD8), v(V_LANE8))
+        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK8), v(V_QBASE))
+        p.i("ds_read_b64", vr(item, 2), v(t1))
+        p.i("s_lshl3_add_u32", s(S_QHEAD8), s(S_N), s(S_QHEAD8))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        x, y = item, item + 1
+        p.i("v_ffbl_b32", v(m), v(x))
+        p.i("v_add_u32", v(rest), -1, v(x))
+        p.i("v_and_b32", v(rest), v(rest), v(x))
+        p.i("v_and_b32", v(col), 0xff, v(y))
+        p.i("v_lshl_add_u32", v(col), v(m), 8, v(col))
+        slots = (S_B0, S_B1, S_B2) if self.j == 1 else (S_B1, S_B2, S_B2)
+        p.i("v_add_u32", v(a0), s(slots[0]), v(col))
+        p.i("v_add_u32", v(a1), s(slots[1]), v(col))
+        p.i("v_add_u32", v(a2), s(slots[2]), v(col))
+        p.i("ds_read_b32", v(a0), v(a0))
+        p.i("ds_read_b32", v(a1), v(a1))
+        p.i("ds_read_b32", v(a2), v(a2))
+        p.i("v_bfe_u32", v(t1), v(y), 9, 5)                   # shift = 2 x (window start within its chunk)
+        p.i("v_bfe_u32", v(tb), v(y), 8, 1)                   # strand
+        p.i("v_mul_u32_u24", v(tb), hex(self.ng * 256), v(tb))
+        p.i("v_add_u32", v(tb), TABLE_OFF, v(tb))              # the strand's table
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("v_alignbit_b32", v(lo), v(a1), v(a0), v(t1))     # bases 0 .. 15 of the window
+        p.i("v_alignbit_b32", v(hi), v(a2), v(a1), v(t1))     # bases 16 .. 31
+        # 3 bases per look-up: field g = bits [6 g, 6 g + 6) of hi:lo
+        for g in range(self.ng):
+            bit = 6 * g
+            nb = min(3, self.k - 3 * g) * 2
+            if bit + nb <= 32:
+                src, off = lo, bit
+            elif bit >= 32:
+                src, off = hi, bit - 32
+            else:
+                if bit == 30:
+                    p.i("v_alignbit_b32", v(mid), v(hi), v(lo), 30)
+                src, off = mid, bit - 30
+            p.i("v_bfe_u32", v(fld[g]), v(src), off, nb)
+            p.i("v_lshl_add_u32", v(fld[g]), v(fld[g]), 2, v(tb))
+        for g in range(self.ng):
+            p.i("ds_read_b32", v(fld[g]), v(fld[g]), mods=f"offset:{g * 256}")
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        words = list(fld[: self.ng])
+        while len(words) > 1:
+            if len(words) >= 3:
+                a, b, c = words[:3]
+                self.bitop3(v(a), v(a), v(b), v(c), lambda q, r, t: q ^ r ^ t)
+                words = words[3:] + [a]
+            else:
+                a, b = words
+                p.i("v_xor_b32", v(a), v(a), v(b))
+                words = [a]
+        w = words[0]
+        if self.sb == 7:
+            p.i("v_and_b32", v(key), s(S_RMASK2), v(w))      # low rBits bits + the sample bit right above them
+            p.i("v_add_u32", v(key), s(S_KEYBASE), v(key))
+        else:
+            raise NotImplementedError
+        # append to the hit log (all active lanes hold a hit)
+        nolog, logged, room = self.lbl("nolog"), self.lbl("logged"), self.lbl("room")
+        p.i("s_cmp_eq_u32", s(S_USELOG), 1)
+        p.i("s_cbranch_scc0", "@" + nolog)
+        p.label(room)
+        p.i("s_lshl2_add_u32", s(S_A), s(S_N), s(S_LFILL4))
+        p.i("s_cmp_le_u32", s(S_A), s(S_LOGCAP4))
+        p.i("s_cbranch_scc0", "@logswitch")
+        p.label("logswitch_back")
+        p.i("v_add_u32", v(t1), s(S_LFILL4), v(V_LANE4))
+        p.i("global_store_dword", v(t1), v(key), sr(S_LOGBASE, 2))
+        p.i("s_mov_b32", s(S_LFILL4), s(S_A))
+        p.i("s_branch", "@" + logged)
+        p.label(nolog)
+        p.label("direct")
+        p.i("v_mov_b32", v(key1), 0)
+        p.i("v_lshl_add_u64", vr(key, 2), vr(key, 2), 2, sr(S_SK, 2))
+        p.i("global_atomic_add", vr(key, 2), v(V_ONE), "off")
+        p.label(logged)
+        # what is left of each word goes to the back of the queue
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
+        p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
+        p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
+        p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
+        p.i("v_lshl_add_u32", v(t1), v(t1), 3, s(S_QTAIL8))
+        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK8), v(V_QBASE))
+        p.i("v_mov_b32", v(x), v(rest))
+        p.i("s_and_b64", "exec", "exec", "vcc")
+        p.i("ds_write_b64", v(t1), vr(item, 2))
+        p.i("s_mov_b64", "exec", -1)
+        p.i("s_lshl3_add_u32", s(S_QTAIL8), s(S_A), s(S_QTAIL8))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        self.probe(2)
+        self.ret()
+        # ---- rare: the log region is full ----
+        p.label("logswitch")
+        p.i("s_mov_b64", "vcc", "exec")
+        self.store_log_fill()
+        p.i("s_add_u32", s(S_LREG), s(S_LREG), s(S_NWAVES))
+        p.i("s_cmp_lt_u32", s(S_LREG), s(S_LOGREG))
+        ok = self.lbl("lsw_ok")
+        p.i("s_cbranch_scc1", "@" + ok)
+        p.i("s_mov_b32", s(S_USELOG), 0)                      # out of regions: ntComp's increment as device atomics from here on
+        p.i("s_mov_b64", "exec", "vcc")
+        p.i("s_branch", "@direct")
+        p.label(ok)
+        self.load_log_region()
+        p.i("s_mov_b64", "exec", "vcc")
+        p.i("s_lshl2_add_u32", s(S_A), s(S_N), s(S_LFILL4))
+        p.i("s_cmp_le_u32", s(S_A), s(S_LOGCAP4))
+        p.i("s_cbranch_scc0", "@logswitch")
+        p.i("s_branch", "@logswitch_back")
+
+    def store_log_fill(self):
+        """log_fill[LREG] = LFILL (one lane)"""
+        p = self.p
+        T = V_T0 + 27
+        p.i("s_mov_b64", "exec", 1)
+        p.i("s_lshl_b32", s(S_B), s(S_LREG), 2)
+        p.i("s_lshr_b32", s(S_CC), s(S_LFILL4), 2)
+        p.i("v_mov_b32", v(T), s(S_B))
+        p.i("v_mov_b32", v(T + 1), s(S_CC))
+        p.i("global_store_dword", v(T), v(T + 1), sr(S_LOGFILL, 2))
+        p.i("s_mov_b64", "exec", -1)
+
+    def load_log_region(self):
+        """LFILL4 and the buffer descriptor of region LREG"""
+        p = self.p
+        p.i("s_lshl_b32", s(S_B), s(S_LREG), 2)
+        p.i("s_load_dword", s(S_LFILL4), sr(S_LOGFILL, 2), s(S_B))
+        p.i("s_mul_i32", s(S_TMP), s(S_LREG), s(S_LOGCAP4))
+        p.i("s_mul_hi_u32", s(S_TMP + 1), s(S_LREG), s(S_LOGCAP4))
+        p.i("s_add_u32", s(S_LOGBASE), s(S_LOG), s(S_TMP))
+        p.i("s_addc_u32", s(S_LOGBASE + 1), s(S_LOG + 1), s(S_TMP + 1))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_lshl_b32", s(S_LFILL4), s(S_LFILL4), 2)
+
+    # ---- scalar helpers: chunk cursor ----------------------------------------------------------------------
+    def cursor_next(self, t, n, real):
+        """(t, n) -> the next chunk of the wave's flat sequence; real = it exists (n < C and t < n_tiles)"""
+        p = self.p
+        same = self.lbl("cur")
+        p.i("s_add_u32", s(n), s(n), 1)
+        p.i("s_cmp_lt_u32", s(n), s(S_NB))
+        p.i("s_cbranch_scc1", "@" + same)
+        p.i("s_mov_b32", s(n), 0)
+        p.i("s_add_u32", s(t), s(t), 1)
+        p.label(same)
+        p.i("s_cmp_lt_u32", s(n), s(S_C))
+        p.i("s_cselect_b32", s(real), 1, 0)
+        p.i("s_cmp_lt_u32", s(t), s(S_NTILES))
+        p.i("s_cselect_b32", s(real), s(real), 0)
+
+    def set_desc(self, t):
+        """S_DESC = slots of tile t"""
+        p = self.p
+        p.i("s_mul_i32", s(S_TMP), s(t), s(S_CHUNKB))
+        p.i("s_mul_hi_u32", s(S_TMP + 1), s(t), s(S_CHUNKB))
+        p.i("s_add_u32", s(S_DESC), s(S_TILES), s(S_TMP))
+        p.i("s_addc_u32", s(S_DESC + 1), s(S_TILES + 1), s(S_TMP + 1))
+
+    # ---- the whole kernel body ------------------------------------------------------------------------------
+    def build(self, emu=False):
+        p = self.p
+        k, phi = self.k, self.phi
+        # -- inputs -> fixed registers (operands %0 .. are the compiler's; the emulator finds them in s0 ..)
+        inp = {name: (s(i) if emu else f"%{i}") for i, name in enumerate(INPUTS)}
+        p.i("s_mov_b32", s(S_KARG), inp["karg_lo"])
+        p.i("s_mov_b32", s(S_KARG + 1), inp["karg_hi"])
+        p.i("s_mov_b32", s(S_WT), inp["wave_gid"])
+        p.i("s_mov_b32", s(S_NWAVES), inp["n_waves"])
+        p.i("s_mov_b32", s(S_B0), inp["lds_wbase"])
+        for reg, name in ((S_TILES, "tiles"), (S_LOG, "log"), (S_LOGFILL, "log_fill"), (S_SK, "sketch0"), (S_F1P, "f1"), (S_DIRTY, "dirty"), (S_TIE, "tie")):
+            p.i("s_load_dwordx2", sr(reg, 2), sr(S_KARG, 2), hex(KARG[name]))
+        for reg, name in ((S_NTILES, "n_tiles"), (S_C, "n_chunks"), (S_L, "read_len"), (S_NVLAST, "nv_last"), (S_KEYBASE, "key_base"), (S_RMASK2, "rmask2"),
+                          (S_LOGREG, "log_regions"), (S_LOGCAP4, "log_region_cap")):
+            p.i("s_load_dword", s(reg), sr(S_KARG, 2), hex(KARG[name]))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_lshl_b32", s(S_LOGCAP4), s(S_LOGCAP4), 2)
+        p.i("s_mov_b32", s(S_EXP0), "0x47ff5554")
+        for reg, val in VCONST:
+            p.i("v_mov_b32", v(reg), hex(val))
+        p.i("s_mov_b32", s(S_DESC + 2), "0x7fffffff")          # records: a tile's slots (C x 32 KiB) always fit
+        p.i("s_mov_b32", s(S_DESC + 3), "0x00020000")
+        p.i("s_lshl_b32", s(S_CHUNKB), s(S_C), 15)             # bytes of one tile
+        # lane constants
+        p.i("v_mbcnt_lo_u32_b32", v(V_LANE4), -1, 0)
+        p.i("v_mbcnt_hi_u32_b32", v(V_LANE4), -1, v(V_LANE4))
+        p.i("v_lshlrev_b32", v(V_LANE16), 4, v(V_LANE4))
+        p.i("v_lshlrev_b32", v(V_LANE8), 3, v(V_LANE4))
+        p.i("v_lshlrev_b32", v(V_LANE4), 2, v(V_LANE4))
+        p.i("v_mov_b32", v(V_ONE), 1)
+        p.i("v_mov_b32", v(V_EXP1), "0x43ff41ff")
+        p.i("s_add_u32", s(S_A), s(S_B0), RING_BYTES)
+        p.i("v_mov_b32", v(V_QBASE), s(S_A))
+        p.i("s_add_u32", s(S_B1), s(S_B0), 8192)
+        p.i("s_add_u32", s(S_B2), s(S_B0), 16384)
+        p.i("s_mov_b32", s(S_QHEAD8), 0)
+        p.i("s_mov_b32", s(S_QTAIL8), 0)
+        p.i("s_mov_b64", sr(S_F1ACC, 2), 0)
+        if "timers" in self.exp:
+            p.i("s_mov_b32", s(S_SPARE), 0)
+            p.i("v_mov_b32", v(V_SPARE0), s(S_F1P))
+            p.i("v_mov_b32", v(V_SPARE1), s(S_F1P + 1))
+        # geometry: W = L - k + 1, NB = ((L - 1 + 16 - phi) >> 4) + 1
+        p.i("s_add_u32", s(S_NB), s(S_L), 15 - phi)
+        p.i("s_lshr_b32", s(S_NB), s(S_NB), 4)
+        p.i("s_add_u32", s(S_NB), s(S_NB), 1)
+        # hit log: this wave's first region
+        p.i("s_cmp_lg_u32", s(S_LOGREG), 0)
+        p.i("s_cselect_b32", s(S_USELOG), 1, 0)
+        p.i("s_mov_b32", s(S_LREG), s(S_WT))
+        p.i("s_mov_b32", s(S_LFILL4), 0)
+        p.i("s_cmp_lt_u32", s(S_LREG), s(S_LOGREG))
+        p.i("s_cselect_b32", s(S_USELOG), s(S_USELOG), 0)
+        nolog0 = self.lbl("nolog0")
+        p.i("s_cmp_eq_u32", s(S_USELOG), 1)
+        p.i("s_cbranch_scc0", "@" + nolog0)
+        self.load_log_region()
+        p.label(nolog0)
+        # This wave's share: the blocks of all tiles form one sequence (tile * NB + block); wave w owns [w T, (w + 1) T), T = blocks_per_wave
+        # — tiles are split wherever a boundary falls (19 tiles per CU over 6 waves are 4 rounds of whole tiles but 3.2 of blocks).
+        # A wave that starts inside a tile first walks up to two blocks it does not own, masked: they fill the window (k - 1 <= 31 bases).
+        p.i("s_load_dword", s(S_A), sr(S_KARG, 2), hex(KARG["blocks_per_wave"]))
+        p.i("s_load_dword", s(S_B), sr(S_KARG, 2), hex(KARG["nb_magic"]))
+        p.i("s_mul_i32", s(S_CC), s(S_NTILES), s(S_NB))          # blocks of the batch
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_mul_i32", s(S_F0), s(S_WT), s(S_A))
+        p.i("s_cmp_lt_u32", s(S_F0), s(S_CC))
+        p.i("s_cbranch_scc0", "@exit")
+        p.i("s_add_u32", s(S_FEND), s(S_F0), s(S_A))
+        p.i("s_min_u32", s(S_FEND), s(S_FEND), s(S_CC))
+        p.i("s_mul_hi_u32", s(S_PT), s(S_F0), s(S_B))            # tile = F0 / NB with nb_magic = floor(2^32 / NB): never too large,
+        p.i("s_mul_i32", s(S_A), s(S_PT), s(S_NB))
+        p.i("s_sub_u32", s(S_PN), s(S_F0), s(S_A))               # block = F0 - tile NB ...
+        fix, fixed = self.lbl("divfix"), self.lbl("divok")
+        p.label(fix)
+        p.i("s_cmp_lt_u32", s(S_PN), s(S_NB))
+        p.i("s_cbranch_scc1", "@" + fixed)
+        p.i("s_sub_u32", s(S_PN), s(S_PN), s(S_NB))              # ... corrected upwards
+        p.i("s_add_u32", s(S_PT), s(S_PT), 1)
+        p.i("s_branch", "@" + fix)
+        p.label(fixed)
+        p.i("s_min_u32", s(S_A), s(S_PN), 2)
+        p.i("s_sub_u32", s(S_PN), s(S_PN), s(S_A))
+        p.i("s_sub_u32", s(S_S0), s(S_F0), s(S_A))               # the first block walked
+        p.i("s_sub_u32", s(S_WF), s(S_S0), 1)
+        p.i("s_cmp_lt_u32", s(S_PN), s(S_C))
+        p.i("s_cselect_b32", s(S_PREAL), 1, 0)
+        p.i("s_mov_b32", s(S_QT), s(S_PT))
+        p.i("s_mov_b32", s(S_QN), s(S_PN))
+        self.cursor_next(S_QT, S_QN, S_QREAL)
+        p.i("s_mov_b32", s(S_WN), -1)                           # the dummy iteration: nothing to walk
+        p.i("s_mov_b32", s(S_STEPMASK), 0)
+        self.set_desc(S_PT)
+        p.i("s_lshl_b32", s(S_PSOFF), s(S_PN), 15)
+        p.i("s_lshl_b32", s(S_QSOFF), s(S_QN), 15)
+        p.i("v_mov_b32", v(V_DN), 0)
+        p.i("v_mov_b32", v(V_TACC), 0)
+        p.i("v_mov_b32", v(V_CMASK), 0)
+        nofirst = self.lbl("nofirst")
+        p.i("s_cmp_eq_u32", s(S_PREAL), 1)
+        p.i("s_cbranch_scc0", "@" + nofirst)
+        self.issue_batch(0, S_PSOFF)
+        p.label(nofirst)
+
+        if "timers" in self.exp:
+            p.i("s_memtime", sr(S_TMP, 2))
+            p.i("s_waitcnt", "lgkmcnt(0)")
+            p.i("s_mov_b32", s(S_F1P + 1), s(S_TMP))
+            p.i("s_mov_b64", sr(S_F1ACC, 2), 0)
+        # ================================ the chunk loop ================================
+        p.label("iter")
+        for a in range(16):
+            self.walk_step(a)
+            skip = self.lbl("nostep")
+            p.i("s_bitcmp1_b32", s(S_STEPMASK), a)
+            p.i("s_cbranch_scc0", "@" + skip)
+            if "noflags" in self.exp:
+                p.i("s_branch", "@" + skip)
+            self.flags_and_push(a)
+            p.label(skip)
+            if a in (4, 8, 12):
+                self.pack_batch(a // 4 - 1)
+            if a == 15:
+                if self.j == 1:  # the plane pair that leaves the window at the first step of the next block
+                    p.i("v_mov_b32", v(V_CARRY0), v(V_H0 + 30))
+                    p.i("v_mov_b32", v(V_CARRY1), v(V_H0 + 31))
+                # the loads behind batch 3 belong to chunk Q: its tile's descriptor (P's loads are all issued); a chunk that does not
+                # exist is replaced by the first chunk of the tile the descriptor points at (loaded, never packed)
+                noq = self.lbl("noq")
+                p.i("s_mov_b32", s(S_CC), 0)
+                p.i("s_cmp_eq_u32", s(S_QREAL), 1)
+                p.i("s_cbranch_scc0", "@" + noq)
+                self.set_desc(S_QT)
+                p.i("s_mov_b32", s(S_CC), s(S_QSOFF))
+                p.label(noq)
+                self.pack_batch(3)
+        # -- end of block: empty the queue (the ring slot of chunk n - 2 is about to be overwritten)
+        drain, drained = self.lbl("drain"), self.lbl("drained")
+        p.label(drain)
+        p.i("s_cmp_eq_u32", s(S_QTAIL8), s(S_QHEAD8))
+        p.i("s_cbranch_scc1", "@" + drained)
+        self.call("pass")
+        p.i("s_branch", "@" + drain)
+        p.label(drained)
+        self.probe(0)
+        # -- tie bits of this block -> tie[(WT * NB + WN) * 64 + lane]
+        notie = self.lbl("notie")
+        p.i("s_add_u32", s(S_A), s(S_WF), 1)                    # (the dummy iteration of a wave that starts at block 0 has WF = -1)
+        p.i("s_cmp_gt_u32", s(S_A), s(S_F0))
+        p.i("s_cbranch_scc0", "@" + notie)
+        p.i("s_lshl_b32", s(S_A), s(S_WF), 8)
+        p.i("v_add_u32", v(V_T0), s(S_A), v(V_LANE4))
+        p.i("global_store_dword", v(V_T0), v(V_TACC), sr(S_TIE, 2))
+        p.label(notie)
+        p.i("v_mov_b32", v(V_TACC), 0)
+        # -- chunk P: packed words -> ring slot of chunk n - 2, dirty bits -> dirty[(PT * C + PN) * 64 + lane], then planes
+        p.i("v_bfrev_b32", v(V_DN), v(V_DN))
+        nopk = self.lbl("nopk")
+        p.i("s_cmp_eq_u32", s(S_PREAL), 1)
+        p.i("s_cbranch_scc0", "@" + nopk)
+        p.i("v_add_u32", v(V_T0), s(S_B0), v(V_LANE4))
+        for mm in range(32):
+            p.i("ds_write_b32", v(V_T0), v(V_H0 + mm), mods=f"offset:{mm * 256}")
+        p.i("s_mul_i32", s(S_A), s(S_PT), s(S_C))
+        p.i("s_add_u32", s(S_A), s(S_A), s(S_PN))
+        p.i("s_lshl_b32", s(S_A), s(S_A), 8)
+        p.i("v_add_u32", v(V_T0), s(S_A), v(V_LANE4))
+        p.i("global_store_dword", v(V_T0), v(V_DN), sr(S_DIRTY, 2))
+        self.transpose()
+        p.label(nopk)
+        # -- rotate: planes (H0, H1, I) <- (H1, I, new), ring slots, dirty words
+        for i in range(32):
+            p.i("v_swap_b32", v(V_H0 + i), v(V_H1 + i))
+        for i in range(32):
+            p.i("v_swap_b32", v(V_H1 + i), v(V_I + i))
+        p.i("s_mov_b32", s(S_A), s(S_B0))
+        p.i("s_mov_b32", s(S_B0), s(S_B1))
+        p.i("s_mov_b32", s(S_B1), s(S_B2))
+        p.i("s_mov_b32", s(S_B2), s(S_A))
+        p.i("v_mov_b32", v(V_D0), v(V_D1))
+        p.i("v_mov_b32", v(V_D1), v(V_D2))
+        p.i("v_mov_b32", v(V_D2), v(V_DN))
+        p.i("v_mov_b32", v(V_DN), 0)
+        # -- advance: W <- P, P <- Q, Q <- next(Q)
+        p.i("s_mov_b32", s(S_WT), s(S_PT))
+        p.i("s_mov_b32", s(S_WN), s(S_PN))
+        p.i("s_add_u32", s(S_WF), s(S_WF), 1)
+        p.i("s_cmp_lt_u32", s(S_WF), s(S_FEND))
+        p.i("s_cbranch_scc0", "@done")
+        p.i("s_mov_b32", s(S_PT), s(S_QT))
+        p.i("s_mov_b32", s(S_PN), s(S_QN))
+        p.i("s_mov_b32", s(S_PREAL), s(S_QREAL))
+        p.i("s_mov_b32", s(S_PSOFF), s(S_QSOFF))
+        self.cursor_next(S_QT, S_QN, S_QREAL)
+        p.i("s_lshl_b32", s(S_QSOFF), s(S_QN), 15)
+        # -- a new tile?
+        notile, newtile = self.lbl("notile"), self.lbl("newtile")
+        p.i("s_cmp_eq_u32", s(S_WN), 0)
+        p.i("s_cbranch_scc1", "@" + newtile)
+        p.i("s_cmp_eq_u32", s(S_WF), s(S_S0))                    # (or the wave's first block, inside a tile)
+        p.i("s_cbranch_scc0", "@" + notile)
+        p.label(newtile)
+        hf, hr = self.poly_a("F"), self.poly_a("R")
+        for jj in range(31):
+            p.i("v_mov_b32", v(V_F + jj), -1 if (hf >> jj) & 1 else 0)
+            p.i("v_mov_b32", v(V_R + jj), -1 if (hr >> jj) & 1 else 0)
+        for i in range(32):
+            p.i("v_mov_b32", v(V_H0 + i), 0)
+            p.i("v_mov_b32", v(V_H1 + i), 0)
+        p.i("v_mov_b32", v(V_CARRY0), 0)
+        p.i("v_mov_b32", v(V_CARRY1), 0)
+        p.i("v_mov_b32", v(V_D0), 0)
+        p.i("v_mov_b32", v(V_D1), 0)
+        # valid reads of this tile: all 2048 but in a partial last tile
+        p.i("s_add_u32", s(S_A), s(S_WT), 1)
+        p.i("s_cmp_eq_u32", s(S_A), s(S_NTILES))
+        p.i("s_cselect_b32", s(S_A), s(S_NVLAST), 2048)
+        # VMASK bit m = (64 m + lane < valid): cnt = clamp((valid - lane + 63) >> 6, 0, 32) low bits set
+        T = V_T0
+        p.i("v_lshrrev_b32", v(T), 2, v(V_LANE4))
+        p.i("v_sub_u32", v(T), s(S_A), v(T))                    # valid - lane
+        p.i("v_add_u32", v(T), 63, v(T))
+        p.i("v_lshrrev_b32", v(T), 6, v(T))                     # (valid >= 1 and lane <= 63: never negative) groups m with 64 m + lane < valid
+        p.i("v_min_u32", v(T), 32, v(T))
+        p.i("v_cmp_gt_u32_e32", "vcc", 32, v(T))
+        p.i("v_lshlrev_b32", v(T + 1), v(T), v(V_ONE))
+        p.i("v_add_u32", v(T + 1), -1, v(T + 1))
+        p.i("v_cndmask_b32_e64", v(V_VMASK), -1, v(T + 1), "vcc")
+        p.label(notile)
+        # -- per block: candidates are dropped wherever one of the block's three chunks holds a dirty piece of the read
+        p.i("v_or3_b32", v(V_T0), v(V_D0), v(V_D1), v(V_D2))
+        self.bitop3(v(V_CMASK), v(V_T0), v(V_VMASK), v(V_VMASK), lambda x, y, z: (1 ^ x) & y)
+        # steps of this block that complete a window: e = 16 (n - 1) + phi + a in [k - 1, L - 1]
+        p.i("s_lshl_b32", s(S_A), s(S_WN), 4)
+        p.i("s_add_i32", s(S_A), s(S_A), phi - 16)              # e0
+        p.i("s_sub_i32", s(S_B), k - 1, s(S_A))
+        p.i("s_max_i32", s(S_B), s(S_B), 0)                     # first valid step
+        p.i("s_sub_i32", s(S_CC), s(S_L), s(S_A))
+        p.i("s_sub_i32", s(S_CC), s(S_CC), 1)
+        p.i("s_min_i32", s(S_CC), s(S_CC), 15)                  # last valid step
+        p.i("s_sub_i32", s(S_CC), s(S_CC), s(S_B))
+        p.i("s_add_i32", s(S_CC), s(S_CC), 1)                   # how many
+        p.i("s_max_i32", s(S_CC), s(S_CC), 0)
+        p.i("s_bfm_b32", s(S_STEPMASK), s(S_CC), s(S_B))
+        p.i("s_cmp_ge_u32", s(S_WF), s(S_F0))                    # a block walked only to fill the window completes nothing
+        p.i("s_cselect_b32", s(S_STEPMASK), s(S_STEPMASK), 0)
+        p.i("s_cselect_b32", s(S_CC), s(S_CC), 0)
+        # F1 (ntcard.cpp:154): every window of every valid read counts here (K1f takes the invalid ones back)
+        p.i("s_add_u32", s(S_A), s(S_WT), 1)
+        p.i("s_cmp_eq_u32", s(S_A), s(S_NTILES))
+        p.i("s_cselect_b32", s(S_A), s(S_NVLAST), 2048)
+        p.i("s_mul_i32", s(S_B), s(S_A), s(S_CC))
+        if "timers" not in self.exp:
+            p.i("s_add_u32", s(S_F1ACC), s(S_F1ACC), s(S_B))
+            p.i("s_addc_u32", s(S_F1ACC + 1), s(S_F1ACC + 1), 0)
+        self.probe(3)
+        p.i("s_branch", "@iter")
+
+        # ================================ epilogue ================================
+        p.label("done")
+        # F1 (ntcard.cpp:154)
+        T = V_T0
+        p.i("s_mov_b64", "exec", 1)
+        if "timers" in self.exp:
+            p.i("v_mov_b32", v(T + 2), v(V_SPARE0))
+            p.i("v_mov_b32", v(T + 3), v(V_SPARE1))
+            p.i("v_mov_b32", v(T + 1), 0)
+            for sec in range(4):
+                p.i("v_mov_b32", v(T), s(S_TACC[sec]))
+                p.i("global_atomic_add_x2", vr(T + 2, 2), vr(T, 2), "off", mods=f"offset:{8 * (1 + sec)}")
+        else:
+            p.i("v_mov_b32", v(T), s(S_F1ACC))
+            p.i("v_mov_b32", v(T + 1), s(S_F1ACC + 1))
+            p.i("v_mov_b32", v(T + 2), s(S_F1P))
+            p.i("v_mov_b32", v(T + 3), s(S_F1P + 1))
+            p.i("global_atomic_add_x2", vr(T + 2, 2), vr(T, 2), "off")
+        p.i("s_mov_b64", "exec", -1)
+        nofill = self.lbl("nofill")
+        p.i("s_cmp_eq_u32", s(S_USELOG), 1)
+        p.i("s_cbranch_scc0", "@" + nofill)
+        self.store_log_fill()
+        p.label(nofill)
+        p.label("exit")
+        p.i("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+        p.i("s_branch", "@end")
+        self.emit_pass()
+        p.label("end")
+        if "nosched" not in self.exp:
+            schedule(p)
+        return p
+
+
+def render_inc(k, sb):
+    g = Gen(k, sb)
+    prog = g.build()
+    lines = prog.render(label_fmt=".Lk1h_{}_%=")
+    body = "\n".join('\t"' + ln.replace('"', '\\"') + '\\n"' for ln in lines)
+    return f"// GENERATED by gen_k1h.py (k = {k}, sBits class {sb}): {prog.n_insts()} instructions\n#define K1H_ASM_K{k}_S{sb} \\\n" + \
+        "\n".join(ln + " \\" for ln in body.split("\n")) + "\n\n"
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else "ntc_k1h_gen.inc"
+    ks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [32]
+    with open(out, "w") as f:
+        f.write("// ntc_k1h_gen.inc — GENERATED by gen_k1h.py (do not edit)\n")
+        f.write(f"#define K1H_N_INPUTS {len(INPUTS)}\n")
+        for k in ks:
+            f.write(render_inc(k, 7))
+    print("wrote", out)

@@ -104,6 +104,7 @@ int ensure_kernel_attrs(int dev)
 	HIP_TRY(ntc::set_apply_smem_limit());
 	HIP_TRY(ntc::set_sketch_bs_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_sketch_ts_smem_limit(kMaxDynLds));
+	HIP_TRY(ntc::set_sketch_k1h_smem_limit());
 	done[dev] = 1;
 	return 0;
 }
@@ -258,6 +259,11 @@ struct ntc_engine {
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
 	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry, of klist[0] (NULL: neither is used by this engine)
 	std::vector<void*> d_t4s;       // K1c: one table per k of the list (d_t4s[0] == d_t4)
+	std::vector<uint32_t*> d_k1h_tabs; // K1h: closed-form table per k of the list (nullptr: K1c takes that k)
+	std::vector<void*> d_k1h_fix;      // K1f: per-byte rolling terms of that k
+	bool k1h_wanted = true;         // !NTC_FLAG_TILED_TEAMS
+	uint32_t *d_dirty = nullptr, *d_tie = nullptr; // K1h -> K1f bit arrays (grow-only)
+	size_t dirty_cap = 0, tie_cap = 0;
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
 	bool bs_ok = false;             // K1b (bit-sliced kernel over row slots) is
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
@@ -811,6 +817,46 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
 		if (read_len < k) continue; // no window of this k (ntHashIterator.hpp:61-64)
+		if (e->d_k1h_tabs[ki] != nullptr) {
+			// K1h + K1f: one wave per tile; the two bit arrays between them are scratch of this launch pair
+			const uint32_t n_chunks = (read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, read_len);
+			const size_t need_d = (size_t)n_tiles * n_chunks * 256, need_t = (size_t)n_tiles * nb * 256;
+			if (need_d < (1ull << 32) && need_t < (1ull << 32)) {
+				if (need_d > e->dirty_cap || need_t > e->tie_cap) {
+					HIP_TRY(hipStreamSynchronize(e->stream));
+					if (e->d_dirty) (void)hipFree(e->d_dirty);
+					if (e->d_tie) (void)hipFree(e->d_tie);
+					e->d_dirty = e->d_tie = nullptr;
+					e->dirty_cap = e->tie_cap = 0;
+					if (hipMalloc((void**)&e->d_dirty, need_d) != hipSuccess || hipMalloc((void**)&e->d_tie, need_t) != hipSuccess)
+						return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
+					e->dirty_cap = need_d;
+					e->tie_cap = need_t;
+				}
+				ntc::K1hArgs h;
+				std::memset(&h, 0, sizeof h);
+				h.tiles = d_tiles;
+				h.log = e->d_log;
+				h.log_fill = e->d_logfill;
+				h.sketch0 = e->d_sketch;
+				h.f1 = e->d_f1 + ki;
+				h.dirty = e->d_dirty;
+				h.tie = e->d_tie;
+				h.n_tiles = (uint32_t)n_tiles;
+				h.n_chunks = n_chunks;
+				h.read_len = read_len;
+				h.nv_last = (uint32_t)(n_reads - (n_tiles - 1) * ntc::kTileReads);
+				h.key_base = (uint32_t)(ki * e->plane_elems());
+				h.rmask2 = (uint32_t)((2ull << e->r_bits) - 1ull);
+				h.log_regions = e->d_log ? e->log_regions : 0u;
+				h.log_region_cap = e->log_region_cap;
+				h.table = e->d_k1h_tabs[ki];
+				h.s_bits = e->s_bits;
+				h.r_bits = e->r_bits;
+				HIP_TRY(ntc::launch_sketch_k1h(h, k, e->d_k1h_fix[ki], (unsigned)di.cus, e->stream));
+				continue;
+			}
+		}
 		ntc::TsArgs a;
 		std::memset(&a, 0, sizeof a);
 		a.tiles = d_tiles;
@@ -962,6 +1008,34 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		e->d_t4 = e->d_t4s[0];
 	}
 	if (!e->d_t4) e->ts_ok = e->bs_ok = false;
+	// K1h (one wave per tile) takes the k it is generated for; K1c keeps the others of a list
+	e->k1h_wanted = !(cfg->flags & NTC_FLAG_TILED_TEAMS);
+	e->d_k1h_tabs.assign(e->klist.size(), nullptr);
+	e->d_k1h_fix.assign(e->klist.size(), nullptr);
+	if (e->ts_ok && e->k1h_wanted) {
+		for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+			const uint32_t k = e->klist[ki];
+			if (!ntc::sketch_k1h_supports(k, e->s_bits, e->r_bits)) continue;
+			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);
+			ntc::build_k1h_table(k, e->r_bits, tab.data());
+			uint32_t* d = nullptr;
+			if (hipMalloc((void**)&d, tab.size() * 4) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+				if (d) (void)hipFree(d);
+				ntc_destroy(e);
+				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the tiled kernel on device");
+			}
+			e->d_k1h_tabs[ki] = d;
+			std::vector<unsigned char> ftab(ntc::k1h_fix_tables_bytes());
+			ntc::build_k1h_fix_tables(k, ftab.data());
+			void* df = nullptr;
+			if (hipMalloc(&df, ftab.size()) != hipSuccess || hipMemcpy(df, ftab.data(), ftab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+				if (df) (void)hipFree(df);
+				ntc_destroy(e);
+				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the fix-up tables of the tiled kernel on device");
+			}
+			e->d_k1h_fix[ki] = df;
+		}
+	}
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
 	e->defer_redo = (cfg->flags & NTC_FLAG_DEFER_REDO) != 0;
 	e->hfk.resize(e->klist.size());
@@ -998,6 +1072,12 @@ void ntc_destroy(ntc_engine* e)
 	}
 	for (void* d : e->d_t4s)
 		if (d) (void)hipFree(d);
+	for (uint32_t* d : e->d_k1h_tabs)
+		if (d) (void)hipFree(d);
+	for (void* d : e->d_k1h_fix)
+		if (d) (void)hipFree(d);
+	if (e->d_dirty) (void)hipFree(e->d_dirty);
+	if (e->d_tie) (void)hipFree(e->d_tie);
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);

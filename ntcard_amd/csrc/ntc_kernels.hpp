@@ -121,7 +121,33 @@ hipError_t launch_sketch_ts(const TsArgs& a, unsigned grid, hipStream_t st);
 hipError_t set_sketch_ts_smem_limit(size_t smem);
 size_t sketch_ts_smem(uint32_t k);
 bool sketch_ts_supports(uint32_t k, uint32_t s_bits);
-// row-major slots -> tiled layout (and back): device-side re-layout for callers that hold the other form
+// K1h + K1f (ntc_sketch_k1h.hip; kernel body generated by gen_k1h.py): one wave per tile.  The generated code reads the first 88 bytes
+// with scalar loads at the offsets of gen_k1h.KARG — keep the two in step (static_asserts in ntc_sketch_k1h.hip).
+struct K1hArgs {
+	const unsigned char* tiles;   // tiled slots (as TsArgs)
+	uint32_t* log;                // hit log, [log_regions][log_region_cap] (log_regions == 0: direct atomics on sketch0)
+	uint32_t* log_fill;
+	uint32_t* sketch0;
+	unsigned long long* f1;
+	uint32_t* dirty;              // [n_tiles][n_chunks][64]: bit m of word (t, c, lane) = the 16-byte piece of read 64 m + lane holds a non-ACGTU byte
+	uint32_t* tie;                // [n_tiles][blocks][64]: bit m = some window of that block of that read has both strands flagged
+	uint32_t n_tiles, n_chunks;
+	uint32_t read_len, nv_last;   // nv_last: reads in the last tile (1 .. 2048)
+	uint32_t key_base, rmask2;    // rmask2 = (2 << r_bits) - 1: the counter index and the sample bit of a table word
+	uint32_t log_regions, log_region_cap;
+	const uint32_t* table;        // build_k1h_table
+	uint32_t s_bits, r_bits;
+	uint32_t blocks_per_wave;     // ceil(n_tiles * blocks / waves of the launch): wave w walks that many consecutive blocks from w * blocks_per_wave
+	uint32_t nb_magic;            // floor(2^32 / blocks)
+};
+bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits);
+uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len);
+void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
+hipError_t set_sketch_k1h_smem_limit();
+void build_k1h_fix_tables(uint32_t k, void* out /* k1h_fix_tables_bytes() */);
+size_t k1h_fix_tables_bytes();
+hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, const void* fix_tables, unsigned cus, hipStream_t st);
+// tiled layout -> row-major slots: device-side re-layout for the configurations the tiled kernels are not built for
 hipError_t launch_gen_tiled(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint32_t dist, uint64_t glen, hipStream_t st);
 hipError_t launch_untile(const unsigned char* tiles, unsigned char* slots, uint64_t n_reads, uint32_t read_len, uint32_t stride, hipStream_t st);
 

@@ -1,0 +1,346 @@
+// ntc_sketch_k1h.hip — K1h + K1f: the round-4 kernel pair for equal-length batches in the TILED slot layout on gfx950.
+//
+// What the pair computes is ntRead + ntComp (ntcard.cpp:132-158) for one k of 12 .. 32: for every window of k consecutive
+// ACGTU bases the canonical ntHash (nthash.hpp:242-257,275-279), ntComp's two sampling patterns on its top bits, one increment
+// of t_Counter[sample][hash & (rBuck - 1)] per sampled window (as a hit-log entry, ntc_apply.hip), and F1.
+//
+// K1h (sketch_k1h_kernel): ONE wave per 2048-read tile, six waves per CU, no wave ever waits for another.  Its body is a
+// generated assembly string (gen_k1h.py: explicit physical registers — 62 bit-sliced state planes, 96 base planes, 32 registers
+// of loads in flight, exactly 255 VGPRs; the same instruction list runs on the CPU in tests/test_k1h_emulator.py).  C++ here only
+// stages the closed-form table in LDS and hands the kernel-argument pointer to the asm statement.  K1h resolves every sampled
+// window it is SURE about; it drops every candidate of a (read, block) whose three chunks hold a 16-byte piece with a
+// non-ACGTU byte, and every window whose two strands tie on the top 8 bits, and leaves one bit per such (read, chunk) /
+// (read, block) in two arrays at fixed positions.
+//
+// K1f (k1h_fixup_kernel): ntHashIterator's semantics (ntHashIterator.hpp:59-86: a window with a non-ACGTU byte yields nothing)
+// from the raw bytes for exactly those (read, block) pairs: validity of every window that ends in the block, F1 taken back for
+// the invalid ones, canonical 64-bit hash -> ntComp -> increment for the valid ones (dirty blocks) or for the windows both
+// strands flag (tie blocks).  A lane walks one dirty piece's blocks with the plain rolling recurrence (nthash.hpp:242-257).
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "ntc_kernels.hpp"
+
+namespace ntc {
+
+namespace {
+
+#include "ntc_k1h_gen.inc"
+
+static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && offsetof(K1hArgs, log_fill) == 16 && offsetof(K1hArgs, sketch0) == 24 &&
+                  offsetof(K1hArgs, f1) == 32 && offsetof(K1hArgs, dirty) == 40 && offsetof(K1hArgs, tie) == 48 && offsetof(K1hArgs, n_tiles) == 56 &&
+                  offsetof(K1hArgs, n_chunks) == 60 && offsetof(K1hArgs, read_len) == 64 && offsetof(K1hArgs, nv_last) == 68 && offsetof(K1hArgs, key_base) == 72 &&
+                  offsetof(K1hArgs, rmask2) == 76 && offsetof(K1hArgs, log_regions) == 80 && offsetof(K1hArgs, log_region_cap) == 84 && offsetof(K1hArgs, table) == 88 &&
+                  offsetof(K1hArgs, blocks_per_wave) == 104 && offsetof(K1hArgs, nb_magic) == 108,
+              "gen_k1h.KARG");
+constexpr uint32_t kK1hWaves = 6;
+constexpr uint32_t kK1hWArea = 25600;
+constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
+
+#define K1H_CLOBBERS_V                                                                                                                 \
+	"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20",   \
+	    "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",   \
+	    "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58",   \
+	    "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",   \
+	    "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",   \
+	    "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",  \
+	    "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129",       \
+	    "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145",       \
+	    "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161",       \
+	    "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177",       \
+	    "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193",       \
+	    "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209",       \
+	    "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225",       \
+	    "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241",       \
+	    "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254"
+#define K1H_CLOBBERS_S "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "memory"
+
+} // namespace
+
+template <int K>
+__global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	{ // the closed-form table: [2 strands][ceil(k / 3)][64] dwords behind the six wave areas
+		constexpr uint32_t n = 2u * ((K + 2) / 3) * 64u;
+		uint32_t* dst = reinterpret_cast<uint32_t*>(smem + kK1hTableOff);
+		for (uint32_t i = threadIdx.x; i < n; i += 384u)
+			dst[i] = a.table[i];
+	}
+	__syncthreads();
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const uint32_t wave_gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kK1hWaves + wave));
+	const uint32_t n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * kK1hWaves));
+	const uint32_t lds_wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kK1hWArea));
+	const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+	const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)karg);
+	const uint32_t karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(karg >> 32));
+	static_assert(K == 32, "gen_k1h.py emits this k");
+	asm volatile(K1H_ASM_K32_S7 ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S);
+}
+
+// ---- K1f ------------------------------------------------------------------------------------------------------------------------
+// Work items come from the two bit arrays K1h leaves behind:
+//   dirty piece (read r, chunk c): the item covers the blocks n in {c, c + 1, c + 2} (n < NB) for which c is the LAST dirty chunk of r
+//   among n - 2 .. n — every dirty-affected (read, block) pair has exactly one owner — i.e. the window ends e in
+//   [16 c - 16 + phi, 16 n_hi + phi), phi = (k - 1) mod 16 (gen_k1h.py).  Every window ending there is examined: invalid ones leave F1,
+//   valid ones take ntComp's test (ntcard.cpp:132-145) on their canonical hash (nthash.hpp:275-279).
+//   tie bit (read r, block b), never in a dirty-affected block: the windows ending in the block whose two strands BOTH carry a
+//   candidate flag (gen_k1h.py, strand_flags) are the ones K1h left out.
+// A wave compacts items into an LDS queue and walks 64 of them at a time, one per lane: the lane's <= 6 raw 16-byte pieces are
+// staged in LDS, then one rolling step per position (nthash.hpp:242-257) with the per-byte terms of two 256-entry tables:
+//   in[b]  = { seed(b), srol^k(comp(b)) },  out[b] = { srol^k(seed(b)), comp(b) },  each 64-bit value as {H | L[32] << 31, L[0..31]}
+// (H: the 31-bit field, L: the 33-bit one, nthash.hpp:186-217); seed(b) == 0 marks a byte that is no base.  The walk starts from
+// the hash of k 'A's and lets 'A's leave the window until k real bases are in (as K1h does): no separate filling recurrence.
+struct FixTables {
+	uint4 in[256], out[256];
+	uint32_t poly_a[4]; // hash of k 'A's: {f.w0, f.w1, r.w0, r.w1}
+};
+constexpr uint32_t kFixQCap = 192;
+constexpr uint32_t kFixStage = 7 * 16; // bytes per lane: up to 7 pieces (k - 1 + 48 positions, any alignment)
+
+__device__ __forceinline__ uint32_t ballot_rank(uint64_t m)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const FixTables* __restrict__ ft, uint32_t k)
+{
+	__shared__ uint4 s_in[256], s_out[256];
+	__shared__ uint2 s_queue[4][kFixQCap];
+	__shared__ __align__(16) unsigned char s_stage[4][64 * kFixStage];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	s_in[tid] = ft->in[tid];
+	s_out[tid] = ft->out[tid];
+	__syncthreads();
+	const uint32_t phi = (k - 1u) & 15u;
+	const uint32_t nb = ((a.read_len - 1u + 16u - phi) >> 4) + 1u, C = a.n_chunks;
+	const uint64_t n_dirty = (uint64_t)a.n_tiles * C * 64u, n_tie = (uint64_t)a.n_tiles * nb * 64u;
+	const uint32_t pa0 = ft->poly_a[0], pa1 = ft->poly_a[1], pa2 = ft->poly_a[2], pa3 = ft->poly_a[3];
+	const uint32_t s_bits = a.s_bits, r_bits = a.r_bits, L = a.read_len;
+	const uint32_t rmask = (1u << r_bits) - 1u;
+	uint2* const queue = s_queue[wv];
+	unsigned char* const stage = s_stage[wv] + lane * kFixStage;
+	uint32_t qhead = 0, qtail = 0; // wave-uniform
+	uint32_t f1_sub = 0;
+
+	// ---- walk the 64 (or fewer) items at the head of the queue ----
+	auto walk = [&](uint32_t n_items) {
+		const bool act = lane < n_items;
+		const uint2 it = queue[(qhead + (act ? lane : 0u)) % kFixQCap];
+		const uint32_t t = it.x, r = it.y & 2047u, c = (it.y >> 11) & 0x1fffu, nblk = (it.y >> 24) & 3u;
+		const bool ties = (it.y >> 26) & 1u;
+		int e_lo = 16 * (int)c - 16 + (int)phi, e_hi = 16 * (int)(c + nblk - 1u) + (int)phi - 1;
+		e_lo = max(e_lo, (int)k - 1);
+		e_hi = min(e_hi, (int)L - 1);
+		const int p0 = e_lo - (int)k + 1;
+		int len = act && e_hi >= e_lo ? e_hi - p0 + 1 : 0; // positions to walk
+		// stage the pieces [p0 >> 4, e_hi >> 4] of the read
+		const unsigned char* tile = a.tiles + (size_t)t * C * (kTileReads * 16u);
+		const int c0 = p0 >> 4, np = len > 0 ? (e_hi >> 4) - c0 + 1 : 0;
+#pragma unroll
+		for (int j = 0; j < 7; ++j)
+			if (j < np) *reinterpret_cast<uint4*>(stage + 16 * j) = *reinterpret_cast<const uint4*>(tile + ((size_t)(c0 + j) * kTileReads + r) * 16u);
+		// (a lane reads back only what it wrote itself: no barrier)
+		uint32_t f0 = pa0, f1 = pa1, r0 = pa2, r1 = pa3; // strand states {H | L[32] << 31, L[0..31]}
+		uint32_t good = 0;
+		const uint32_t off0 = (uint32_t)(p0 & 15);
+		const int first_end = e_lo - p0; // step index of the first window end
+		int max_len = len;
+		for (int o = 32; o > 0; o >>= 1)
+			max_len = max(max_len, __shfl_xor(max_len, o));
+		for (int i = 0; i < max_len; ++i) {
+			const bool on = i < len;
+			const uint32_t bi = stage[on ? off0 + (uint32_t)i : 0u];
+			const uint4 ein = s_in[bi];
+			if (on) {
+				if (ein.x == 0u) { // not a base: the window restarts behind it
+					good = 0;
+					f0 = pa0;
+					f1 = pa1;
+					r0 = pa2;
+					r1 = pa3;
+				} else {
+					++good;
+					const uint32_t bo = good > k ? stage[off0 + (uint32_t)i - k] : (uint32_t)'A';
+					const uint4 eo = s_out[bo];
+					// forward: srol by one, then the two terms (nthash.hpp:242-248)
+					const uint32_t nf1 = __builtin_amdgcn_alignbit(f1, f0, 31);
+					const uint32_t nf0 = ((f0 << 1) & 0x7ffffffeu) | ((f0 >> 30) & 1u) | (f1 & 0x80000000u);
+					f0 = nf0 ^ ein.x ^ eo.x;
+					f1 = nf1 ^ ein.y ^ eo.y;
+					// reverse: the two terms, then sror by one (nthash.hpp:251-257)
+					const uint32_t x0 = r0 ^ ein.z ^ eo.z, x1 = r1 ^ ein.w ^ eo.w;
+					r1 = __builtin_amdgcn_alignbit(x0 >> 31, x1, 1);
+					r0 = ((x0 & 0x7fffffffu) >> 1) | ((x0 & 1u) << 30) | (x1 << 31);
+				}
+				if (i >= first_end) {
+					if (good < k) {
+						if (!ties) ++f1_sub;
+					} else {
+						const uint32_t fH = f0 & 0x7fffffffu, rH = r0 & 0x7fffffffu;
+						bool take = true;
+						if (ties) {
+							const uint32_t f8 = fH >> 23, r8 = rH >> 23;
+							bool cf, cr;
+							if (s_bits == 7u) {
+								cf = ((f8 >> 1) == 0x3fu && (r8 >> 1) >= 0x3fu) || (f8 == 1u && r8 >= 1u);
+								cr = ((r8 >> 1) == 0x3fu && (f8 >> 1) >= 0x3fu) || (r8 == 1u && f8 >= 1u);
+							} else {
+								cf = (f8 == 0x7fu && r8 >= 0x7fu) || f8 == 0u;
+								cr = (r8 == 0x7fu && f8 >= 0x7fu) || r8 == 0u;
+							}
+							take = cf && cr;
+						}
+						// canonical strand (nthash.hpp:275-279): compare H, then L[32], then L[0..31]
+						const bool rev = rH != fH ? rH < fH : ((r0 ^ f0) >> 31) ? (r0 >> 31) < (f0 >> 31) : r1 < f1;
+						const uint32_t hH = rev ? rH : fH, hL = rev ? r1 : f1;
+						// ntComp (ntcard.cpp:132-145) on the top s_bits + 1 bits: all of them lie in H (s_bits <= 30)
+						uint32_t smp = 2;
+						if ((hH >> (30u - s_bits)) == 1u) smp = 0;
+						if ((hH >> (31u - s_bits)) == (1u << (s_bits - 1u)) - 1u) smp = 1;
+						if (take && smp < 2u) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(hL & rmask), 1u);
+					}
+				}
+			}
+		}
+		qhead += n_items;
+	};
+	auto push = [&](bool have, uint32_t x, uint32_t y) {
+		const uint64_t m = __builtin_amdgcn_ballot_w64(have);
+		if (have) queue[(qtail + ballot_rank(m)) % kFixQCap] = make_uint2(x, y);
+		qtail += (uint32_t)__popcll(m);
+		if (qtail - qhead >= 64u) walk(64u);
+	};
+
+	const uint64_t n_rows = (n_dirty + n_tie) / 64u; // rows of 64 words: (tile, chunk) of the dirty array, then (tile, block) of the tie array
+	const uint64_t wave_g = (uint64_t)blockIdx.x * 4u + wv, n_wv = (uint64_t)gridDim.x * 4u;
+	for (uint64_t row = wave_g; row < n_rows; row += n_wv) {
+		const bool is_d = row < n_dirty / 64u;
+		uint32_t word, t, c;
+		uint32_t d1 = 0, d2 = 0;
+		if (is_d) {
+			t = (uint32_t)(row / C);
+			c = (uint32_t)(row % C);
+			word = a.dirty[row * 64u + lane];
+			if (__builtin_amdgcn_ballot_w64(word != 0u) == 0) continue;
+			if (c + 1u < C) d1 = a.dirty[(row + 1u) * 64u + lane];
+			if (c + 2u < C) d2 = a.dirty[(row + 2u) * 64u + lane];
+			const uint32_t nv = t + 1u == a.n_tiles ? a.nv_last : kTileReads; // slots behind the batch's last read
+			const uint32_t groups = nv > lane ? (nv - lane + 63u) >> 6 : 0u;
+			word &= groups >= 32u ? 0xffffffffu : (1u << groups) - 1u;
+		} else {
+			const uint64_t j = row - n_dirty / 64u;
+			t = (uint32_t)(j / nb);
+			c = (uint32_t)(j % nb);
+			word = a.tie[j * 64u + lane];
+		}
+		while (__builtin_amdgcn_ballot_w64(word != 0u) != 0) {
+			const bool have = word != 0u;
+			const uint32_t m = have ? (uint32_t)__builtin_ctz(word) : 0u;
+			word &= word - 1u;
+			uint32_t nblk = 1;
+			if (is_d) { // blocks c .. c + 2 this piece is the last dirty chunk of
+				if (!((d1 >> m) & 1u)) nblk = ((d2 >> m) & 1u) ? 2u : 3u;
+				if (c + nblk > nb) nblk = nb - c;
+			}
+			const bool ok = have && (!is_d || c < nb);
+			push(ok, t, (64u * m + lane) | (c << 11) | (nblk << 24) | (is_d ? 0u : 1u << 26));
+		}
+	}
+	if (qtail != qhead) walk(qtail - qhead);
+	for (int o = 32; o > 0; o >>= 1)
+		f1_sub += (uint32_t)__shfl_xor((int)f1_sub, o);
+	if (lane == 0u && f1_sub != 0u) atomicAdd(a.f1, (unsigned long long)0 - (unsigned long long)f1_sub);
+}
+
+void build_k1h_fix_tables(uint32_t k, void* out_)
+{
+	FixTables* out = static_cast<FixTables*>(out_);
+	auto seed_b = [](unsigned c) -> uint64_t { // the reference's byte table (nthash.hpp:31-64)
+		switch (c) {
+		case 'A': case 'a': case 4: case 5: return kSeed[0];
+		case 'C': case 'c': case 7: return kSeed[1];
+		case 'G': case 'g': case 3: return kSeed[2];
+		case 'T': case 't': case 'U': case 'u': case 1: return kSeed[3];
+		default: return 0;
+		}
+	};
+	auto w0 = [](uint64_t x) { return (uint32_t)(x >> 33) | ((uint32_t)((x >> 32) & 1u) << 31); };
+	auto w1 = [](uint64_t x) { return (uint32_t)x; };
+	for (unsigned c = 0; c < 256; ++c) {
+		const uint64_t sd = seed_b(c), sc = seed_b(c & 7u); // complement = the table at byte & 7 (nthash.hpp:16)
+		if (sd == 0) {
+			out->in[c] = make_uint4(0, 0, 0, 0);
+			out->out[c] = make_uint4(0, 0, 0, 0);
+			continue;
+		}
+		const uint64_t tsc = srol(sc, k), tsd = srol(sd, k);
+		out->in[c] = make_uint4(w0(sd), w1(sd), w0(tsc), w1(tsc));
+		out->out[c] = make_uint4(w0(tsd), w1(tsd), w0(sc), w1(sc));
+	}
+	uint64_t fh = 0, rh = 0;
+	for (unsigned i = 0; i < k; ++i) {
+		fh ^= srol(seed_of(0), i);
+		rh ^= srol(comp_of(0), i);
+	}
+	out->poly_a[0] = w0(fh);
+	out->poly_a[1] = w1(fh);
+	out->poly_a[2] = w0(rh);
+	out->poly_a[3] = w1(rh);
+}
+size_t k1h_fix_tables_bytes() { return sizeof(FixTables); }
+
+bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits) { return k == 32 && s_bits == 7 && r_bits <= 30; }
+
+uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len) { return ((read_len - 1u + 16u - ((k - 1u) & 15u)) >> 4) + 1u; }
+
+// closed-form table of the resolve passes: [strand][group g][64 values] dwords, 3 bases per entry (code2 order: A=0 C=1 T/U=2 G=3, base t
+// of the group in bits 2t+1:2t).  Word = low r_bits bits of the strand's term (nthash.hpp:220-239: fh = XOR srol^(k-1-i) seed(c_i),
+// rh = XOR srol^i comp(c_i)) | its bit 62 << r_bits: ntComp's patterns differ in that bit, and the counter index is
+// key_base + (sample << r_bits) + (hash & (rBuck - 1)) (ntcard.cpp:132-145)
+void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t* out)
+{
+	static const unsigned code_of_code2[4] = { 0, 1, 3, 2 };
+	const uint32_t ng = (k + 2) / 3;
+	for (uint32_t st = 0; st < 2; ++st)
+		for (uint32_t g = 0; g < ng; ++g)
+			for (uint32_t v = 0; v < 64; ++v) {
+				uint64_t x = 0;
+				for (uint32_t t = 0; t < 3; ++t) {
+					const uint32_t i = 3 * g + t;
+					if (i >= k) break;
+					const unsigned c = code_of_code2[(v >> (2 * t)) & 3u];
+					x ^= st == 0 ? srol(seed_of(c), k - 1 - i) : srol(comp_of(c), i);
+				}
+				out[(st * ng + g) * 64 + v] = (uint32_t)(x & ((1ull << r_bits) - 1ull)) | ((uint32_t)((x >> 62) & 1u) << r_bits);
+			}
+}
+
+hipError_t set_sketch_k1h_smem_limit()
+{
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, const void* fix_tables, unsigned cus, hipStream_t st)
+{
+	if (k != 32) return hipErrorInvalidValue;
+	const uint32_t nb = sketch_k1h_blocks(k, a.read_len);
+	const uint64_t total = (uint64_t)a.n_tiles * nb; // blocks of the batch, shared out evenly: a wave needs at least ~4 blocks to be worth its start-up
+	const unsigned grid = (unsigned)std::min<uint64_t>((total + 4 * kK1hWaves - 1) / (4 * kK1hWaves), cus);
+	K1hArgs b = a;
+	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
+	b.nb_magic = (uint32_t)((1ull << 32) / nb);
+	hipLaunchKernelGGL((sketch_k1h_kernel<32>), dim3(grid), dim3(384), 160 * 1024, st, b);
+	hipError_t rc = hipGetLastError();
+	if (rc != hipSuccess) return rc;
+	const size_t rows = (size_t)a.n_tiles * (a.n_chunks + nb);
+	const unsigned fgrid = (unsigned)std::min<size_t>((rows + 3) / 4, (size_t)cus * 4);
+	hipLaunchKernelGGL(k1h_fixup_kernel, dim3(fgrid), dim3(256), 0, st, b, static_cast<const FixTables*>(fix_tables), k);
+	return hipGetLastError();
+}
+
+} // namespace ntc

@@ -20,6 +20,7 @@ FLAG_ALWAYS_LOG = 8  # NTC_FLAG_ALWAYS_LOG: never switch from the hit log to dir
 FLAG_PARTITION_ALWAYS = 16  # NTC_FLAG_PARTITION_ALWAYS: small logs go through the partition passes too (validation)
 FLAG_DEFER_REDO = 128  # NTC_FLAG_DEFER_REDO: submit_device buffers stay unchanged until sync(); the handed-back reads of several batches share one pass
 FLAG_REQUIRE_TILED = 64  # NTC_FLAG_REQUIRE_TILED: submit_tiled_device fails instead of falling back to the general kernel
+FLAG_TILED_TEAMS = 256  # NTC_FLAG_TILED_TEAMS: tiled batches through K1c (teams of four waves) instead of K1h (one wave per tile)
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 

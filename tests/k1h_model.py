@@ -1,0 +1,161 @@
+"""k1h_model.py — CPU-side harness of the K1h kernel (ntcard_amd/csrc/gen_k1h.py): runs the GENERATED instruction list on the wave
+emulator (k1h_asm.Emu) and models K1f, the fix-up kernel, in plain Python.  Test infrastructure only.
+
+K1h's contract (gen_k1h.py): per wave it appends one hit-log key per sampled window it is sure about, adds valid-reads x windows to
+F1, and leaves two bit arrays behind — dirty[tile][chunk][lane] (bit m: the 16-byte piece of read 64 m + lane holds a non-ACGTU
+byte) and tie[tile][block][lane] (bit m: some window of that block has both strands flagged).  K1f owns every (read, block) whose
+chunks b-2 .. b hold a dirty piece (all windows ending in the block: validity, F1 correction, hits) and, in the other blocks, the
+windows both strands flag (hit through the canonical strand, nthash.hpp:275-279).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ntcard_amd", "csrc"))
+
+import gen_k1h  # noqa: E402
+from k1h_asm import Emu  # noqa: E402
+import orc  # noqa: E402
+
+CODE2_OF = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3, ord("U"): 2, ord("a"): 0, ord("c"): 1, ord("t"): 2, ord("g"): 3, ord("u"): 2}
+BASE_OF_CODE2 = "ACTG"
+
+
+def build_table(k, r_bits, s_bits):
+    """[2][ng][64] uint32: 3 bases per entry (code2, base t of the group in bits 2t+1:2t); word = low r_bits bits of the strand's
+    closed-form term (nthash.hpp:220-239) | its bit 62 << r_bits (s_bits == 7: tells sample 1 from sample 0)"""
+    L = orc.lib()
+    ng = gen_k1h.n_groups(k)
+    out = np.zeros((2, ng, 64), dtype=np.uint32)
+    for g in range(ng):
+        for val in range(64):
+            f = r = 0
+            for t in range(3):
+                i = 3 * g + t
+                if i >= k:
+                    break
+                base = BASE_OF_CODE2[(val >> (2 * t)) & 3]
+                f ^= L.orc_srol(L.orc_seed(ord(base)), k - 1 - i)
+                r ^= L.orc_srol(L.orc_seed_comp(ord(base)), i)
+            for st, x in ((0, f), (1, r)):
+                assert s_bits == 7
+                out[st, g, val] = (x & ((1 << r_bits) - 1)) | (((x >> 62) & 1) << r_bits)
+    return out
+
+
+class Layout:
+    """flat device memory for the emulator"""
+
+    def __init__(self, nbytes):
+        self.mem = np.zeros(nbytes, dtype=np.uint8)
+        self.top = 256
+
+    def alloc(self, nbytes, align=256):
+        self.top = (self.top + align - 1) // align * align
+        a = self.top
+        self.top += nbytes
+        assert self.top <= self.mem.size
+        return a
+
+
+def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True):
+    """-> dict(keys=uint32[], f1=int, dirty=[n_tiles][C][64], tie=[n_tiles][NB][64], insts=executed per wave)"""
+    Cn = (read_len + 15) // 16
+    n_tiles = (n_reads + 2047) // 2048
+    phi = (k - 1) % 16
+    NB = ((read_len - 1 + 16 - phi) >> 4) + 1
+    if log_regions is None:
+        log_regions = n_waves * 4
+    lay = Layout(tiles.size + (1 << 22) + log_regions * log_region_cap * 4 + (4 << (r_bits + 1)))
+    a_karg = lay.alloc(256)
+    a_tiles = lay.alloc(tiles.size)
+    a_log = lay.alloc(log_regions * log_region_cap * 4)
+    a_fill = lay.alloc(log_regions * 4)
+    a_sk = lay.alloc(4 << (r_bits + 1))
+    a_f1 = lay.alloc(8)
+    a_dirty = lay.alloc(n_tiles * Cn * 256)
+    a_tie = lay.alloc(n_tiles * NB * 256)
+    mem = lay.mem
+    mem[a_tiles:a_tiles + tiles.size] = tiles
+    m32, m64 = mem.view(np.uint32), mem.view(np.uint64)
+    K = gen_k1h.KARG
+    for name, val in (("tiles", a_tiles), ("log", a_log), ("log_fill", a_fill), ("sketch0", a_sk), ("f1", a_f1), ("dirty", a_dirty), ("tie", a_tie)):
+        m64[(a_karg + K[name]) // 8] = val
+    nv_last = n_reads - (n_tiles - 1) * 2048
+    for name, val in (("n_tiles", n_tiles), ("n_chunks", Cn), ("read_len", read_len), ("nv_last", nv_last), ("key_base", 0),
+                      ("rmask2", (2 << r_bits) - 1), ("log_regions", log_regions if use_log else 0), ("log_region_cap", log_region_cap)):
+        m32[(a_karg + K[name]) // 4] = val
+    total = n_tiles * NB
+    m32[(a_karg + K["blocks_per_wave"]) // 4] = (total + n_waves - 1) // n_waves
+    m32[(a_karg + K["nb_magic"]) // 4] = (1 << 32) // NB
+    lds = np.zeros(gen_k1h.LDS_BYTES, dtype=np.uint8)
+    tab = build_table(k, r_bits, s_bits)
+    lds.view(np.uint32)[gen_k1h.TABLE_OFF // 4: gen_k1h.TABLE_OFF // 4 + tab.size] = tab.reshape(-1)
+    prog = gen_k1h.Gen(k, 7 if s_bits == 7 else 8).build(emu=True)
+    insts = []
+    for w in range(n_waves):
+        e = Emu(prog, mem, lds)
+        rng = np.random.default_rng(w)
+        e.V[:] = rng.integers(0, 1 << 32, size=e.V.shape, dtype=np.uint64).astype(np.uint32)  # registers start as garbage
+        e.S[0], e.S[1] = a_karg & 0xFFFFFFFF, a_karg >> 32
+        e.S[2], e.S[3], e.S[4] = w, n_waves, (w % gen_k1h.WAVES) * gen_k1h.WAREA
+        e.run()
+        insts.append(e.executed)
+    fill = m32[a_fill // 4: a_fill // 4 + log_regions]
+    keys = [m32[a_log // 4 + rgn * log_region_cap: a_log // 4 + rgn * log_region_cap + int(fill[rgn])] for rgn in range(log_regions)]
+    keys = np.concatenate(keys) if keys else np.zeros(0, dtype=np.uint32)
+    sk = m32[a_sk // 4: a_sk // 4 + (2 << r_bits)].copy()
+    return dict(keys=keys.copy(), sketch=sk, f1=int(m64[a_f1 // 8]), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
+                tie=m32[a_tie // 4: a_tie // 4 + n_tiles * NB * 64].reshape(n_tiles, NB, 64).copy(), insts=insts, NB=NB, C=Cn)
+
+
+def flags_of(fh, rh, s_bits):
+    """K1h's per-strand candidate flags from the top 8 bits of both strands (gen_k1h.Gen.strand_flags)"""
+    f8, r8 = fh >> 56, rh >> 56
+    if s_bits == 7:
+        def fl(x):
+            return (x >> 1) == 0x3f, (x >> 1) >= 0x3f, x == 1, x >= 1
+        fa, fg, fb, fnz = fl(f8)
+        ra, rg, rb, rnz = fl(r8)
+        return (fa and rg) or (fb and rnz), (ra and fg) or (rb and fnz)
+    fa, fg, fb = f8 == 0x7f, f8 >= 0x7f, f8 == 0
+    ra, rg, rb = r8 == 0x7f, r8 >= 0x7f, r8 == 0
+    return (fa and rg) or fb, (ra and fg) or rb
+
+
+def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie):
+    """-> (keys list, f1_sub) of the fix-up kernel"""
+    L = orc.lib()
+    phi = (k - 1) % 16
+    NB = ((read_len - 1 + 16 - phi) >> 4) + 1
+    Cn = (read_len + 15) // 16
+    keys, f1_sub = [], 0
+    fh, rh, bad = C.c_uint64(), C.c_uint64(), C.c_uint()
+    for r, seq in enumerate(reads):
+        t, lane, m = r // 2048, (r % 2048) % 64, (r % 2048) // 64
+        for b in range(NB):
+            aff = any(0 <= c < Cn and (int(dirty[t, c, lane]) >> m) & 1 for c in (b - 2, b - 1, b))
+            tb = (int(tie[t, b, lane]) >> m) & 1
+            if not (aff or tb):
+                continue
+            for e in range(max(16 * b - 16 + phi, k - 1), min(16 * b + phi - 1, read_len - 1) + 1):
+                win = seq[e - k + 1: e + 1]
+                ok = L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad))
+                if aff:
+                    if not ok:
+                        f1_sub += 1
+                        continue
+                else:
+                    assert ok
+                    cf, cr = flags_of(fh.value, rh.value, s_bits)
+                    if not (cf and cr):
+                        continue
+                h = min(fh.value, rh.value)
+                if (h >> (63 - s_bits)) == 1:
+                    keys.append(h & ((1 << r_bits) - 1))
+                elif (h >> (64 - s_bits)) == (1 << (s_bits - 1)) - 1:
+                    keys.append((1 << r_bits) + (h & ((1 << r_bits) - 1)))
+    return keys, f1_sub
