@@ -304,7 +304,7 @@ def main():
                     flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
                     | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0) | (nt.FLAG_TILED_TEAMS if args.teams else 0)
                     | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0)
-                    | (0 if tiled else nt.FLAG_DEFER_REDO))
+                    | nt.FLAG_DEFER_REDO)  # (tiled batches too: the fix-up kernels of batch i then run beside the hash kernel of batch i + 1)
 
     def submit(buf):
         if tiled:
@@ -351,6 +351,7 @@ def main():
 
     ker_ms, launches = eng.kernel_time()
     apply_ms, applies = eng.apply_time()
+    fix_ms = eng.fixup_time()
     update_mode = eng.update_mode()
     if ph_merged is not None:
         eng.sync()
@@ -377,10 +378,12 @@ def main():
         read_bytes = R * (L + 4)
         alg_bytes = read_bytes + 4.0 * per_step_hits
         hash_ms = ker_ms / max(K, 1)
-        step_ms = (ker_ms + apply_ms) / max(K, 1)
+        step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: K1f on the side stream, counted in full although it overlaps the next hash launch)
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
-        if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
+        if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits == 7 and not args.lane_kernel and not args.teams:
+            kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_f1 / k1h_suspect kernels (K1f, side stream)"
+        elif tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
             kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"
         elif (nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255 and not tiled
               and (args.bitslice or (R >= 2048 * 128 and L - 31 >= 97 and not args.lane_kernel and not args.direct_atomics))):
@@ -412,7 +415,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),
                          "kernel": kern + " + split_kernel / count_kernel (deferred sketch update)",
-                         "avg_launch_ms": step_ms, "hash_ms": hash_ms, "apply_ms": apply_ms / max(K, 1), "launches": launches,
+                         "avg_launch_ms": step_ms, "hash_ms": hash_ms, "apply_ms": apply_ms / max(K, 1), "fixup_ms": fix_ms / max(K, 1), "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_step_kmers},
             # the hash kernels alone against the read stream alone (what the sketch update costs is in "roofline" above)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NTC_ABI_VERSION 2
+#define NTC_ABI_VERSION 4
 #define NTC_MAX_K_LIST 32
 
 typedef enum {
@@ -224,6 +224,9 @@ int ntc_hll_estimate(const uint8_t *regs, uint32_t n_bits, double *est_out);
 int ntc_kernel_time(ntc_engine *e, double *ms_total, uint64_t *launches);
 /* same for the deferred sketch update (partition + count passes): milliseconds and number of applies */
 int ntc_apply_time(ntc_engine *e, double *ms_total, uint64_t *applies);
+/* same for the fix-up kernels of the one-wave-per-tile kernel when they run on the engine's side stream (NTC_FLAG_DEFER_REDO engines: beside
+ * the next batch's hash kernel, so this time is NOT part of ntc_kernel_time; without the flag they run on the engine's stream and are) */
+int ntc_fixup_time(ntc_engine *e, double *ms_total);
 int ntc_set_profiling(ntc_engine *e, int enable);
 /* how ntComp's increment is currently carried out on the device: 0 = hit log + partitioned apply, 1 = direct atomics
  * (NTC_FLAG_DIRECT_ATOMICS, or chosen by the engine after an apply found mostly repeated counters); waits for the stream */

@@ -56,8 +56,9 @@ def table_bytes(k):
 
 # ---- register map ------------------------------------------------------------------------------------------
 # VGPRs
-V_LANE4, V_LANE16, V_LANE8, V_QBASE, V_SPARE0, V_ONE, V_EXP1, V_VMASK = range(0, 8)
+V_LANE4, V_LANE16, V_LANE8, V_QBASE, V_WAVE4, V_ONE, V_EXP1, V_VMASK = range(0, 8)  # V_WAVE4: 4 x the wave's number in the launch
 V_D0, V_D1, V_D2, V_DN, V_CMASK, V_TACC, V_CARRY0, V_CARRY1, V_SPARE1 = range(8, 17)
+V_DMASK = 17       # reads of this block with a dirty piece in one of its three chunks (and valid): their candidates are SUSPECTS
 V_F = 18           # F[31]   (register tuples — loads, 64-bit LDS items — must start at even registers on gfx90a+)
 V_R = 49           # R[31]
 V_H0 = 80          # chunk n-2 planes / P_next
@@ -67,7 +68,10 @@ V_RAW = 176        # 8 slots x 4
 V_T = 208          # temps 208 .. 252
 V_PX = V_T         # forward candidate item (x, y)
 V_RX = V_T + 2     # reverse candidate item
-V_T0 = V_T + 4     # scratch: V_T0 .. V_T0 + 29 (walk, pack, pass); the transpose uses V_T .. V_T + 31
+V_SXF = V_T + 4    # the same for suspects
+V_SXR = V_T + 6
+V_T0 = V_T + 4     # scratch of the walk / test / pack: V_T0 .. V_T0 + 29 (the suspect pairs are written behind the test, whose scratch they share)
+V_TP = V_T + 8     # scratch of the resolve pass: V_TP .. V_TP + 25; the transpose uses V_T .. V_T + 31
 # constants that VOP3 instructions cannot take as literals (gfx9: one SGPR or inline constant per instruction, no 32-bit literal)
 V_CMUL, V_CPERMLO, V_CPERMHI, V_CP16A, V_CP16B, V_CP8A, V_CP8B, V_CM4, V_CM2, V_CM1, V_CQMASK8 = [V_T0 + 30 + i for i in range(11)]
 assert V_CQMASK8 <= 254
@@ -92,18 +96,17 @@ S_EXP0 = _salloc()
 S_CHUNKB = _salloc()         # bytes of one tile's slots = C * 32768 (the product with the tile index is 64-bit)
 S_DESC = _salloc(4, 4)       # tile being loaded
 S_TILES = _salloc(2, 2)
-S_LOG = _salloc(2, 2)
-S_LOGFILL = _salloc(2, 2)
 S_SK = _salloc(2, 2)
-S_F1P = _salloc(2, 2)
+S_SUS = _salloc(2, 2)        # this wave's region of the suspect list
 S_DIRTY = _salloc(2, 2)
 S_TIE = _salloc(2, 2)
 S_LOGBASE = _salloc(2, 2)    # current log region
 S_RET = _salloc(2, 2)
 S_F1ACC = _salloc(2, 2)
 S_TMP = _salloc(2, 2)        # 64-bit scratch
-S_KARG = _salloc(2, 2)
-S_F0, S_S0 = S_KARG, S_KARG + 1   # (the kernel-argument pointer is dead once the arguments are loaded) first block this wave owns / walks
+S_KARG = _salloc(2, 2)       # kept: the pointers needed once in a while (log, log_fill, f1) are re-read from the kernel arguments
+S_F0, S_S0 = _salloc(), _salloc()  # first block this wave owns / walks
+S_SUSOFF, S_SUSCAP = _salloc(), _salloc()  # bytes used / capacity of the suspect region
 S_NTILES, S_C, S_L, S_NVLAST, S_KEYBASE, S_RMASK2, S_LOGREG, S_LOGCAP4 = [_salloc() for _ in range(8)]  # (loaded in this order)
 S_NB, S_FEND = _salloc(), _salloc()
 S_WF = _salloc()             # flat index (tile * NB + block) of the block being walked
@@ -121,13 +124,13 @@ S_SPARE = _salloc()
 S_END = _sn[0]
 assert S_END <= 100, S_END
 
-S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_F1P)  # timing build only (S_F1P + 1 = the last time stamp, the pointer itself waits in two VGPRs): no F1
+S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCAP = the last time stamp): no F1, no suspects
 
 # the asm statement's "s" operands, in order
 INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase"]
 # byte offsets in struct K1hArgs (ntc_kernels.hpp); the kernel reads them with scalar loads
 KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_tiles=56, n_chunks=60, read_len=64, nv_last=68, key_base=72,
-            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108)
+            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128)
 
 
 class Gen:
@@ -169,9 +172,9 @@ class Gen:
         p = self.p
         p.i("s_memtime", sr(S_TMP, 2))
         p.i("s_waitcnt", "lgkmcnt(0)")
-        p.i("s_sub_u32", s(S_N), s(S_TMP), s(S_F1P + 1))
+        p.i("s_sub_u32", s(S_N), s(S_TMP), s(S_SUSCAP))
         p.i("s_add_u32", s(S_TACC[sec]), s(S_TACC[sec]), s(S_N))
-        p.i("s_mov_b32", s(S_F1P + 1), s(S_TMP))
+        p.i("s_mov_b32", s(S_SUSCAP), s(S_TMP))
 
     # ---- poly-A start state (gen_ts.poly_a_state) ----
     def poly_a(self, strand):
@@ -316,12 +319,34 @@ class Gen:
         p.i("v_and_b32", v(tie), v(cf), v(cr))
         self.bitop3(v(V_PX), v(cf), v(V_CMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
         self.bitop3(v(V_RX), v(cr), v(V_CMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
-        self.bitop3(v(V_TACC), v(V_TACC), v(tie), v(V_CMASK), lambda x, y, z: x | (y & z))
-        # room for the new items?  (count + nF + nR <= QCAP, else resolve passes first; a pass keeps PX / RX and nothing else)
+        sus = "timers" not in self.exp
+        if sus:
+            # suspects: candidates of reads with a dirty piece near by — resolved like the others, then parked for K1f, which knows the bytes
+            # ... and windows whose strands tie on the top bits: they ride along in the forward word (K1f re-derives every suspect's hash from
+            # the bytes, so the strand it is queued under does not matter)
+            p.i("v_and_b32", v(tie), v(tie), v(V_VMASK))
+            self.bitop3(v(V_SXF), v(cf), v(V_DMASK), v(tie), lambda x, y, z: (x & y) | z)
+            self.bitop3(v(V_SXR), v(cr), v(V_DMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
+            p.i("v_or_b32", v(V_TACC), v(V_TACC), v(tie))  # (the tie array serves K1f's slow path only)
+        else:
+            self.bitop3(v(V_TACC), v(V_TACC), v(tie), v(V_CMASK), lambda x, y, z: x | (y & z))
+        self.push_items(a, V_PX, V_RX, 0)
+        if sus:
+            nosus = self.lbl("nosus")
+            p.i("v_or_b32", v(T + 4), v(V_SXF), v(V_SXR))
+            p.i("v_cmp_ne_u32_e32", "vcc", 0, v(T + 4))
+            p.i("s_cbranch_vccz", "@" + nosus)
+            self.push_items(a, V_SXF, V_SXR, 1)
+            p.label(nosus)
+
+    def push_items(self, a, xf, xr, suspect):
+        """queue the two hit words (register pairs xf, xr: word + meta) of step a; resolve passes first while the queue lacks room"""
+        p = self.p
+        T = V_TP
         chk, go = self.lbl("chk"), self.lbl("go")
         p.label(chk)
-        p.i("v_cmp_ne_u32_e64", sr(S_TMP, 2), 0, v(V_PX))
-        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(V_RX))
+        p.i("v_cmp_ne_u32_e64", sr(S_TMP, 2), 0, v(xf))
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(xr))
         p.i("s_bcnt1_i32_b64", s(S_A), sr(S_TMP, 2))
         p.i("s_bcnt1_i32_b64", s(S_B), "vcc")
         p.i("s_sub_u32", s(S_N), s(S_QTAIL8), s(S_QHEAD8))
@@ -330,12 +355,12 @@ class Gen:
         p.i("s_add_u32", s(S_N), s(S_N), s(S_B))
         p.i("s_cmp_le_u32", s(S_N), QCAP)
         p.i("s_cbranch_scc1", "@" + go)
-        self.call("pass")
+        self.call("pass")                                        # (keeps V_T .. V_T + 7: the four item pairs)
         p.i("s_branch", "@" + chk)
         p.label(go)
-        meta_f = (0 << 8) | ((2 * a) << 9)
-        meta_r = (1 << 8) | ((2 * a) << 9)
-        for strand, px, meta, msk, cnt in (("F", V_PX, meta_f, sr(S_TMP, 2), S_A), ("R", V_RX, meta_r, "vcc", S_B)):
+        meta_f = (0 << 8) | ((2 * a) << 9) | (suspect << 15)
+        meta_r = (1 << 8) | ((2 * a) << 9) | (suspect << 15)
+        for strand, px, meta, msk, cnt in (("F", xf, meta_f, sr(S_TMP, 2), S_A), ("R", xr, meta_r, "vcc", S_B)):
             lo = f"s{S_TMP}" if strand == "F" else "vcc_lo"
             hi = f"s{S_TMP + 1}" if strand == "F" else "vcc_hi"
             p.i("v_mbcnt_lo_u32_b32", v(T + 1), lo, 0)
@@ -447,12 +472,11 @@ class Gen:
     # ---- the resolve pass (subroutine) ----------------------------------------------------------------------
     def emit_pass(self):
         p = self.p
-        T = V_T0
+        T = V_TP
         item = T            # (x, y)
         m, rest, col, a0, a1, a2 = T + 2, T + 3, T + 4, T + 5, T + 6, T + 7
-        lo, hi, mid, tb, key, key1, acc = T + 8, T + 9, T + 10, T + 11, T + 12, T + 13, T + 14
+        lo, hi, mid, tb, key, key1, t1 = T + 8, T + 9, T + 10, T + 11, T + 12, T + 13, T + 14
         fld = [T + 15 + g for g in range(11)]
-        t1 = T + 26
         p.label("pass")
         self.probe(0)
         if "nopass" in self.exp:
@@ -486,7 +510,7 @@ class Gen:
         p.i("v_bfe_u32", v(t1), v(y), 9, 5)                   # shift = 2 x (window start within its chunk)
         p.i("v_bfe_u32", v(tb), v(y), 8, 1)                   # strand
         p.i("v_mul_u32_u24", v(tb), hex(self.ng * 256), v(tb))
-        p.i("v_add_u32", v(tb), TABLE_OFF, v(tb))              # the strand's table
+        p.i("v_add_u32", v(tb), TABLE_OFF, v(tb))             # the strand's table
         p.i("s_waitcnt", "lgkmcnt(0)")
         p.i("v_alignbit_b32", v(lo), v(a1), v(a0), v(t1))     # bases 0 .. 15 of the window
         p.i("v_alignbit_b32", v(hi), v(a2), v(a1), v(t1))     # bases 16 .. 31
@@ -523,25 +547,62 @@ class Gen:
             p.i("v_add_u32", v(key), s(S_KEYBASE), v(key))
         else:
             raise NotImplementedError
-        # append to the hit log (all active lanes hold a hit)
-        nolog, logged, room = self.lbl("nolog"), self.lbl("logged"), self.lbl("room")
+        sflag = a0                                            # (the ring words are spent)
+        p.i("v_bfe_u32", v(sflag), v(y), 15, 1)
+        # ---- clean candidates: append to the hit log (every one of them is a hit); exec = the active items throughout ----
+        nolog, logged = self.lbl("nolog"), self.lbl("logged")
+        p.label("logswitch_back")
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(sflag))           # vcc = suspects, S_TMP = clean
+        p.i("s_andn2_b64", sr(S_TMP, 2), "exec", "vcc")
+        p.i("s_bcnt1_i32_b64", s(S_B), sr(S_TMP, 2))
         p.i("s_cmp_eq_u32", s(S_USELOG), 1)
         p.i("s_cbranch_scc0", "@" + nolog)
-        p.label(room)
-        p.i("s_lshl2_add_u32", s(S_A), s(S_N), s(S_LFILL4))
+        p.i("s_lshl2_add_u32", s(S_A), s(S_B), s(S_LFILL4))
         p.i("s_cmp_le_u32", s(S_A), s(S_LOGCAP4))
         p.i("s_cbranch_scc0", "@logswitch")
-        p.label("logswitch_back")
-        p.i("v_add_u32", v(t1), s(S_LFILL4), v(V_LANE4))
+        p.i("v_mbcnt_lo_u32_b32", v(t1), s(S_TMP), 0)
+        p.i("v_mbcnt_hi_u32_b32", v(t1), s(S_TMP + 1), v(t1))
+        p.i("v_lshl_add_u32", v(t1), v(t1), 2, s(S_LFILL4))
+        p.i("s_mov_b64", "exec", sr(S_TMP, 2))
         p.i("global_store_dword", v(t1), v(key), sr(S_LOGBASE, 2))
         p.i("s_mov_b32", s(S_LFILL4), s(S_A))
         p.i("s_branch", "@" + logged)
         p.label(nolog)
         p.label("direct")
+        p.i("s_mov_b64", "exec", sr(S_TMP, 2))
         p.i("v_mov_b32", v(key1), 0)
-        p.i("v_lshl_add_u64", vr(key, 2), vr(key, 2), 2, sr(S_SK, 2))
-        p.i("global_atomic_add", vr(key, 2), v(V_ONE), "off")
+        p.i("v_lshl_add_u64", vr(lo, 2), vr(key, 2), 2, sr(S_SK, 2))
+        p.i("global_atomic_add", vr(lo, 2), v(V_ONE), "off")
         p.label(logged)
+        # ---- suspects: (key, tile, read | window << 11) -> this wave's region of the suspect list ----
+        nosus, susfull = self.lbl("nosus"), self.lbl("susfull")
+        p.i("s_cbranch_vccz", "@" + nosus)
+        p.i("s_mov_b64", "exec", "vcc")
+        p.i("s_bcnt1_i32_b64", s(S_B), "vcc")
+        p.i("s_lshl_b32", s(S_B), s(S_B), 4)
+        p.i("s_add_u32", s(S_A), s(S_SUSOFF), s(S_B))
+        p.i("s_cmp_le_u32", s(S_A), s(S_SUSCAP))
+        p.i("s_cbranch_scc0", "@" + susfull)
+        p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
+        p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
+        p.i("v_lshl_add_u32", v(t1), v(t1), 4, s(S_SUSOFF))
+        sx = fld[1]                                           # four consecutive registers from an even one: the entry
+        assert sx % 2 == 0
+        p.i("v_mov_b32", v(sx), v(key))
+        p.i("v_mov_b32", v(sx + 1), s(S_WT))
+        p.i("s_sub_u32", s(S_B), s(S_WN), 1 + self.j)          # the block's windows start in chunk n - 1 - j
+        p.i("s_lshl_b32", s(S_B), s(S_B), 4)
+        p.i("v_bfe_u32", v(sx + 2), v(y), 10, 4)
+        p.i("v_add_u32", v(sx + 2), s(S_B), v(sx + 2))
+        p.i("v_lshrrev_b32", v(sx + 3), 2, v(col))
+        p.i("v_lshl_or_b32", v(sx + 2), v(sx + 2), 11, v(sx + 3))
+        p.i("v_mov_b32", v(sx + 3), 0)
+        p.i("global_store_dwordx4", v(t1), vr(sx, 4), sr(S_SUS, 2))
+        p.i("s_nop", 1)                                       # (a 128-bit store reads its data a little after it issues)
+        p.label(susfull)                                      # no room: the count runs past the capacity, which K1f reads as "walk everything"
+        p.i("s_mov_b32", s(S_SUSOFF), s(S_A))
+        p.label(nosus)
+        p.i("s_or_b64", "exec", sr(S_TMP, 2), "vcc")         # clean + suspects = the active items again
         # what is left of each word goes to the back of the queue
         p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
         p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
@@ -560,43 +621,44 @@ class Gen:
         # ---- rare: the log region is full ----
         p.label("logswitch")
         p.i("s_mov_b64", "vcc", "exec")
-        self.store_log_fill()
+        self.store_log_fill(fld[1])
         p.i("s_add_u32", s(S_LREG), s(S_LREG), s(S_NWAVES))
         p.i("s_cmp_lt_u32", s(S_LREG), s(S_LOGREG))
         ok = self.lbl("lsw_ok")
         p.i("s_cbranch_scc1", "@" + ok)
         p.i("s_mov_b32", s(S_USELOG), 0)                      # out of regions: ntComp's increment as device atomics from here on
         p.i("s_mov_b64", "exec", "vcc")
-        p.i("s_branch", "@direct")
+        p.i("s_branch", "@logswitch_back")
         p.label(ok)
         self.load_log_region()
         p.i("s_mov_b64", "exec", "vcc")
-        p.i("s_lshl2_add_u32", s(S_A), s(S_N), s(S_LFILL4))
-        p.i("s_cmp_le_u32", s(S_A), s(S_LOGCAP4))
-        p.i("s_cbranch_scc0", "@logswitch")
         p.i("s_branch", "@logswitch_back")
 
-    def store_log_fill(self):
-        """log_fill[LREG] = LFILL (one lane)"""
+    def store_log_fill(self, T=V_TP + 16):
+        """log_fill[LREG] = LFILL (one lane); T, T + 1: scratch"""
         p = self.p
-        T = V_T0 + 27
         p.i("s_mov_b64", "exec", 1)
         p.i("s_lshl_b32", s(S_B), s(S_LREG), 2)
         p.i("s_lshr_b32", s(S_CC), s(S_LFILL4), 2)
         p.i("v_mov_b32", v(T), s(S_B))
         p.i("v_mov_b32", v(T + 1), s(S_CC))
-        p.i("global_store_dword", v(T), v(T + 1), sr(S_LOGFILL, 2))
+        p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["log_fill"]))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("global_store_dword", v(T), v(T + 1), sr(S_TMP, 2))
         p.i("s_mov_b64", "exec", -1)
 
     def load_log_region(self):
         """LFILL4 and the buffer descriptor of region LREG"""
         p = self.p
         p.i("s_lshl_b32", s(S_B), s(S_LREG), 2)
-        p.i("s_load_dword", s(S_LFILL4), sr(S_LOGFILL, 2), s(S_B))
+        p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["log_fill"]))
+        p.i("s_load_dwordx2", sr(S_LOGBASE, 2), sr(S_KARG, 2), hex(KARG["log"]))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_load_dword", s(S_LFILL4), sr(S_TMP, 2), s(S_B))
         p.i("s_mul_i32", s(S_TMP), s(S_LREG), s(S_LOGCAP4))
         p.i("s_mul_hi_u32", s(S_TMP + 1), s(S_LREG), s(S_LOGCAP4))
-        p.i("s_add_u32", s(S_LOGBASE), s(S_LOG), s(S_TMP))
-        p.i("s_addc_u32", s(S_LOGBASE + 1), s(S_LOG + 1), s(S_TMP + 1))
+        p.i("s_add_u32", s(S_LOGBASE), s(S_LOGBASE), s(S_TMP))
+        p.i("s_addc_u32", s(S_LOGBASE + 1), s(S_LOGBASE + 1), s(S_TMP + 1))
         p.i("s_waitcnt", "lgkmcnt(0)")
         p.i("s_lshl_b32", s(S_LFILL4), s(S_LFILL4), 2)
 
@@ -633,15 +695,23 @@ class Gen:
         p.i("s_mov_b32", s(S_KARG), inp["karg_lo"])
         p.i("s_mov_b32", s(S_KARG + 1), inp["karg_hi"])
         p.i("s_mov_b32", s(S_WT), inp["wave_gid"])
+        p.i("s_lshl_b32", s(S_A), s(S_WT), 2)
+        p.i("v_mov_b32", v(V_WAVE4), s(S_A))
         p.i("s_mov_b32", s(S_NWAVES), inp["n_waves"])
         p.i("s_mov_b32", s(S_B0), inp["lds_wbase"])
-        for reg, name in ((S_TILES, "tiles"), (S_LOG, "log"), (S_LOGFILL, "log_fill"), (S_SK, "sketch0"), (S_F1P, "f1"), (S_DIRTY, "dirty"), (S_TIE, "tie")):
+        for reg, name in ((S_TILES, "tiles"), (S_SK, "sketch0"), (S_DIRTY, "dirty"), (S_TIE, "tie"), (S_SUS, "sus")):
             p.i("s_load_dwordx2", sr(reg, 2), sr(S_KARG, 2), hex(KARG[name]))
         for reg, name in ((S_NTILES, "n_tiles"), (S_C, "n_chunks"), (S_L, "read_len"), (S_NVLAST, "nv_last"), (S_KEYBASE, "key_base"), (S_RMASK2, "rmask2"),
-                          (S_LOGREG, "log_regions"), (S_LOGCAP4, "log_region_cap")):
+                          (S_LOGREG, "log_regions"), (S_LOGCAP4, "log_region_cap"), (S_SUSCAP, "sus_cap")):
             p.i("s_load_dword", s(reg), sr(S_KARG, 2), hex(KARG[name]))
         p.i("s_waitcnt", "lgkmcnt(0)")
         p.i("s_lshl_b32", s(S_LOGCAP4), s(S_LOGCAP4), 2)
+        p.i("s_lshl_b32", s(S_SUSCAP), s(S_SUSCAP), 4)         # bytes
+        p.i("s_mul_i32", s(S_A), s(S_WT), s(S_SUSCAP))
+        p.i("s_mul_hi_u32", s(S_B), s(S_WT), s(S_SUSCAP))
+        p.i("s_add_u32", s(S_SUS), s(S_SUS), s(S_A))
+        p.i("s_addc_u32", s(S_SUS + 1), s(S_SUS + 1), s(S_B))
+        p.i("s_mov_b32", s(S_SUSOFF), 0)
         p.i("s_mov_b32", s(S_EXP0), "0x47ff5554")
         for reg, val in VCONST:
             p.i("v_mov_b32", v(reg), hex(val))
@@ -665,8 +735,6 @@ class Gen:
         p.i("s_mov_b64", sr(S_F1ACC, 2), 0)
         if "timers" in self.exp:
             p.i("s_mov_b32", s(S_SPARE), 0)
-            p.i("v_mov_b32", v(V_SPARE0), s(S_F1P))
-            p.i("v_mov_b32", v(V_SPARE1), s(S_F1P + 1))
         # geometry: W = L - k + 1, NB = ((L - 1 + 16 - phi) >> 4) + 1
         p.i("s_add_u32", s(S_NB), s(S_L), 15 - phi)
         p.i("s_lshr_b32", s(S_NB), s(S_NB), 4)
@@ -692,7 +760,7 @@ class Gen:
         p.i("s_waitcnt", "lgkmcnt(0)")
         p.i("s_mul_i32", s(S_F0), s(S_WT), s(S_A))
         p.i("s_cmp_lt_u32", s(S_F0), s(S_CC))
-        p.i("s_cbranch_scc0", "@exit")
+        p.i("s_cbranch_scc0", "@done")                           # nothing to walk: F1 += 0, no suspects
         p.i("s_add_u32", s(S_FEND), s(S_F0), s(S_A))
         p.i("s_min_u32", s(S_FEND), s(S_FEND), s(S_CC))
         p.i("s_mul_hi_u32", s(S_PT), s(S_F0), s(S_B))            # tile = F0 / NB with nb_magic = floor(2^32 / NB): never too large,
@@ -732,7 +800,7 @@ class Gen:
         if "timers" in self.exp:
             p.i("s_memtime", sr(S_TMP, 2))
             p.i("s_waitcnt", "lgkmcnt(0)")
-            p.i("s_mov_b32", s(S_F1P + 1), s(S_TMP))
+            p.i("s_mov_b32", s(S_SUSCAP), s(S_TMP))
             p.i("s_mov_b64", sr(S_F1ACC, 2), 0)
         # ================================ the chunk loop ================================
         p.label("iter")
@@ -857,6 +925,7 @@ class Gen:
         # -- per block: candidates are dropped wherever one of the block's three chunks holds a dirty piece of the read
         p.i("v_or3_b32", v(V_T0), v(V_D0), v(V_D1), v(V_D2))
         self.bitop3(v(V_CMASK), v(V_T0), v(V_VMASK), v(V_VMASK), lambda x, y, z: (1 ^ x) & y)
+        p.i("v_and_b32", v(V_DMASK), v(V_T0), v(V_VMASK))
         # steps of this block that complete a window: e = 16 (n - 1) + phi + a in [k - 1, L - 1]
         p.i("s_lshl_b32", s(S_A), s(S_WN), 4)
         p.i("s_add_i32", s(S_A), s(S_A), phi - 16)              # e0
@@ -887,10 +956,12 @@ class Gen:
         p.label("done")
         # F1 (ntcard.cpp:154)
         T = V_T0
+        p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["f1"]))
+        p.i("s_waitcnt", "lgkmcnt(0)")
         p.i("s_mov_b64", "exec", 1)
+        p.i("v_mov_b32", v(T + 2), s(S_TMP))
+        p.i("v_mov_b32", v(T + 3), s(S_TMP + 1))
         if "timers" in self.exp:
-            p.i("v_mov_b32", v(T + 2), v(V_SPARE0))
-            p.i("v_mov_b32", v(T + 3), v(V_SPARE1))
             p.i("v_mov_b32", v(T + 1), 0)
             for sec in range(4):
                 p.i("v_mov_b32", v(T), s(S_TACC[sec]))
@@ -898,9 +969,15 @@ class Gen:
         else:
             p.i("v_mov_b32", v(T), s(S_F1ACC))
             p.i("v_mov_b32", v(T + 1), s(S_F1ACC + 1))
-            p.i("v_mov_b32", v(T + 2), s(S_F1P))
-            p.i("v_mov_b32", v(T + 3), s(S_F1P + 1))
             p.i("global_atomic_add_x2", vr(T + 2, 2), vr(T, 2), "off")
+            # suspects of this wave: their number (or all ones: the region overflowed, K1f falls back to walking every dirty block)
+            p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["sus_count"]))
+            p.i("s_lshr_b32", s(S_A), s(S_SUSOFF), 4)
+            p.i("s_cmp_le_u32", s(S_SUSOFF), s(S_SUSCAP))
+            p.i("s_cselect_b32", s(S_A), s(S_A), -1)
+            p.i("s_waitcnt", "lgkmcnt(0)")
+            p.i("v_mov_b32", v(T), s(S_A))
+            p.i("global_store_dword", v(V_WAVE4), v(T), sr(S_TMP, 2))
         p.i("s_mov_b64", "exec", -1)
         nofill = self.lbl("nofill")
         p.i("s_cmp_eq_u32", s(S_USELOG), 1)

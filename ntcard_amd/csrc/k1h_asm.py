@@ -754,6 +754,14 @@ class Emu:
         addr = self._gaddr(o[0], o[2], m)
         self.mem32[addr[em] // 4] = self.rd_v(o[1])[em]
 
+    def op_global_store_dwordx4(self, pc, o, m):
+        em = self.mask_arr()
+        addr = self._gaddr(o[0], o[2], m)
+        kind, a, n = o[1]
+        assert np.all(addr[em] % 4 == 0)
+        for j in range(4):
+            self.mem32[addr[em] // 4 + j] = self.V[a + j][em]
+
     def op_global_load_dword(self, pc, o, m):
         em = self.mask_arr()
         addr = self._gaddr(o[1], o[2], m)

@@ -262,8 +262,22 @@ struct ntc_engine {
 	std::vector<uint32_t*> d_k1h_tabs; // K1h: closed-form table per k of the list (nullptr: K1c takes that k)
 	std::vector<void*> d_k1h_fix;      // K1f: per-byte rolling terms of that k
 	bool k1h_wanted = true;         // !NTC_FLAG_TILED_TEAMS
-	uint32_t *d_dirty = nullptr, *d_tie = nullptr; // K1h -> K1f bit arrays (grow-only)
-	size_t dirty_cap = 0, tie_cap = 0;
+	// What K1h hands to K1f (two bit arrays, the suspect list, a little state): two sets, so that — for a caller that promised to leave its
+	// batches alone until ntc_sync (NTC_FLAG_DEFER_REDO) — K1f of one batch runs on a side stream beside K1h of the next one (K1f waits on
+	// memory, K1h on instruction issue; K1h's six waves leave half of two SIMDs' registers free).
+	struct K1hSet {
+		uint32_t *d_dirty = nullptr, *d_tie = nullptr;
+		size_t dirty_cap = 0, tie_cap = 0;
+		uint4* d_sus = nullptr;            // kK1hSusCap entries per wave of a launch
+		uint32_t *d_sus_count = nullptr, *d_fix_state = nullptr;
+		hipEvent_t k1h_done = nullptr, k1f_done = nullptr;
+		bool k1f_pending = false;
+	} k1h_set[2];
+	int k1h_cur = 0;
+	hipStream_t k1f_stream = nullptr;
+	uint32_t k1h_launch_id = 0;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: K1f on the side stream
+	double k1f_ms = 0.0;
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
 	bool bs_ok = false;             // K1b (bit-sliced kernel over row slots) is
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
@@ -337,6 +351,15 @@ int drain_events(ntc_engine* e)
 		(void)hipEventDestroy(pr.second);
 	}
 	e->apply_pending.clear();
+	for (auto& pr : e->k1f_events) {
+		float ms = 0.f;
+		HIP_TRY(hipEventSynchronize(pr.second));
+		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+		e->k1f_ms += ms;
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
+	}
+	e->k1f_events.clear();
 	return 0;
 }
 
@@ -415,9 +438,22 @@ int flush_redo(ntc_engine* e)
 	return 0;
 }
 
+// K1f launches still under way on the side stream: the engine's stream waits for them (no host wait).  Before anything reads the counters or
+// F1, or touches the sketch without atomics (the apply's sweep does).
+int join_k1f(ntc_engine* e)
+{
+	for (auto& ks : e->k1h_set)
+		if (ks.k1f_pending) {
+			HIP_TRY(hipStreamWaitEvent(e->stream, ks.k1f_done, 0));
+			ks.k1f_pending = false;
+		}
+	return 0;
+}
+
 // Apply the pending hit log to the sketch (asynchronous on the engine's stream): partition, count, add, clear.
 int apply_log(ntc_engine* e)
 {
+	if (int rc = join_k1f(e)) return rc;
 	if (int rc = flush_redo(e)) return rc; // K1 may log too: its pass comes first
 	if (!e->d_log || !e->log_pending) return 0;
 	const auto& ap = e->ap;
@@ -822,26 +858,51 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 			const uint32_t n_chunks = (read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, read_len);
 			const size_t need_d = (size_t)n_tiles * n_chunks * 256, need_t = (size_t)n_tiles * nb * 256;
 			if (need_d < (1ull << 32) && need_t < (1ull << 32)) {
-				if (need_d > e->dirty_cap || need_t > e->tie_cap) {
-					HIP_TRY(hipStreamSynchronize(e->stream));
-					if (e->d_dirty) (void)hipFree(e->d_dirty);
-					if (e->d_tie) (void)hipFree(e->d_tie);
-					e->d_dirty = e->d_tie = nullptr;
-					e->dirty_cap = e->tie_cap = 0;
-					if (hipMalloc((void**)&e->d_dirty, need_d) != hipSuccess || hipMalloc((void**)&e->d_tie, need_t) != hipSuccess)
-						return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
-					e->dirty_cap = need_d;
-					e->tie_cap = need_t;
+				constexpr uint32_t kK1hSusCap = 2048; // suspects per K1h wave (a 10 M-read batch with 0.05 % N leaves ~400); a wave that needs more sends the launch down K1f's slow path
+				const uint32_t max_waves = (uint32_t)di.cus * 6u;
+				const bool side = e->defer_redo; // K1f beside the next K1h only when the caller keeps its batches unchanged until ntc_sync
+				auto& ks = e->k1h_set[side ? e->k1h_cur : 0];
+				if (side) e->k1h_cur ^= 1;
+				if (ks.k1f_pending) { // the K1f launch that last used this set
+					HIP_TRY(hipStreamWaitEvent(e->stream, ks.k1f_done, 0));
+					ks.k1f_pending = false;
 				}
+				if (need_d > ks.dirty_cap || need_t > ks.tie_cap) {
+					HIP_TRY(hipStreamSynchronize(e->stream));
+					if (ks.d_dirty) (void)hipFree(ks.d_dirty);
+					if (ks.d_tie) (void)hipFree(ks.d_tie);
+					ks.d_dirty = ks.d_tie = nullptr;
+					ks.dirty_cap = ks.tie_cap = 0;
+					if (hipMalloc((void**)&ks.d_dirty, need_d) != hipSuccess || hipMalloc((void**)&ks.d_tie, need_t) != hipSuccess)
+						return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
+					ks.dirty_cap = need_d;
+					ks.tie_cap = need_t;
+				}
+				if (!ks.d_sus) {
+					if (hipMalloc((void**)&ks.d_sus, (size_t)max_waves * kK1hSusCap * 16) != hipSuccess || hipMalloc((void**)&ks.d_sus_count, (size_t)max_waves * 4) != hipSuccess ||
+					    hipMalloc((void**)&ks.d_fix_state, 16) != hipSuccess)
+						return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
+					HIP_TRY(hipMemsetAsync(ks.d_fix_state, 0, 16, e->stream));
+					HIP_TRY(hipMemsetAsync(ks.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
+					HIP_TRY(hipEventCreateWithFlags(&ks.k1h_done, hipEventDisableTiming));
+					HIP_TRY(hipEventCreateWithFlags(&ks.k1f_done, hipEventDisableTiming));
+				}
+				if (side && !e->k1f_stream) HIP_TRY(hipStreamCreateWithFlags(&e->k1f_stream, hipStreamNonBlocking));
 				ntc::K1hArgs h;
 				std::memset(&h, 0, sizeof h);
+				h.sus = ks.d_sus;
+				h.sus_count = ks.d_sus_count;
+				h.sus_cap = kK1hSusCap;
+				h.launch_id = ++e->k1h_launch_id;
+				if (h.launch_id == 0) h.launch_id = ++e->k1h_launch_id;
+				h.fix_state = ks.d_fix_state;
 				h.tiles = d_tiles;
 				h.log = e->d_log;
 				h.log_fill = e->d_logfill;
 				h.sketch0 = e->d_sketch;
 				h.f1 = e->d_f1 + ki;
-				h.dirty = e->d_dirty;
-				h.tie = e->d_tie;
+				h.dirty = ks.d_dirty;
+				h.tie = ks.d_tie;
 				h.n_tiles = (uint32_t)n_tiles;
 				h.n_chunks = n_chunks;
 				h.read_len = read_len;
@@ -853,7 +914,28 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				h.table = e->d_k1h_tabs[ki];
 				h.s_bits = e->s_bits;
 				h.r_bits = e->r_bits;
-				HIP_TRY(ntc::launch_sketch_k1h(h, k, e->d_k1h_fix[ki], (unsigned)di.cus, e->stream));
+				ntc::K1hArgs launched;
+				uint32_t n_waves = 0;
+				HIP_TRY(ntc::launch_sketch_k1h(h, k, (unsigned)di.cus, e->stream, &launched, &n_waves));
+				if (side) {
+					HIP_TRY(hipEventRecord(ks.k1h_done, e->stream));
+					HIP_TRY(hipStreamWaitEvent(e->k1f_stream, ks.k1h_done, 0));
+					hipEvent_t f0 = nullptr, f1 = nullptr;
+					if (e->profiling) {
+						HIP_TRY(hipEventCreate(&f0));
+						HIP_TRY(hipEventCreate(&f1));
+						HIP_TRY(hipEventRecord(f0, e->k1f_stream));
+					}
+					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_k1h_fix[ki], e->d_t4s[ki], (unsigned)di.cus, e->k1f_stream));
+					if (e->profiling) {
+						HIP_TRY(hipEventRecord(f1, e->k1f_stream));
+						e->k1f_events.emplace_back(f0, f1);
+					}
+					HIP_TRY(hipEventRecord(ks.k1f_done, e->k1f_stream));
+					ks.k1f_pending = true;
+				} else {
+					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_k1h_fix[ki], e->d_t4s[ki], (unsigned)di.cus, e->stream));
+				}
 				continue;
 			}
 		}
@@ -1076,8 +1158,18 @@ void ntc_destroy(ntc_engine* e)
 		if (d) (void)hipFree(d);
 	for (void* d : e->d_k1h_fix)
 		if (d) (void)hipFree(d);
-	if (e->d_dirty) (void)hipFree(e->d_dirty);
-	if (e->d_tie) (void)hipFree(e->d_tie);
+	if (e->k1f_stream) (void)hipStreamSynchronize(e->k1f_stream);
+	for (auto& ks : e->k1h_set) {
+		for (void* d : {(void*)ks.d_dirty, (void*)ks.d_tie, (void*)ks.d_sus, (void*)ks.d_sus_count, (void*)ks.d_fix_state})
+			if (d) (void)hipFree(d);
+		if (ks.k1h_done) (void)hipEventDestroy(ks.k1h_done);
+		if (ks.k1f_done) (void)hipEventDestroy(ks.k1f_done);
+	}
+	for (auto& pr : e->k1f_events) {
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
+	}
+	if (e->k1f_stream) (void)hipStreamDestroy(e->k1f_stream);
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);
@@ -1096,6 +1188,7 @@ int ntc_reset(ntc_engine* e)
 	if (!e) return fail(NTC_ERR_ARG, "ntc_reset: null engine");
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
+	if (int rc = join_k1f(e)) return rc;
 	if (e->redo_pending) { // what was handed to the deferred K1 pass belongs to the counts that are being dropped
 		e->redo_pending = false;
 		e->redo_bound = 0;
@@ -1118,6 +1211,7 @@ int ntc_reset(ntc_engine* e)
 	e->launches = 0;
 	e->apply_ms = 0.0;
 	e->applies = 0;
+	e->k1f_ms = 0.0;
 	return 0;
 }
 
@@ -1357,6 +1451,7 @@ int ntc_sync(ntc_engine* e)
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
 	if (int rc = flush_redo(e)) return rc; // after ntc_sync the caller may recycle its batches: the listed slots are read now
+	if (int rc = join_k1f(e)) return rc;   // (K1f reads the batches too)
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return drain_events(e);
 }
@@ -1820,6 +1915,16 @@ int ntc_apply_time(ntc_engine* e, double* ms_total, uint64_t* applies)
 	if (int rc = drain_events(e)) return rc;
 	if (ms_total) *ms_total = e->apply_ms;
 	if (applies) *applies = e->applies;
+	return 0;
+}
+
+int ntc_fixup_time(ntc_engine* e, double* ms_total)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_fixup_time: null engine");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	if (int rc = drain_events(e)) return rc;
+	if (ms_total) *ms_total = e->k1f_ms;
 	return 0;
 }
 

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "ntc_kernels.hpp"
+#include "ntc_tile_bits.hpp"
 
 namespace ntc {
 
@@ -34,11 +35,13 @@ static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && of
                   offsetof(K1hArgs, f1) == 32 && offsetof(K1hArgs, dirty) == 40 && offsetof(K1hArgs, tie) == 48 && offsetof(K1hArgs, n_tiles) == 56 &&
                   offsetof(K1hArgs, n_chunks) == 60 && offsetof(K1hArgs, read_len) == 64 && offsetof(K1hArgs, nv_last) == 68 && offsetof(K1hArgs, key_base) == 72 &&
                   offsetof(K1hArgs, rmask2) == 76 && offsetof(K1hArgs, log_regions) == 80 && offsetof(K1hArgs, log_region_cap) == 84 && offsetof(K1hArgs, table) == 88 &&
-                  offsetof(K1hArgs, blocks_per_wave) == 104 && offsetof(K1hArgs, nb_magic) == 108,
+                  offsetof(K1hArgs, blocks_per_wave) == 104 && offsetof(K1hArgs, nb_magic) == 108 && offsetof(K1hArgs, sus) == 112 &&
+                  offsetof(K1hArgs, sus_count) == 120 && offsetof(K1hArgs, sus_cap) == 128,
               "gen_k1h.KARG");
 constexpr uint32_t kK1hWaves = 6;
 constexpr uint32_t kK1hWArea = 25600;
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
+constexpr uint32_t kK1hLdsBytes = kK1hTableOff + 2u * 11u * 256u; // exactly what the waves use: the 4.5 KiB left of a CU's LDS let k1h_f1_kernel's blocks in beside them
 
 #define K1H_CLOBBERS_V                                                                                                                 \
 	"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20",   \
@@ -83,31 +86,202 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 }
 
 // ---- K1f ------------------------------------------------------------------------------------------------------------------------
-// Work items come from the two bit arrays K1h leaves behind:
-//   dirty piece (read r, chunk c): the item covers the blocks n in {c, c + 1, c + 2} (n < NB) for which c is the LAST dirty chunk of r
-//   among n - 2 .. n — every dirty-affected (read, block) pair has exactly one owner — i.e. the window ends e in
-//   [16 c - 16 + phi, 16 n_hi + phi), phi = (k - 1) mod 16 (gen_k1h.py).  Every window ending there is examined: invalid ones leave F1,
-//   valid ones take ntComp's test (ntcard.cpp:132-145) on their canonical hash (nthash.hpp:275-279).
-//   tie bit (read r, block b), never in a dirty-affected block: the windows ending in the block whose two strands BOTH carry a
-//   candidate flag (gen_k1h.py, strand_flags) are the ones K1h left out.
-// A wave compacts items into an LDS queue and walks 64 of them at a time, one per lane: the lane's <= 6 raw 16-byte pieces are
-// staged in LDS, then one rolling step per position (nthash.hpp:242-257) with the per-byte terms of two 256-entry tables:
+// What K1h leaves behind: dirty[tile][chunk][lane] (bit m: the 16-byte piece of read 64 m + lane holds a byte that is no ACGTU letter),
+// tie[tile][block][lane] (bit m: some window of that block of that read has both strands flagged), and per wave a list of SUSPECTS —
+// candidates it resolved (counter index known) whose block touches a dirty piece of the read.  A block is "dirty-affected" for a read
+// when one of its chunks b - 2 .. b is dirty; block b = the window ends [16 b - 16 + phi, 16 b + phi), phi = (k - 1) mod 16.
+//   k1h_f1_kernel     one thread per dirty word: the exact byte masks of the piece and (only where the dirty bits say so) of the two
+//                     behind it -> the windows whose RIGHTMOST non-base byte lies in the piece leave F1 (ntHashIterator.hpp:59-86);
+//                     a byte of the reference table's slots 1, 3, 4, 5, 7 (nthash.hpp:32: bases to the reference, not letters to K1h)
+//                     sends the whole launch down the slow path
+//   k1h_fixup_kernel  fast path: a suspect counts iff its window holds no non-base byte (<= 3 pieces, read only where dirty);
+//                     slow path (a suspect region overflowed, or a table-slot byte turned up): every window of every dirty-affected
+//                     block is re-derived from the bytes with the rolling recurrence (nthash.hpp:242-257), suspects are ignored;
+//                     always: the windows of tie blocks that both strands flag, by the same walk.
+// The walk: a wave compacts items into an LDS queue and takes 64 at a time, one per lane; the lane's <= 6 raw pieces are staged in
+// LDS, then one step per position with the per-byte terms of two 256-entry tables
 //   in[b]  = { seed(b), srol^k(comp(b)) },  out[b] = { srol^k(seed(b)), comp(b) },  each 64-bit value as {H | L[32] << 31, L[0..31]}
-// (H: the 31-bit field, L: the 33-bit one, nthash.hpp:186-217); seed(b) == 0 marks a byte that is no base.  The walk starts from
-// the hash of k 'A's and lets 'A's leave the window until k real bases are in (as K1h does): no separate filling recurrence.
+// (H: the 31-bit field, L: the 33-bit one, nthash.hpp:186-217); seed(b) == 0 marks a byte that is no base.  It starts from the hash of
+// k 'A's and lets 'A's leave the window until k real bases are in (as K1h does): no separate filling recurrence.
 struct FixTables {
 	uint4 in[256], out[256];
 	uint32_t poly_a[4]; // hash of k 'A's: {f.w0, f.w1, r.w0, r.w1}
 };
-constexpr uint32_t kFixQCap = 192;
-constexpr uint32_t kFixStage = 7 * 16; // bytes per lane: up to 7 pieces (k - 1 + 48 positions, any alignment)
+constexpr uint32_t kFixQCap = 128;
+constexpr uint32_t kFixStage = 6 * 16; // bytes per lane: up to 6 pieces (k - 1 + 48 positions from any offset in the first one)
 
 __device__ __forceinline__ uint32_t ballot_rank(uint64_t m)
 {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-__global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const FixTables* __restrict__ ft, uint32_t k)
+__device__ __forceinline__ tilebits::v4u32 raw_piece(const K1hArgs& a, uint32_t t, uint32_t c, uint32_t r)
+{
+	return *reinterpret_cast<const tilebits::v4u32*>(a.tiles + (((size_t)t * a.n_chunks + c) * kTileReads + r) * 16u);
+}
+// some byte of the piece is one of the reference table's slots 1, 3, 4, 5, 7 (nthash.hpp:32: bases to the reference, no letters to K1h)
+__device__ __forceinline__ bool has_slot_byte(const tilebits::v4u32 v)
+{
+	bool any = false;
+	const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+	for (int d = 0; d < 4; ++d) {
+		const uint32_t z = w[d] & 0xf8f8f8f8u; // a zero byte here = a byte below 8
+		if (((z - 0x01010101u) & ~z & 0x80808080u) != 0u) // (rare)
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t c = (w[d] >> (8 * j)) & 0xffu;
+				any |= c == 1u || c == 3u || c == 4u || c == 5u || c == 7u;
+			}
+	}
+	return any;
+}
+
+// F1 correction: a wave compacts the dirty pieces of its rows into an LDS queue and takes 64 at a time, one per lane (a scattered 16-byte
+// load each, all in flight together)
+__global__ __launch_bounds__(256) void k1h_f1_kernel(const K1hArgs a, uint32_t k, uint32_t n_sus_waves)
+{
+	__shared__ uint2 s_q[4][128];
+	__shared__ uint32_t s_sum[4], s_slow[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	const uint32_t C = a.n_chunks, L = a.read_len, W = L - k + 1u;
+	const uint64_t n_rows = (uint64_t)a.n_tiles * C;
+	uint32_t f1_sub = 0;
+	bool slow = false;
+	for (uint32_t i = blockIdx.x * 256u + tid; i < n_sus_waves; i += gridDim.x * 256u)
+		slow |= a.sus_count[i] == 0xffffffffu; // a K1h wave ran out of room for its suspects
+	uint2* const queue = s_q[wv];
+	uint32_t qhead = 0, qtail = 0;
+	auto take = [&](uint32_t n_items) {
+		if (lane < n_items) {
+			const uint2 it = queue[(qhead + lane) & 127u];
+			const uint32_t t = it.x, r = it.y & 2047u, c = (it.y >> 11) & 0xfffu;
+			const tilebits::v4u32 pa = raw_piece(a, t, c, r);
+			const uint32_t A = tilebits::inv16(pa);
+			slow |= has_slot_byte(pa);
+			uint32_t B = 0;
+			if ((it.y >> 24) & 1u) B |= tilebits::inv16(raw_piece(a, t, c + 1u, r));
+			if ((it.y >> 25) & 1u) B |= tilebits::inv16(raw_piece(a, t, c + 2u, r)) << 16;
+			// window w = 16 c - (k - 1) + j ends at base 16 c + j: it holds a byte of A iff some bit of A lies in [j - k + 1, j] (A smeared over
+			// k positions), and no later non-letter byte iff j <= 15 + ctz(B) (B covers the 32 bases behind the piece); 0 <= w < W
+			uint64_t E = A;
+			uint32_t cov = 1;
+			while (cov * 2u <= k) {
+				E |= E << cov;
+				cov *= 2u;
+			}
+			if (cov < k) E |= E << (k - cov);
+			const int tzb = B ? __builtin_ctz(B) : 32;
+			const int jmin = max(0, (int)k - 1 - 16 * (int)c);
+			const int jmax = min(min(46, 15 + tzb), (int)W + (int)k - 2 - 16 * (int)c);
+			if (A != 0u && jmax >= jmin) f1_sub += (uint32_t)__popcll((E >> jmin) & ((2ull << (jmax - jmin)) - 1ull));
+		}
+		qhead += n_items;
+	};
+	const uint64_t wave_g = (uint64_t)blockIdx.x * 4u + wv, n_wv = (uint64_t)gridDim.x * 4u;
+	for (uint64_t row4 = wave_g * 4u; row4 < n_rows; row4 += n_wv * 4u) {
+		uint32_t w[6];
+#pragma unroll
+		for (int q = 0; q < 6; ++q)
+			w[q] = row4 + (uint64_t)q < n_rows ? a.dirty[(row4 + (uint64_t)q) * 64u + lane] : 0u;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint64_t row = row4 + (uint64_t)q;
+			if (row >= n_rows) break;
+			uint32_t word = w[q];
+			if (__builtin_amdgcn_ballot_w64(word != 0u) == 0) continue;
+			const uint32_t t = (uint32_t)(row / C), c = (uint32_t)(row % C);
+			const uint32_t d1 = c + 1u < C ? w[q + 1] : 0u, d2 = c + 2u < C ? w[q + 2] : 0u;
+			const uint32_t nv = t + 1u == a.n_tiles ? a.nv_last : kTileReads; // slots behind the batch's last read
+			const uint32_t groups = nv > lane ? (nv - lane + 63u) >> 6 : 0u;
+			word &= groups >= 32u ? 0xffffffffu : (1u << groups) - 1u;
+			while (__builtin_amdgcn_ballot_w64(word != 0u) != 0) {
+				const bool have = word != 0u;
+				const uint32_t m = have ? (uint32_t)__builtin_ctz(word) : 0u;
+				word &= word - 1u;
+				const uint64_t bm = __builtin_amdgcn_ballot_w64(have);
+				if (have) queue[(qtail + tilebits::mbcnt(bm)) & 127u] = make_uint2(t, (64u * m + lane) | (c << 11) | (((d1 >> m) & 1u) << 24) | (((d2 >> m) & 1u) << 25));
+				qtail += (uint32_t)__popcll(bm);
+				if (qtail - qhead >= 64u) take(64u);
+			}
+		}
+	}
+	if (qtail != qhead) take(qtail - qhead);
+	for (int o = 32; o > 0; o >>= 1)
+		f1_sub += (uint32_t)__shfl_xor((int)f1_sub, o);
+	const bool any_slow = __builtin_amdgcn_ballot_w64(slow) != 0;
+	if (lane == 0u) {
+		s_sum[wv] = f1_sub;
+		s_slow[wv] = any_slow ? 1u : 0u;
+	}
+	__syncthreads();
+	if (tid == 0) { // one atomic per block: thousands of them on one address would take longer than the kernel
+		const uint32_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+		if (sum != 0u) atomicAdd(reinterpret_cast<unsigned long long*>(a.fix_state + 2), (unsigned long long)sum);
+		if (s_slow[0] | s_slow[1] | s_slow[2] | s_slow[3]) a.fix_state[0] = a.launch_id; // (every writer writes the same value)
+	}
+}
+
+// fast path, after k1h_f1_kernel: the suspects, and the F1 correction it summed up.  No LDS, few registers: it runs beside the next
+// batch's K1h waves (the engine launches K1f on a side stream).
+__global__ __launch_bounds__(256) void k1h_suspect_kernel(const K1hArgs a, const void* __restrict__ t4, uint32_t k, uint32_t n_sus_waves)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
+	const uint32_t rmask = (1u << r_bits) - 1u;
+	const bool slow = a.fix_state[0] == a.launch_id; // (decided before this launch: a K1h wave's suspect region overflowed, or k1h_f1_kernel met a table-slot byte)
+	if (!slow) {
+		// ---- suspects (near a dirty piece, or with tied strands): the window's hash from its bytes — packed to 2 bits per base, four bases
+		// per look-up in K1c's closed-form table (nthash.hpp:220-239) — counted iff every byte is a letter (the fast path has made sure
+		// that no table-slot byte exists).  One block per K1h wave's region. ----
+		const uint4* const t4v = reinterpret_cast<const uint4*>(t4);
+		for (uint32_t hb = blockIdx.x; hb < 2u * n_sus_waves; hb += gridDim.x) { // half a region per block
+			const uint32_t reg = hb >> 1, n = a.sus_count[reg];
+			for (uint32_t i = (hb & 1u) * 256u + tid; i < n; i += 512u) {
+				const uint4 e = a.sus[(size_t)reg * a.sus_cap + i];
+				const uint32_t t = e.y, r = e.z & 2047u, w = e.z >> 11;
+				const uint32_t c0 = w >> 4, off = w & 15u;
+				uint32_t pk[3], bad[3];
+				uint64_t inv = 0;
+#pragma unroll
+				for (uint32_t j = 0; j < 3; ++j) { // the window's <= 3 pieces
+					pk[j] = bad[j] = 0;
+					if (c0 + j < C && 16u * j < off + k) {
+						const tilebits::v4u32 v = raw_piece(a, t, c0 + j, r);
+						pk[j] = tilebits::pack16(v, bad[j]);
+						if (bad[j]) inv |= (uint64_t)tilebits::inv16(v) << (16u * j); // (rare-ish: the exact positions)
+					}
+				}
+				const uint64_t win = k >= 64u ? ~0ull : (1ull << k) - 1ull;
+				if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
+				const uint32_t lo = tilebits::alignbit(pk[1], pk[0], 2u * off), hi = tilebits::alignbit(pk[2], pk[1], 2u * off);
+				uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+				for (uint32_t g = 0; g < (k + 3u) / 4u; ++g) {
+					const uint32_t b = ((g < 4u ? lo : hi) >> (8u * (g & 3u))) & 0xffu;
+					const uint4 x = t4v[g * 256u + b];
+					f0 ^= x.x;
+					f1 ^= x.y;
+					r0 ^= x.z;
+					r1 ^= x.w;
+				}
+				const uint64_t fh = ((uint64_t)f1 << 32) | f0, rh = ((uint64_t)r1 << 32) | r0;
+				const uint64_t h = rh < fh ? rh : fh;                                                          // nthash.hpp:275-279
+				uint32_t smp = 2;                                                                             // ntcard.cpp:132-145
+				if ((h >> (63u - s_bits)) == 1ull) smp = 0;
+				if ((h >> (64u - s_bits)) == (1ull << (s_bits - 1u)) - 1ull) smp = 1;
+				if (smp < 2u) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(h & (uint64_t)rmask), 1u);
+			}
+		}
+		if (blockIdx.x == 0 && tid == 0) { // the F1 correction k1h_f1_kernel summed up
+			unsigned long long* fs = reinterpret_cast<unsigned long long*>(a.fix_state + 2);
+			const unsigned long long sub = *fs;
+			if (sub) atomicAdd(a.f1, (unsigned long long)0 - sub);
+			__threadfence();
+		}
+	}
+	if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<unsigned long long*>(a.fix_state + 2) = 0ull; // (ready for the next launch; the slow path counts F1 itself)
+}
+
+__global__ __launch_bounds__(256) void k1h_slow_kernel(const K1hArgs a, const FixTables* __restrict__ ft, uint32_t k)
 {
 	__shared__ uint4 s_in[256], s_out[256];
 	__shared__ uint2 s_queue[4][kFixQCap];
@@ -126,6 +300,10 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 	unsigned char* const stage = s_stage[wv] + lane * kFixStage;
 	uint32_t qhead = 0, qtail = 0; // wave-uniform
 	uint32_t f1_sub = 0;
+	// only when the launch must take the slow path (a suspect region overflowed, or a table-slot byte turned up): otherwise k1h_f1_kernel
+	// and k1h_suspect_kernel have done everything
+	if (a.fix_state[0] != a.launch_id) return;
+	const bool slow = true;
 
 	// ---- walk the 64 (or fewer) items at the head of the queue ----
 	auto walk = [&](uint32_t n_items) {
@@ -142,7 +320,7 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 		const unsigned char* tile = a.tiles + (size_t)t * C * (kTileReads * 16u);
 		const int c0 = p0 >> 4, np = len > 0 ? (e_hi >> 4) - c0 + 1 : 0;
 #pragma unroll
-		for (int j = 0; j < 7; ++j)
+		for (int j = 0; j < 6; ++j)
 			if (j < np) *reinterpret_cast<uint4*>(stage + 16 * j) = *reinterpret_cast<const uint4*>(tile + ((size_t)(c0 + j) * kTileReads + r) * 16u);
 		// (a lane reads back only what it wrote itself: no barrier)
 		uint32_t f0 = pa0, f1 = pa1, r0 = pa2, r1 = pa3; // strand states {H | L[32] << 31, L[0..31]}
@@ -152,10 +330,21 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 		int max_len = len;
 		for (int o = 32; o > 0; o >>= 1)
 			max_len = max(max_len, __shfl_xor(max_len, o));
+		// one rolling step per position; the byte and its two table entries are fetched one iteration ahead of their use (three LDS
+		// round trips in a row would otherwise be all a lone item-walk does)
+		uint32_t bi_n = stage[len > 0 ? off0 : 0u];
+		uint4 ein_n = s_in[bi_n];
+		uint4 eo_n = s_out[(uint32_t)'A'];
 		for (int i = 0; i < max_len; ++i) {
 			const bool on = i < len;
-			const uint32_t bi = stage[on ? off0 + (uint32_t)i : 0u];
-			const uint4 ein = s_in[bi];
+			const uint4 ein = ein_n, eo_real = eo_n;
+			{ // prefetch for position i + 1: its byte, and the byte that leaves the window there (position i + 1 - k, if staged)
+				const bool nx = i + 1 < len;
+				bi_n = stage[nx ? off0 + (uint32_t)(i + 1) : 0u];
+				const uint32_t bo_n = stage[nx && i + 1 >= (int)k ? off0 + (uint32_t)(i + 1) - k : 0u];
+				ein_n = s_in[bi_n];
+				eo_n = s_out[bo_n];
+			}
 			if (on) {
 				if (ein.x == 0u) { // not a base: the window restarts behind it
 					good = 0;
@@ -165,8 +354,7 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 					r1 = pa3;
 				} else {
 					++good;
-					const uint32_t bo = good > k ? stage[off0 + (uint32_t)i - k] : (uint32_t)'A';
-					const uint4 eo = s_out[bo];
+					const uint4 eo = good > k ? eo_real : s_out[(uint32_t)'A']; // the first k bases of a run push out 'A's (the start state's)
 					// forward: srol by one, then the two terms (nthash.hpp:242-248)
 					const uint32_t nf1 = __builtin_amdgcn_alignbit(f1, f0, 31);
 					const uint32_t nf0 = ((f0 << 1) & 0x7ffffffeu) | ((f0 >> 30) & 1u) | (f1 & 0x80000000u);
@@ -182,19 +370,6 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 						if (!ties) ++f1_sub;
 					} else {
 						const uint32_t fH = f0 & 0x7fffffffu, rH = r0 & 0x7fffffffu;
-						bool take = true;
-						if (ties) {
-							const uint32_t f8 = fH >> 23, r8 = rH >> 23;
-							bool cf, cr;
-							if (s_bits == 7u) {
-								cf = ((f8 >> 1) == 0x3fu && (r8 >> 1) >= 0x3fu) || (f8 == 1u && r8 >= 1u);
-								cr = ((r8 >> 1) == 0x3fu && (f8 >> 1) >= 0x3fu) || (r8 == 1u && f8 >= 1u);
-							} else {
-								cf = (f8 == 0x7fu && r8 >= 0x7fu) || f8 == 0u;
-								cr = (r8 == 0x7fu && f8 >= 0x7fu) || r8 == 0u;
-							}
-							take = cf && cr;
-						}
 						// canonical strand (nthash.hpp:275-279): compare H, then L[32], then L[0..31]
 						const bool rev = rH != fH ? rH < fH : ((r0 ^ f0) >> 31) ? (r0 >> 31) < (f0 >> 31) : r1 < f1;
 						const uint32_t hH = rev ? rH : fH, hL = rev ? r1 : f1;
@@ -202,7 +377,22 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 						uint32_t smp = 2;
 						if ((hH >> (30u - s_bits)) == 1u) smp = 0;
 						if ((hH >> (31u - s_bits)) == (1u << (s_bits - 1u)) - 1u) smp = 1;
-						if (take && smp < 2u) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(hL & rmask), 1u);
+						if (smp < 2u) { // rare (2^(1 - s_bits))
+							bool take = true;
+							if (ties) {
+								const uint32_t f8 = fH >> 23, r8 = rH >> 23;
+								bool cf, cr;
+								if (s_bits == 7u) {
+									cf = ((f8 >> 1) == 0x3fu && (r8 >> 1) >= 0x3fu) || (f8 == 1u && r8 >= 1u);
+									cr = ((r8 >> 1) == 0x3fu && (f8 >> 1) >= 0x3fu) || (r8 == 1u && f8 >= 1u);
+								} else {
+									cf = (f8 == 0x7fu && r8 >= 0x7fu) || f8 == 0u;
+									cr = (r8 == 0x7fu && f8 >= 0x7fu) || r8 == 0u;
+								}
+								take = cf && cr;
+							}
+							if (take) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(hL & rmask), 1u);
+						}
 					}
 				}
 			}
@@ -216,39 +406,55 @@ __global__ __launch_bounds__(256) void k1h_fixup_kernel(const K1hArgs a, const F
 		if (qtail - qhead >= 64u) walk(64u);
 	};
 
-	const uint64_t n_rows = (n_dirty + n_tie) / 64u; // rows of 64 words: (tile, chunk) of the dirty array, then (tile, block) of the tie array
+	// rows of 64 words: (tile, chunk) of the dirty array, then (tile, block) of the tie array.  A wave takes four consecutive rows
+	// per iteration (their loads are in flight together; the two dirty rows behind them say whether a piece is the last dirty one)
+	const uint64_t n_drows = n_dirty / 64u, n_rows = (n_dirty + n_tie) / 64u;
 	const uint64_t wave_g = (uint64_t)blockIdx.x * 4u + wv, n_wv = (uint64_t)gridDim.x * 4u;
-	for (uint64_t row = wave_g; row < n_rows; row += n_wv) {
-		const bool is_d = row < n_dirty / 64u;
-		uint32_t word, t, c;
-		uint32_t d1 = 0, d2 = 0;
-		if (is_d) {
-			t = (uint32_t)(row / C);
-			c = (uint32_t)(row % C);
-			word = a.dirty[row * 64u + lane];
-			if (__builtin_amdgcn_ballot_w64(word != 0u) == 0) continue;
-			if (c + 1u < C) d1 = a.dirty[(row + 1u) * 64u + lane];
-			if (c + 2u < C) d2 = a.dirty[(row + 2u) * 64u + lane];
-			const uint32_t nv = t + 1u == a.n_tiles ? a.nv_last : kTileReads; // slots behind the batch's last read
-			const uint32_t groups = nv > lane ? (nv - lane + 63u) >> 6 : 0u;
-			word &= groups >= 32u ? 0xffffffffu : (1u << groups) - 1u;
-		} else {
-			const uint64_t j = row - n_dirty / 64u;
-			t = (uint32_t)(j / nb);
-			c = (uint32_t)(j % nb);
-			word = a.tie[j * 64u + lane];
+	const uint64_t row_hi = n_rows;
+	const uint64_t row_first = slow ? 0u : n_rows; // (fast path: the suspects above were everything)
+	for (uint64_t row4 = row_first + wave_g * 4u; row4 < n_rows; row4 += n_wv * 4u) { // (strided: the heavy dirty rows and the light tie rows spread over all waves)
+		uint32_t w[6];
+#pragma unroll
+		for (int q = 0; q < 6; ++q) {
+			const uint64_t row = row4 + (uint64_t)q;
+			w[q] = 0;
+			if (row < n_rows && (q < 4 || row < n_drows)) w[q] = row < n_drows ? a.dirty[row * 64u + lane] : a.tie[(row - n_drows) * 64u + lane];
 		}
-		while (__builtin_amdgcn_ballot_w64(word != 0u) != 0) {
-			const bool have = word != 0u;
-			const uint32_t m = have ? (uint32_t)__builtin_ctz(word) : 0u;
-			word &= word - 1u;
-			uint32_t nblk = 1;
-			if (is_d) { // blocks c .. c + 2 this piece is the last dirty chunk of
-				if (!((d1 >> m) & 1u)) nblk = ((d2 >> m) & 1u) ? 2u : 3u;
-				if (c + nblk > nb) nblk = nb - c;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint64_t row = row4 + (uint64_t)q;
+			if (row >= row_hi) break;
+			uint32_t word = w[q];
+			if (__builtin_amdgcn_ballot_w64(word != 0u) == 0) continue;
+			const bool is_d = row < n_drows;
+			uint32_t t, c, d1 = 0, d2 = 0;
+			if (is_d) {
+				t = (uint32_t)(row / C);
+				c = (uint32_t)(row % C);
+				if (c + 1u < C) d1 = w[q + 1];
+				if (c + 2u < C) d2 = w[q + 2];
+				const uint32_t nv = t + 1u == a.n_tiles ? a.nv_last : kTileReads; // slots behind the batch's last read
+				const uint32_t groups = nv > lane ? (nv - lane + 63u) >> 6 : 0u;
+				word &= groups >= 32u ? 0xffffffffu : (1u << groups) - 1u;
+			} else {
+				const uint64_t j = row - n_drows;
+				t = (uint32_t)(j / nb);
+				c = (uint32_t)(j % nb);
+				if (slow) // the dirty items of this launch cover every window of the dirty-affected blocks, both-flag windows included
+					for (int cc = (int)c - 2; cc <= (int)c; ++cc)
+						if (cc >= 0 && (uint32_t)cc < C) word &= ~a.dirty[((size_t)t * C + (uint32_t)cc) * 64u + lane];
 			}
-			const bool ok = have && (!is_d || c < nb);
-			push(ok, t, (64u * m + lane) | (c << 11) | (nblk << 24) | (is_d ? 0u : 1u << 26));
+			while (__builtin_amdgcn_ballot_w64(word != 0u) != 0) {
+				const bool have = word != 0u;
+				const uint32_t m = have ? (uint32_t)__builtin_ctz(word) : 0u;
+				word &= word - 1u;
+				uint32_t nblk = 1;
+				if (is_d) { // blocks c .. c + 2 this piece is the last dirty chunk of
+					if (!((d1 >> m) & 1u)) nblk = ((d2 >> m) & 1u) ? 2u : 3u;
+					if (c + nblk > nb) nblk = nb - c;
+				}
+				push(have, t, (64u * m + lane) | (c << 11) | (nblk << 24) | (is_d ? 0u : 1u << 26));
+			}
 		}
 	}
 	if (qtail != qhead) walk(qtail - qhead);
@@ -322,10 +528,11 @@ void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t* out)
 
 hipError_t set_sketch_k1h_smem_limit()
 {
-	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLdsBytes);
 }
 
-hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, const void* fix_tables, unsigned cus, hipStream_t st)
+// K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
+hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
 {
 	if (k != 32) return hipErrorInvalidValue;
 	const uint32_t nb = sketch_k1h_blocks(k, a.read_len);
@@ -334,12 +541,20 @@ hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, const void* fix_table
 	K1hArgs b = a;
 	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
 	b.nb_magic = (uint32_t)((1ull << 32) / nb);
-	hipLaunchKernelGGL((sketch_k1h_kernel<32>), dim3(grid), dim3(384), 160 * 1024, st, b);
-	hipError_t rc = hipGetLastError();
-	if (rc != hipSuccess) return rc;
-	const size_t rows = (size_t)a.n_tiles * (a.n_chunks + nb);
-	const unsigned fgrid = (unsigned)std::min<size_t>((rows + 3) / 4, (size_t)cus * 4);
-	hipLaunchKernelGGL(k1h_fixup_kernel, dim3(fgrid), dim3(256), 0, st, b, static_cast<const FixTables*>(fix_tables), k);
+	hipLaunchKernelGGL((sketch_k1h_kernel<32>), dim3(grid), dim3(384), kK1hLdsBytes, st, b);
+	*args_out = b;
+	*n_waves = grid * kK1hWaves;
+	return hipGetLastError();
+}
+
+// K1f for a batch K1h has been launched over (same arguments), on any stream ordered behind that launch
+hipError_t launch_k1h_fixup(const K1hArgs& b, uint32_t k, uint32_t n_k1h_waves, const void* fix_tables, const void* t4, unsigned cus, hipStream_t st)
+{
+	const size_t rows = (size_t)b.n_tiles * b.n_chunks;
+	hipLaunchKernelGGL(k1h_f1_kernel, dim3((unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8)), dim3(256), 0, st, b, k, n_k1h_waves);
+	hipLaunchKernelGGL(k1h_suspect_kernel, dim3(2u * n_k1h_waves), dim3(256), 0, st, b, t4, k, n_k1h_waves);
+	// the slow path takes LDS and a CU's worth of blocks; it returns at once unless the launch is flagged
+	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus), dim3(256), 0, st, b, static_cast<const FixTables*>(fix_tables), k);
 	return hipGetLastError();
 }
 

@@ -147,6 +147,12 @@ class Engine:
         check(self._lib.ntc_update_mode(self._h, C.byref(m)))
         return m.value
 
+    def fixup_time(self):
+        """milliseconds of K1f launches on the engine's side stream (FLAG_DEFER_REDO engines; 0 otherwise)"""
+        ms = C.c_double()
+        check(self._lib.ntc_fixup_time(self._h, C.byref(ms)))
+        return ms.value
+
     def apply_time(self):
         ms, n = C.c_double(), C.c_uint64()
         check(self._lib.ntc_apply_time(self._h, C.byref(ms), C.byref(n)))

@@ -61,7 +61,7 @@ class Layout:
         return a
 
 
-def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True):
+def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096):
     """-> dict(keys=uint32[], f1=int, dirty=[n_tiles][C][64], tie=[n_tiles][NB][64], insts=executed per wave)"""
     Cn = (read_len + 15) // 16
     n_tiles = (n_reads + 2047) // 2048
@@ -69,7 +69,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     NB = ((read_len - 1 + 16 - phi) >> 4) + 1
     if log_regions is None:
         log_regions = n_waves * 4
-    lay = Layout(tiles.size + (1 << 22) + log_regions * log_region_cap * 4 + (4 << (r_bits + 1)))
+    lay = Layout(tiles.size + (1 << 22) + log_regions * log_region_cap * 4 + (4 << (r_bits + 1)) + n_waves * sus_cap * 16)
     a_karg = lay.alloc(256)
     a_tiles = lay.alloc(tiles.size)
     a_log = lay.alloc(log_regions * log_region_cap * 4)
@@ -78,11 +78,14 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     a_f1 = lay.alloc(8)
     a_dirty = lay.alloc(n_tiles * Cn * 256)
     a_tie = lay.alloc(n_tiles * NB * 256)
+    a_sus = lay.alloc(n_waves * sus_cap * 16)
+    a_susn = lay.alloc(n_waves * 4)
     mem = lay.mem
     mem[a_tiles:a_tiles + tiles.size] = tiles
     m32, m64 = mem.view(np.uint32), mem.view(np.uint64)
     K = gen_k1h.KARG
-    for name, val in (("tiles", a_tiles), ("log", a_log), ("log_fill", a_fill), ("sketch0", a_sk), ("f1", a_f1), ("dirty", a_dirty), ("tie", a_tie)):
+    for name, val in (("tiles", a_tiles), ("log", a_log), ("log_fill", a_fill), ("sketch0", a_sk), ("f1", a_f1), ("dirty", a_dirty), ("tie", a_tie), ("sus", a_sus),
+                      ("sus_count", a_susn)):
         m64[(a_karg + K[name]) // 8] = val
     nv_last = n_reads - (n_tiles - 1) * 2048
     for name, val in (("n_tiles", n_tiles), ("n_chunks", Cn), ("read_len", read_len), ("nv_last", nv_last), ("key_base", 0),
@@ -91,6 +94,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     total = n_tiles * NB
     m32[(a_karg + K["blocks_per_wave"]) // 4] = (total + n_waves - 1) // n_waves
     m32[(a_karg + K["nb_magic"]) // 4] = (1 << 32) // NB
+    m32[(a_karg + K["sus_cap"]) // 4] = sus_cap
     lds = np.zeros(gen_k1h.LDS_BYTES, dtype=np.uint8)
     tab = build_table(k, r_bits, s_bits)
     lds.view(np.uint32)[gen_k1h.TABLE_OFF // 4: gen_k1h.TABLE_OFF // 4 + tab.size] = tab.reshape(-1)
@@ -108,7 +112,9 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     keys = [m32[a_log // 4 + rgn * log_region_cap: a_log // 4 + rgn * log_region_cap + int(fill[rgn])] for rgn in range(log_regions)]
     keys = np.concatenate(keys) if keys else np.zeros(0, dtype=np.uint32)
     sk = m32[a_sk // 4: a_sk // 4 + (2 << r_bits)].copy()
-    return dict(keys=keys.copy(), sketch=sk, f1=int(m64[a_f1 // 8]), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
+    susn = m32[a_susn // 4: a_susn // 4 + n_waves].copy()
+    sus = [m32[a_sus // 4 + w * sus_cap * 4: a_sus // 4 + (w * sus_cap + min(int(susn[w]), sus_cap)) * 4].reshape(-1, 4).copy() for w in range(n_waves)]
+    return dict(sus=np.concatenate(sus) if sus else np.zeros((0, 4), dtype=np.uint32), sus_overflow=bool(np.any(susn == 0xFFFFFFFF)), keys=keys.copy(), sketch=sk, f1=int(m64[a_f1 // 8]), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
                 tie=m32[a_tie // 4: a_tie // 4 + n_tiles * NB * 64].reshape(n_tiles, NB, 64).copy(), insts=insts, NB=NB, C=Cn)
 
 
@@ -126,36 +132,50 @@ def flags_of(fh, rh, s_bits):
     return (fa and rg) or fb, (ra and fg) or rb
 
 
-def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie):
-    """-> (keys list, f1_sub) of the fix-up kernel"""
+def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_overflow=False):
+    """-> (keys list, f1_sub) of the fix-up kernel.
+    F1: every window with a non-ACGTU byte leaves it (they all lie in dirty-affected blocks).
+    Hits: suspects (K1h resolved them, K1f checks their bytes) — or, when the suspect list overflowed, every window of every
+    dirty-affected block; plus the windows of tie blocks both strands flag."""
     L = orc.lib()
     phi = (k - 1) % 16
     NB = ((read_len - 1 + 16 - phi) >> 4) + 1
     Cn = (read_len + 15) // 16
     keys, f1_sub = [], 0
     fh, rh, bad = C.c_uint64(), C.c_uint64(), C.c_uint()
+
+    def key_of(h):
+        if (h >> (63 - s_bits)) == 1:
+            return h & ((1 << r_bits) - 1)
+        if (h >> (64 - s_bits)) == (1 << (s_bits - 1)) - 1:
+            return (1 << r_bits) + (h & ((1 << r_bits) - 1))
+        return None
+
     for r, seq in enumerate(reads):
         t, lane, m = r // 2048, (r % 2048) % 64, (r % 2048) // 64
         for b in range(NB):
             aff = any(0 <= c < Cn and (int(dirty[t, c, lane]) >> m) & 1 for c in (b - 2, b - 1, b))
             tb = (int(tie[t, b, lane]) >> m) & 1
-            if not (aff or tb):
-                continue
             for e in range(max(16 * b - 16 + phi, k - 1), min(16 * b + phi - 1, read_len - 1) + 1):
                 win = seq[e - k + 1: e + 1]
                 ok = L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad))
-                if aff:
-                    if not ok:
-                        f1_sub += 1
-                        continue
-                else:
-                    assert ok
-                    cf, cr = flags_of(fh.value, rh.value, s_bits)
-                    if not (cf and cr):
-                        continue
-                h = min(fh.value, rh.value)
-                if (h >> (63 - s_bits)) == 1:
-                    keys.append(h & ((1 << r_bits) - 1))
-                elif (h >> (64 - s_bits)) == (1 << (s_bits - 1)) - 1:
-                    keys.append((1 << r_bits) + (h & ((1 << r_bits) - 1)))
+                if not ok:
+                    assert aff
+                    f1_sub += 1
+                    continue
+                if not sus_overflow:
+                    continue
+                cf, cr = flags_of(fh.value, rh.value, s_bits)
+                if aff or (tb and cf and cr):  # slow path: every window of a dirty-affected block, and the both-flag windows of tie blocks
+                    kk = key_of(min(fh.value, rh.value))
+                    if kk is not None:
+                        keys.append(kk)
+    if sus is not None and not sus_overflow:
+        for _, t, rw, _ in sus:  # (K1f re-derives the hash: the entry's key is K1h's, of the strand the candidate was queued under)
+            r, w = int(t) * 2048 + (int(rw) & 2047), int(rw) >> 11
+            win = reads[r][w: w + k]
+            if L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad)):
+                kk = key_of(min(fh.value, rh.value))
+                assert kk is not None, (r, w)
+                keys.append(kk)
     return keys, f1_sub

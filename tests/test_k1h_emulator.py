@@ -1,0 +1,61 @@
+"""K1h on the CPU: the GENERATED instruction list of the one-wave-per-tile kernel (ntcard_amd/csrc/gen_k1h.py) runs on the wave
+emulator (k1h_asm.Emu) and, together with a Python model of the fix-up kernels K1f, must reproduce the oracle's counters and F1
+exactly (tests/k1h_model.py).  This is what pins the generator's logic before the kernel reaches a GPU: register assignment, the
+list scheduler's reordering, the chunk cursor, the ring, the queue, the hit log with its region switches, suspects and ties.
+"""
+import numpy as np
+import pytest
+
+import k1h_model as km
+import orc
+
+
+def tile_array(arr):
+    n, L = arr.shape
+    C16, ntl = (L + 15) // 16, (n + 2047) // 2048
+    a = np.full((ntl * 2048, C16 * 16), ord("A"), dtype=np.uint8)
+    a[:n, :L] = arr
+    return np.ascontiguousarray(a.reshape(ntl, 2048, C16, 16).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def run(n, L, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, **kw):
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    if p_bad:
+        arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    res = km.run_k1h(tile_array(arr), n, L, k, r_bits=r_bits, n_waves=n_waves, **kw)
+    reads = [arr[i].tobytes() for i in range(n)]
+    fk, f1_sub = km.k1f_model(reads, L, k, r_bits, 7, res["dirty"], res["tie"], res["sus"], res["sus_overflow"])
+    got = np.bincount(np.concatenate([res["keys"], np.array(fk, dtype=np.uint32)]).astype(np.int64), minlength=2 << r_bits).astype(np.uint32) + res["sketch"]
+    oc, of1 = orc.sketch_reads(reads, [k], 0, r_bits, 7)
+    assert res["f1"] - f1_sub == int(of1[0])
+    assert np.array_equal(got, oc[0].reshape(-1).astype(np.uint32))
+    return res
+
+
+@pytest.mark.parametrize("n,L,k,p_bad,n_waves", [
+    (2048, 40, 32, 0.0, 2),       # one tile shared by two waves (the second one fills its window with two masked blocks)
+    (4097, 47, 32, 0.02, 3),      # a partial last tile of one read
+    (2100, 64, 25, 0.01, 2), (2049, 33, 20, 0.0, 2), (3000, 30, 16, 0.01, 2), (2500, 20, 12, 0.02, 2),  # other k: window start chunk, phase, table groups
+    (1, 150, 32, 0.0, 2), (2048, 160, 32, 0.001, 2),  # a virtual chunk behind the read (blocks = chunks + 1)
+])
+def test_k1h_emulated_matches_oracle(n, L, k, p_bad, n_waves):
+    run(n, L, k, p_bad, n_waves=n_waves)
+
+
+def test_k1h_emulated_150bp_two_tiles():
+    res = run(5000, 150, 32, 0.002)
+    assert len(res["sus"]) > 0 and not res["sus_overflow"]
+
+
+def test_k1h_emulated_log_regions_and_direct_atomics():
+    run(4096, 100, 31, 0.005, log_region_cap=256, log_regions=6)  # region switches, then out of regions: device atomics
+    run(2048, 80, 32, use_log=False)
+
+
+def test_k1h_emulated_suspect_overflow_and_dense_non_bases():
+    res = run(4097, 47, 32, 0.02, n_waves=3, sus_cap=16)
+    assert res["sus_overflow"]                                   # K1f's slow path (the model's)
+    run(2100, 150, 32, 0.3)
+    run(500, 150, 32, 1.0, n_waves=1)

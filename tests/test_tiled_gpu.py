@@ -34,8 +34,21 @@ def gen_host(n, L, dist, genome_len=200_000, seed=1):
     return [sl[i * stride: i * stride + L].tobytes() for i in range(n)]
 
 
+VARIANT_FLAGS = 0  # set per test by the `tiled_variant` fixture: 0 = the engine's choice (K1h where it is built, else K1c), or FLAG_TILED_TEAMS = K1c
+
+
+@pytest.fixture(autouse=True, params=["default", "teams"])
+def tiled_variant(request, nt):
+    """every test of this module runs twice: through the engine's default tiled kernel (K1h + K1f for k = 32, sBits = 7; K1c otherwise)
+    and with NTC_FLAG_TILED_TEAMS (K1c throughout)"""
+    global VARIANT_FLAGS
+    VARIANT_FLAGS = nt.FLAG_TILED_TEAMS if request.param == "teams" else 0
+    yield
+    VARIANT_FLAGS = 0
+
+
 def run_tiled(nt, reads, L, k=32, r_bits=18, s_bits=7, flags=0, pieces=1):
-    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | nt.FLAG_REQUIRE_TILED) as e:
+    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | VARIANT_FLAGS | nt.FLAG_REQUIRE_TILED) as e:
         step = (len(reads) + pieces - 1) // pieces
         keep = []
         for i in range(0, len(reads), step):
@@ -140,7 +153,7 @@ def test_tiled_kernel_k_lists(nt):
     for klist, L, n in (([21, 25, 31], 150, 5000), ([32, 16, 24], 100, 2100), ([17, 29], 20, 3000), ([20, 32], 19, 100), ([12, 15, 13], 14, 2500)):
         reads = gen_host(n, L, 1)
         t = torch.from_numpy(nt.tile_reads(reads, L)).cuda()
-        with nt.Engine(klist, r_bits=16, s_bits=7, flags=nt.FLAG_REQUIRE_TILED) as e:
+        with nt.Engine(klist, r_bits=16, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
             e.submit_tiled_device(t.data_ptr(), n, L)
             e.submit_tiled_device(t.data_ptr(), n // 2, L)  # a prefix of a tiled buffer is a batch: the slots behind its last read are ignored
             tc, ph, f1 = e.finish(counters=True)
@@ -168,7 +181,7 @@ def test_tiled_many_tiles_per_team_short_reads(nt, L, k):
     arr = alpha[rng.integers(0, 4, size=(n, L))]
     arr = np.where(rng.random((n, L)) < 0.015, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
     t = torch.from_numpy(tile_array(arr)).cuda()
-    with nt.Engine([k], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED) as e:
+    with nt.Engine([k], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
         e.submit_tiled_device(t.data_ptr(), n, L)
         tc, ph, f1 = e.finish(counters=True)
     counters = np.zeros((1, 2, 1 << 20), dtype=np.uint16)
@@ -202,7 +215,7 @@ def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     cfg = meta["configs"][name]
     n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
     buf = torch.empty(nt.tiled_bytes(R, L), dtype=torch.uint8, device="cuda")
-    with nt.Engine(cfg["klist"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED) as e:
+    with nt.Engine(cfg["klist"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
         for first in range(0, n, R):
             m = min(R, n - first)
             nt.gen_reads_tiled_device(buf.data_ptr(), meta["seed"], first, m, L, cfg["dist"], genome_len=100_000_000)
@@ -215,3 +228,50 @@ def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     out = tmp_path / f"{name}.hist"
     nt.write_hist(out, f1[0], F0, f, cov)
     assert out.read_bytes() == open(os.path.join(GOLD, pl["hist_file"]), "rb").read()
+
+
+def test_tiled_side_stream_fixups(nt):
+    """NTC_FLAG_DEFER_REDO: the caller leaves its batches alone until sync, so K1f of one batch runs on the engine's side stream beside K1h of
+    the next (two sets of hand-over arrays, used in turn); five batches with non-ACGTU bytes, several engines' worth of launches"""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    parts, bufs = [], []
+    for i in range(5):
+        n, L = 30_000 + 4000 * i, 150
+        arr = alpha[rng.integers(0, 4, size=(n, L))]
+        arr = np.where(rng.random((n, L)) < 0.003, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+        parts.append(arr)
+        bufs.append(torch.from_numpy(tile_array(arr)).cuda())
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | nt.FLAG_DEFER_REDO | VARIANT_FLAGS) as e:
+        for arr, t in zip(parts, bufs):
+            e.submit_tiled_device(t.data_ptr(), arr.shape[0], 150)
+        e.flush()
+        for arr, t in zip(parts[:2], bufs[:2]):  # and on after a flush
+            e.submit_tiled_device(t.data_ptr(), arr.shape[0], 150)
+        tc, ph, f1 = e.finish(counters=True)
+    allr = np.concatenate(parts + parts[:2])
+    counters = np.zeros((1, 2, 1 << 20), dtype=np.uint16)
+    offs = np.arange(allr.shape[0] + 1, dtype=np.uint64) * np.uint64(150)
+    of1 = orc.sketch_update(counters, np.ascontiguousarray(allr).reshape(-1), offs, [32], 0, 20, 7)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, counters)
+
+
+def test_tiled_reference_table_slot_bytes_and_suspect_overflow(nt):
+    """bytes 1, 3, 4, 5, 7 are bases to the reference (its seed table's first row, nthash.hpp:32) and no letters to the packing kernels: K1f
+    notices them and re-derives every window near them from the bytes; a read set dense with N overflows the suspect list — same slow path"""
+    rng = np.random.default_rng(5)
+    n, L = 6000, 150
+    arr = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))]
+    odd = np.array([1, 3, 4, 5, 7], dtype=np.uint8)
+    arr = np.where(rng.random((n, L)) < 0.002, odd[rng.integers(0, 5, size=(n, L))], arr).astype(np.uint8)
+    if VARIANT_FLAGS == 0:  # (K1c takes those bytes for non-bases: a documented deviation of that kernel only)
+        check(nt, [arr[i].tobytes() for i in range(n)], L)
+    dense = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(400_000, 64))].astype(np.uint8)
+    t = torch.from_numpy(tile_array(dense)).cuda()
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
+        e.submit_tiled_device(t.data_ptr(), dense.shape[0], 64)
+        tc, ph, f1 = e.finish(counters=True)
+    counters = np.zeros((1, 2, 1 << 20), dtype=np.uint16)
+    offs = np.arange(dense.shape[0] + 1, dtype=np.uint64) * np.uint64(64)
+    of1 = orc.sketch_update(counters, np.ascontiguousarray(dense).reshape(-1), offs, [32], 0, 20, 7)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, counters)

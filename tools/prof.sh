@@ -30,7 +30,7 @@ for f in glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:40]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k,v in agg.items():
-    if "sketch" in k or "nthash" in k or "split" in k or "count" in k:
+    if "sketch" in k or "nthash" in k or "split" in k or "count" in k or "k1h" in k:
         print("== counters (mean per dispatch)", k)
         for c,vals in sorted(v.items()): print("  %-28s %16.1f  n=%d"%(c,sum(vals)/len(vals),len(vals)))
 PY
