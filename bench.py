@@ -381,7 +381,8 @@ def main():
         step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: K1f on the side stream, counted in full although it overlaps the next hash launch)
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
-        if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits == 7 and not args.lane_kernel and not args.teams:
+        if (tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel
+                and not args.teams):
             kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_f1 / k1h_suspect kernels (K1f, side stream)"
         elif tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
             kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"

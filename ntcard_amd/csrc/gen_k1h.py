@@ -130,7 +130,7 @@ S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCA
 INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase"]
 # byte offsets in struct K1hArgs (ntc_kernels.hpp); the kernel reads them with scalar loads
 KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_tiles=56, n_chunks=60, read_len=64, nv_last=68, key_base=72,
-            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128)
+            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128, s_bits=96)
 
 
 class Gen:
@@ -542,18 +542,51 @@ class Gen:
                 p.i("v_xor_b32", v(a), v(a), v(b))
                 words = [a]
         w = words[0]
-        if self.sb == 7:
-            p.i("v_and_b32", v(key), s(S_RMASK2), v(w))      # low rBits bits + the sample bit right above them
-            p.i("v_add_u32", v(key), s(S_KEYBASE), v(key))
-        else:
-            raise NotImplementedError
-        sflag = a0                                            # (the ring words are spent)
+        p.i("v_and_b32", v(key), s(S_RMASK2), v(w))          # low rBits bits + the sample bit right above them
+        p.i("v_add_u32", v(key), s(S_KEYBASE), v(key))
+        sflag = a0                                            # (the ring words are spent) 0: a hit to log, bit 0: suspect, bit 1: no hit
         p.i("v_bfe_u32", v(sflag), v(y), 15, 1)
-        # ---- clean candidates: append to the hit log (every one of them is a hit); exec = the active items throughout ----
+        if self.sb != 7:
+            # s_bits >= 8: the walk only saw the 8-bit prefixes of ntComp's patterns; the table word carries the s_bits - 7 hash bits below them
+            # (bits 55 .. 63 - s_bits, above the sample bit).  Sample 1 (0 1..1) needs all but the lowest of them set, sample 0 (0..0 1)
+            # exactly the lowest; S_SPARE = 2^(s_bits - 7) - 1
+            smp, ext = a1, a2
+            p.i("s_bcnt1_i32_b32", s(S_B), s(S_RMASK2))      # r_bits + 1
+            p.i("v_lshrrev_b32", v(ext), s(S_B), v(w))
+            p.i("s_sub_u32", s(S_B), s(S_B), 1)
+            p.i("v_lshrrev_b32", v(smp), s(S_B), v(w))
+            p.i("v_and_b32", v(smp), 1, v(smp))
+            p.i("v_or_b32", v(mid), 1, v(ext))
+            p.i("v_cmp_ne_u32_e64", sr(S_TMP, 2), s(S_SPARE), v(mid))   # sample 1 fails
+            p.i("v_cmp_ne_u32_e32", "vcc", 1, v(ext))                   # sample 0 fails
+            p.i("v_cndmask_b32_e64", v(mid), 0, 2, sr(S_TMP, 2))
+            p.i("v_cndmask_b32_e64", v(ext), 0, 2, "vcc")
+            p.i("v_cmp_ne_u32_e32", "vcc", 0, v(smp))
+            p.i("v_cndmask_b32_e64", v(mid), v(ext), v(mid), "vcc")     # 2 where the candidate's own pattern fails
+            p.i("v_or_b32", v(sflag), v(sflag), v(mid))
+        # ---- what is left of each word goes to the back of the queue (exec = the active items) ----
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
+        p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
+        p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
+        p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
+        p.i("v_lshl_add_u32", v(t1), v(t1), 3, s(S_QTAIL8))
+        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK8), v(V_QBASE))
+        p.i("v_mov_b32", v(x), v(rest))
+        p.i("s_and_b64", "exec", "exec", "vcc")
+        p.i("ds_write_b64", v(t1), vr(item, 2))
+        p.i("s_lshl3_add_u32", s(S_QTAIL8), s(S_A), s(S_QTAIL8))
+        p.i("s_bfm_b64", "exec", s(S_N), 0)                  # the active items again
+        p.i("s_cmp_eq_u32", s(S_N), 64)
+        p.i("s_cselect_b64", "exec", -1, "exec")
+        # ---- clean hits: append to the hit log ----
         nolog, logged = self.lbl("nolog"), self.lbl("logged")
         p.label("logswitch_back")
-        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(sflag))           # vcc = suspects, S_TMP = clean
-        p.i("s_andn2_b64", sr(S_TMP, 2), "exec", "vcc")
+        if self.sb == 7:
+            p.i("v_cmp_ne_u32_e32", "vcc", 0, v(sflag))       # vcc = suspects
+        else:
+            p.i("v_and_b32", v(t1), 1, v(sflag))
+            p.i("v_cmp_ne_u32_e32", "vcc", 0, v(t1))
+        p.i("v_cmp_eq_u32_e64", sr(S_TMP, 2), 0, v(sflag))    # S_TMP = hits to log
         p.i("s_bcnt1_i32_b64", s(S_B), sr(S_TMP, 2))
         p.i("s_cmp_eq_u32", s(S_USELOG), 1)
         p.i("s_cbranch_scc0", "@" + nolog)
@@ -602,19 +635,7 @@ class Gen:
         p.label(susfull)                                      # no room: the count runs past the capacity, which K1f reads as "walk everything"
         p.i("s_mov_b32", s(S_SUSOFF), s(S_A))
         p.label(nosus)
-        p.i("s_or_b64", "exec", sr(S_TMP, 2), "vcc")         # clean + suspects = the active items again
-        # what is left of each word goes to the back of the queue
-        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
-        p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
-        p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
-        p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
-        p.i("v_lshl_add_u32", v(t1), v(t1), 3, s(S_QTAIL8))
-        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK8), v(V_QBASE))
-        p.i("v_mov_b32", v(x), v(rest))
-        p.i("s_and_b64", "exec", "exec", "vcc")
-        p.i("ds_write_b64", v(t1), vr(item, 2))
         p.i("s_mov_b64", "exec", -1)
-        p.i("s_lshl3_add_u32", s(S_QTAIL8), s(S_A), s(S_QTAIL8))
         p.i("s_waitcnt", "lgkmcnt(0)")
         self.probe(2)
         self.ret()
@@ -713,6 +734,11 @@ class Gen:
         p.i("s_addc_u32", s(S_SUS + 1), s(S_SUS + 1), s(S_B))
         p.i("s_mov_b32", s(S_SUSOFF), 0)
         p.i("s_mov_b32", s(S_EXP0), "0x47ff5554")
+        if self.sb != 7:
+            p.i("s_load_dword", s(S_SPARE), sr(S_KARG, 2), hex(KARG["s_bits"]))
+            p.i("s_waitcnt", "lgkmcnt(0)")
+            p.i("s_sub_u32", s(S_SPARE), s(S_SPARE), 7)
+            p.i("s_bfm_b32", s(S_SPARE), s(S_SPARE), 0)       # 2^(s_bits - 7) - 1
         for reg, val in VCONST:
             p.i("v_mov_b32", v(reg), hex(val))
         p.i("s_mov_b32", s(S_DESC + 2), "0x7fffffff")          # records: a tile's slots (C x 32 KiB) always fit
@@ -1010,5 +1036,6 @@ if __name__ == "__main__":
         f.write("// ntc_k1h_gen.inc — GENERATED by gen_k1h.py (do not edit)\n")
         f.write(f"#define K1H_N_INPUTS {len(INPUTS)}\n")
         for k in ks:
-            f.write(render_inc(k, 7))
+            for sb in (7, 8):
+                f.write(render_inc(k, sb))
     print("wrote", out)

@@ -340,6 +340,11 @@ class Emu:
         self.wr_s(o[0], r)
         self.scc = 1 if r else 0
 
+    def op_s_bcnt1_i32_b32(self, pc, o, m):
+        r = bin(self.rd_s(o[1])).count("1")
+        self.wr_s(o[0], r)
+        self.scc = 1 if r else 0
+
     def op_s_bitcmp1_b32(self, pc, o, m):
         self.scc = (self.rd_s(o[0]) >> (self.rd_s(o[1]) & 31)) & 1
 

@@ -1099,7 +1099,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			const uint32_t k = e->klist[ki];
 			if (!ntc::sketch_k1h_supports(k, e->s_bits, e->r_bits)) continue;
 			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);
-			ntc::build_k1h_table(k, e->r_bits, tab.data());
+			ntc::build_k1h_table(k, e->r_bits, e->s_bits, tab.data());
 			uint32_t* d = nullptr;
 			if (hipMalloc((void**)&d, tab.size() * 4) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
 				if (d) (void)hipFree(d);

@@ -147,7 +147,7 @@ struct K1hArgs {
 };
 bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits);
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len);
-void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
+void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t s_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
 hipError_t set_sketch_k1h_smem_limit();
 void build_k1h_fix_tables(uint32_t k, void* out /* k1h_fix_tables_bytes() */);
 size_t k1h_fix_tables_bytes();

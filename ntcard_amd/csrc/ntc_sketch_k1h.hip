@@ -63,7 +63,7 @@ constexpr uint32_t kK1hLdsBytes = kK1hTableOff + 2u * 11u * 256u; // exactly wha
 
 } // namespace
 
-template <int K>
+template <int K, int SB>
 __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 	const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
 	const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)karg);
 	const uint32_t karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(karg >> 32));
-	static_assert(K == 32, "gen_k1h.py emits this k");
-	asm volatile(K1H_ASM_K32_S7 ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S);
+	static_assert(K == 32 && (SB == 7 || SB == 8), "gen_k1h.py emits this k for the two s_bits classes (7, >= 8)");
+	if constexpr (SB == 7)
+		asm volatile(K1H_ASM_K32_S7 ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S);
+	else
+		asm volatile(K1H_ASM_K32_S8 ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S);
 }
 
 // ---- K1f ------------------------------------------------------------------------------------------------------------------------
@@ -500,15 +503,17 @@ void build_k1h_fix_tables(uint32_t k, void* out_)
 }
 size_t k1h_fix_tables_bytes() { return sizeof(FixTables); }
 
-bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits) { return k == 32 && s_bits == 7 && r_bits <= 30; }
+// the resolve pass works on ONE 32-bit word per candidate: the low r_bits bits of the hash, the bit that tells the samples apart, and
+// (s_bits >= 8) the s_bits - 7 bits between the 8-bit prefix the walk tests and the end of ntComp's patterns
+bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits) { return k == 32 && s_bits >= 7 && s_bits <= 30 && r_bits + 1 + (s_bits - 7) <= 32; }
 
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len) { return ((read_len - 1u + 16u - ((k - 1u) & 15u)) >> 4) + 1u; }
 
 // closed-form table of the resolve passes: [strand][group g][64 values] dwords, 3 bases per entry (code2 order: A=0 C=1 T/U=2 G=3, base t
 // of the group in bits 2t+1:2t).  Word = low r_bits bits of the strand's term (nthash.hpp:220-239: fh = XOR srol^(k-1-i) seed(c_i),
 // rh = XOR srol^i comp(c_i)) | its bit 62 << r_bits: ntComp's patterns differ in that bit, and the counter index is
-// key_base + (sample << r_bits) + (hash & (rBuck - 1)) (ntcard.cpp:132-145)
-void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t* out)
+// key_base + (sample << r_bits) + (hash & (rBuck - 1)) (ntcard.cpp:132-145); s_bits >= 8: + hash bits 55 .. 63 - s_bits above that
+void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t s_bits, uint32_t* out)
 {
 	static const unsigned code_of_code2[4] = { 0, 1, 3, 2 };
 	const uint32_t ng = (k + 2) / 3;
@@ -522,13 +527,16 @@ void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t* out)
 					const unsigned c = code_of_code2[(v >> (2 * t)) & 3u];
 					x ^= st == 0 ? srol(seed_of(c), k - 1 - i) : srol(comp_of(c), i);
 				}
-				out[(st * ng + g) * 64 + v] = (uint32_t)(x & ((1ull << r_bits) - 1ull)) | ((uint32_t)((x >> 62) & 1u) << r_bits);
+				const uint32_t ext = (uint32_t)((x >> (63 - s_bits)) & ((1ull << (s_bits - 7)) - 1ull)); // hash bits 55 .. 63 - s_bits
+				out[(st * ng + g) * 64 + v] = (uint32_t)(x & ((1ull << r_bits) - 1ull)) | ((uint32_t)((x >> 62) & 1u) << r_bits) | (s_bits > 7 ? ext << (r_bits + 1) : 0u);
 			}
 }
 
 hipError_t set_sketch_k1h_smem_limit()
 {
-	return hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLdsBytes);
+	hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLdsBytes);
+	if (rc == hipSuccess) rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLdsBytes);
+	return rc;
 }
 
 // K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
@@ -541,7 +549,10 @@ hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, unsigned cus, hipStre
 	K1hArgs b = a;
 	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
 	b.nb_magic = (uint32_t)((1ull << 32) / nb);
-	hipLaunchKernelGGL((sketch_k1h_kernel<32>), dim3(grid), dim3(384), kK1hLdsBytes, st, b);
+	if (a.s_bits == 7)
+		hipLaunchKernelGGL((sketch_k1h_kernel<32, 7>), dim3(grid), dim3(384), kK1hLdsBytes, st, b);
+	else
+		hipLaunchKernelGGL((sketch_k1h_kernel<32, 8>), dim3(grid), dim3(384), kK1hLdsBytes, st, b);
 	*args_out = b;
 	*n_waves = grid * kK1hWaves;
 	return hipGetLastError();

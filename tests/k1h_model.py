@@ -41,8 +41,9 @@ def build_table(k, r_bits, s_bits):
                 f ^= L.orc_srol(L.orc_seed(ord(base)), k - 1 - i)
                 r ^= L.orc_srol(L.orc_seed_comp(ord(base)), i)
             for st, x in ((0, f), (1, r)):
-                assert s_bits == 7
-                out[st, g, val] = (x & ((1 << r_bits) - 1)) | (((x >> 62) & 1) << r_bits)
+                ext = (x >> (63 - s_bits)) & ((1 << (s_bits - 7)) - 1)  # s_bits >= 8: the hash bits between the top 8 and ntComp's last pattern bit
+                assert r_bits + 1 + (s_bits - 7) <= 32
+                out[st, g, val] = (x & ((1 << r_bits) - 1)) | (((x >> 62) & 1) << r_bits) | (ext << (r_bits + 1))
     return out
 
 
@@ -89,7 +90,8 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
         m64[(a_karg + K[name]) // 8] = val
     nv_last = n_reads - (n_tiles - 1) * 2048
     for name, val in (("n_tiles", n_tiles), ("n_chunks", Cn), ("read_len", read_len), ("nv_last", nv_last), ("key_base", 0),
-                      ("rmask2", (2 << r_bits) - 1), ("log_regions", log_regions if use_log else 0), ("log_region_cap", log_region_cap)):
+                      ("rmask2", (2 << r_bits) - 1), ("log_regions", log_regions if use_log else 0), ("log_region_cap", log_region_cap),
+                      ("s_bits", s_bits)):
         m32[(a_karg + K[name]) // 4] = val
     total = n_tiles * NB
     m32[(a_karg + K["blocks_per_wave"]) // 4] = (total + n_waves - 1) // n_waves
@@ -176,6 +178,7 @@ def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_over
             win = reads[r][w: w + k]
             if L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad)):
                 kk = key_of(min(fh.value, rh.value))
-                assert kk is not None, (r, w)
-                keys.append(kk)
+                assert kk is not None or s_bits > 7, (r, w)  # (s_bits >= 8: the walk tests a prefix of the patterns, a suspect may turn out to be none)
+                if kk is not None:
+                    keys.append(kk)
     return keys, f1_sub

@@ -18,17 +18,17 @@ def tile_array(arr):
     return np.ascontiguousarray(a.reshape(ntl, 2048, C16, 16).transpose(0, 2, 1, 3)).reshape(-1)
 
 
-def run(n, L, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, **kw):
+def run(n, L, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, s_bits=7, **kw):
     rng = np.random.default_rng(seed)
     alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
     arr = alpha[rng.integers(0, 4, size=(n, L))]
     if p_bad:
         arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
-    res = km.run_k1h(tile_array(arr), n, L, k, r_bits=r_bits, n_waves=n_waves, **kw)
+    res = km.run_k1h(tile_array(arr), n, L, k, r_bits=r_bits, n_waves=n_waves, s_bits=s_bits, **kw)
     reads = [arr[i].tobytes() for i in range(n)]
-    fk, f1_sub = km.k1f_model(reads, L, k, r_bits, 7, res["dirty"], res["tie"], res["sus"], res["sus_overflow"])
+    fk, f1_sub = km.k1f_model(reads, L, k, r_bits, s_bits, res["dirty"], res["tie"], res["sus"], res["sus_overflow"])
     got = np.bincount(np.concatenate([res["keys"], np.array(fk, dtype=np.uint32)]).astype(np.int64), minlength=2 << r_bits).astype(np.uint32) + res["sketch"]
-    oc, of1 = orc.sketch_reads(reads, [k], 0, r_bits, 7)
+    oc, of1 = orc.sketch_reads(reads, [k], 0, r_bits, s_bits)
     assert res["f1"] - f1_sub == int(of1[0])
     assert np.array_equal(got, oc[0].reshape(-1).astype(np.uint32))
     return res
@@ -59,3 +59,9 @@ def test_k1h_emulated_suspect_overflow_and_dense_non_bases():
     assert res["sus_overflow"]                                   # K1f's slow path (the model's)
     run(2100, 150, 32, 0.3)
     run(500, 150, 32, 1.0, n_waves=1)
+
+
+@pytest.mark.parametrize("s_bits", [8, 9, 11])
+def test_k1h_emulated_larger_s_bits(s_bits):
+    """sBits >= 8 (>= 50 GB of input, ntcard.cpp:427-431): the walk tests 8-bit prefixes of ntComp's patterns, the resolve pass the rest"""
+    run(6000, 150, 32, 0.002, s_bits=s_bits, r_bits=12)
