@@ -340,7 +340,8 @@ def main():
         # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms
         def value_hist(counters, hist):
             nt.value_hist_device(counters.data_ptr(), counters.numel(), hist.data_ptr(), device=local_rank, stream=stream)
-        ph_merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0)
+        merge_t = {}
+        ph_merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0, timings=merge_t)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -432,6 +433,9 @@ def main():
                                 "wave_insts_per_s": (v / (step_ms * 1e-3)) if v and step_ms > 0 else None,
                                 "peak_wave_insts_per_s": peak_valu,
                                 "frac": (v / (step_ms * 1e-3) / peak_valu) if v and step_ms > 0 else None})(pmc_valu(args, R)),
+            # N > 1: this rank's share of the one exchange step (inside the timed region): narrow to 16 bits / all-to-all of the slices / wrapping
+            # sums / value histograms of the summed slice / histograms + F1 to rank 0
+            "merge": (merge_t if use_dist else None),
             "f1_total": total_kmers,
             "sampled_increments": hits,
         }

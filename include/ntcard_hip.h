@@ -227,6 +227,9 @@ int ntc_apply_time(ntc_engine *e, double *ms_total, uint64_t *applies);
 /* same for the fix-up kernels of the one-wave-per-tile kernel when they run on the engine's side stream (NTC_FLAG_DEFER_REDO engines: beside
  * the next batch's hash kernel, so this time is NOT part of ntc_kernel_time; without the flag they run on the engine's stream and are) */
 int ntc_fixup_time(ntc_engine *e, double *ms_total);
+/* device buffers, copy streams and events ntc_merge_devices has created for this engine so far: they are kept between merges, so the count
+ * stops growing after the first merge of a given group of engines (diagnostic) */
+int ntc_merge_allocations(ntc_engine *e, uint64_t *n);
 int ntc_set_profiling(ntc_engine *e, int enable);
 /* how ntComp's increment is currently carried out on the device: 0 = hit log + partitioned apply, 1 = direct atomics
  * (NTC_FLAG_DIRECT_ATOMICS, or chosen by the engine after an apply found mostly repeated counters); waits for the stream */

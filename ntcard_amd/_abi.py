@@ -14,7 +14,7 @@ ABI_SYMBOLS = [
     "ntc_abi_version", "ntc_max_k", "ntc_last_error", "ntc_create", "ntc_destroy", "ntc_reset",
     "ntc_submit", "ntc_submit_spans", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_hash_dump_k1_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
-    "ntc_kernel_time", "ntc_apply_time", "ntc_fixup_time", "ntc_update_mode", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
+    "ntc_kernel_time", "ntc_apply_time", "ntc_fixup_time", "ntc_merge_allocations", "ntc_update_mode", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
     "ntc_submit_tiled_device", "ntc_tiled_bytes", "ntc_gen_reads_tiled_device",
 ]
 
@@ -88,6 +88,7 @@ def lib():
     L.ntc_kernel_time.argtypes = [p, C.POINTER(C.c_double), C.POINTER(u64)]
     L.ntc_apply_time.argtypes = [p, C.POINTER(C.c_double), C.POINTER(u64)]
     L.ntc_fixup_time.argtypes = [p, C.POINTER(C.c_double)]
+    L.ntc_merge_allocations.argtypes = [p, C.POINTER(u64)]
     L.ntc_flush.argtypes = [p]
     L.ntc_update_mode.argtypes = [p, C.POINTER(u32)]
     L.ntc_set_profiling.argtypes = [p, C.c_int]

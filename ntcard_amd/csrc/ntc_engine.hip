@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ntcard_hip.h"
@@ -274,6 +275,15 @@ struct ntc_engine {
 		bool k1f_pending = false;
 	} k1h_set[2];
 	int k1h_cur = 0;
+	// ntc_merge_devices: exchange buffers, copy streams and events, kept between merges (grow-only)
+	struct MergeCache {
+		uint16_t *narrow = nullptr, *recv = nullptr;
+		size_t narrow_cap = 0, recv_cap = 0; // elements
+		std::vector<hipStream_t> lanes;
+		std::vector<hipEvent_t> arrived;
+		hipEvent_t narrowed = nullptr, summed = nullptr;
+	} mc;
+	uint64_t merge_allocs = 0; // device allocations + streams + events ntc_merge_devices has created for this engine
 	hipStream_t k1f_stream = nullptr;
 	uint32_t k1h_launch_id = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: K1f on the side stream
@@ -1158,6 +1168,17 @@ void ntc_destroy(ntc_engine* e)
 		if (d) (void)hipFree(d);
 	for (void* d : e->d_k1h_fix)
 		if (d) (void)hipFree(d);
+	for (hipStream_t st : e->mc.lanes)
+		if (st) {
+			(void)hipStreamSynchronize(st);
+			(void)hipStreamDestroy(st);
+		}
+	for (hipEvent_t ev : e->mc.arrived)
+		if (ev) (void)hipEventDestroy(ev);
+	if (e->mc.narrowed) (void)hipEventDestroy(e->mc.narrowed);
+	if (e->mc.summed) (void)hipEventDestroy(e->mc.summed);
+	if (e->mc.narrow) (void)hipFree(e->mc.narrow);
+	if (e->mc.recv) (void)hipFree(e->mc.recv);
 	if (e->k1f_stream) (void)hipStreamSynchronize(e->k1f_stream);
 	for (auto& ks : e->k1h_set) {
 		for (void* d : {(void*)ks.d_dirty, (void*)ks.d_tie, (void*)ks.d_sus, (void*)ks.d_sus_count, (void*)ks.d_fix_state})
@@ -1261,11 +1282,120 @@ int ntc_gen_reads_tiled_device(int32_t device, void* stream, void* d_tiles, uint
 namespace {
 // read i = bytes [ptr_of(i), ptr_of(i) + len_of(i)): ntc_submit (concatenated reads + offsets) and ntc_submit_spans (spans of
 // a caller buffer, e.g. the sequence lines inside a block of a FASTQ file) pack into the pinned staging pair the same way
-template <typename LenOf, typename PtrOf>
-int submit_impl(ntc_engine* e, uint64_t n_reads, LenOf len_of, PtrOf ptr_of)
+// Equal-length reads of a host batch go to the device in the TILED layout (round 4): the packing loop writes each read's 16-byte pieces
+// where ntc_submit_tiled_device expects them, so the reads the reference's parsers hand to ntRead (ntcard.cpp:182,203,230) reach the
+// tiled kernels (K1h / K1c) like a device-resident producer's do.
+using LenFn = std::function<uint64_t(uint64_t)>;
+using PtrFn = std::function<const char*(uint64_t)>;
+int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const PtrFn& ptr_of)
+{
+	HIP_TRY(hipSetDevice(e->device));
+	ntc_engine::StageSlot* sl = nullptr;
+	{
+		std::unique_lock<std::mutex> lk(e->stage_mu);
+		e->stage_cv.wait(lk, [&] {
+			for (auto& c : e->stage)
+				if (!c.busy) return true;
+			return false;
+		});
+		for (auto& c : e->stage)
+			if (!c.busy) {
+				sl = &c;
+				break;
+			}
+		sl->busy = true;
+	}
+	struct Release {
+		ntc_engine* e;
+		ntc_engine::StageSlot* sl;
+		~Release()
+		{
+			{
+				std::lock_guard<std::mutex> lk(e->stage_mu);
+				sl->busy = false;
+			}
+			e->stage_cv.notify_one();
+		}
+	} release{e, sl};
+	if (sl->done == nullptr) HIP_TRY(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+	if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));
+	const size_t need = (size_t)ntc_tiled_bytes(n_reads, len);
+	if (need > sl->h_stage_cap) {
+		if (sl->h_stage) (void)hipHostFree(sl->h_stage);
+		sl->h_stage = nullptr;
+		size_t cap = std::max(need, sl->h_stage_cap * 2);
+		if (hipHostMalloc((void**)&sl->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
+			sl->h_stage_cap = 0;
+			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot pin %zu B", cap);
+		}
+		sl->h_stage_cap = cap;
+	}
+	if (need > sl->d_stage_cap) {
+		if (sl->d_stage) (void)hipFree(sl->d_stage);
+		sl->d_stage = nullptr;
+		size_t cap = std::max(need, sl->d_stage_cap * 2);
+		if (hipMalloc((void**)&sl->d_stage, cap) != hipSuccess) {
+			sl->d_stage_cap = 0;
+			return fail(NTC_ERR_MEMORY, "ntc_submit: cannot allocate %zu B on device", cap);
+		}
+		sl->d_stage_cap = cap;
+	}
+	// ---- pack: piece c of read i -> ((tile * C + c) * 2048 + i % 2048) * 16 ----
+	unsigned char* hs = sl->h_stage;
+	const uint32_t C = (len + 15u) / 16u, tail = len - (C - 1u) * 16u;
+	for (uint64_t i = 0; i < n_reads; ++i) {
+		const char* src = ptr_of(i);
+		unsigned char* dst = hs + ((i / ntc::kTileReads) * C * ntc::kTileReads + i % ntc::kTileReads) * 16u;
+		for (uint32_t c = 0; c + 1u < C; ++c)
+			std::memcpy(dst + (size_t)c * ntc::kTileReads * 16u, src + 16u * c, 16);
+		unsigned char* last = dst + (size_t)(C - 1u) * ntc::kTileReads * 16u;
+		std::memcpy(last, src + 16u * (C - 1u), tail);
+		std::memset(last + tail, 'A', 16u - tail);
+	}
+	{
+		std::lock_guard<std::mutex> lk(e->mu);
+		if (hipMemcpyAsync(sl->d_stage, hs, need, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
+			(void)hipStreamSynchronize(e->stream);
+			return fail(NTC_ERR_DEVICE, "ntc_submit: host to device copy failed");
+		}
+		const bool keep = e->defer_redo; // the staging pair is recycled: its K1f may not run late on the side stream
+		e->defer_redo = false;
+		const int rc = run_tiled(e, sl->d_stage, n_reads, len);
+		e->defer_redo = keep;
+		sl->used = true;
+		if (hipEventRecord(sl->done, e->stream) != hipSuccess) (void)hipStreamSynchronize(e->stream);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+int submit_impl(ntc_engine* e, uint64_t n_reads, const LenFn& len_of, const PtrFn& ptr_of, bool rows_only = false)
 {
 	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
 	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
+	if (!rows_only && e->ts_ok && n_reads >= 1024) {
+		// the reads of the most frequent length (a FASTQ file's untrimmed reads) take the tiled path when they are the bulk of the batch
+		std::unordered_map<uint64_t, uint64_t> cnt;
+		uint64_t best = 0, best_n = 0;
+		for (uint64_t i = 0; i < n_reads; ++i) {
+			const uint64_t l = len_of(i);
+			const uint64_t c = ++cnt[l];
+			if (c > best_n) {
+				best_n = c;
+				best = l;
+			}
+		}
+		if (best >= kmin && best <= 0xffffu && best_n >= 1024 && best_n * 10 >= n_reads * 9) {
+			if (best_n == n_reads) return submit_tiled_host(e, n_reads, (uint32_t)best, ptr_of);
+			std::vector<uint64_t> same, rest;
+			same.reserve(best_n);
+			rest.reserve(n_reads - best_n);
+			for (uint64_t i = 0; i < n_reads; ++i)
+				(len_of(i) == best ? same : rest).push_back(i);
+			if (int rc = submit_tiled_host(e, same.size(), (uint32_t)best, [&](uint64_t i) { return ptr_of(same[i]); })) return rc;
+			return submit_impl(e, rest.size(), [&](uint64_t i) { return len_of(rest[i]); }, [&](uint64_t i) { return ptr_of(rest[i]); }, true);
+		}
+	}
 	// ---- plan: one slot per read, or chunks with kmax-1 overlap for long sequences ----
 	uint64_t maxlen = 0;
 	bool uniform = true;
@@ -1567,23 +1697,14 @@ void enable_peer_access(const std::vector<MergePeer>& peers)
 			(void)hipGetLastError();
 		}
 }
-void release_peers(std::vector<MergePeer>& peers)
+void release_peers(std::vector<MergePeer>& peers) // (buffers, streams and events belong to the engines' merge caches: only wait)
 {
 	for (MergePeer& p : peers) {
 		if (!p.e) continue;
 		(void)hipSetDevice(p.e->device);
-		for (hipStream_t s : p.lanes) {
-			if (!s) continue;
-			(void)hipStreamSynchronize(s);
-			(void)hipStreamDestroy(s);
-		}
+		for (hipStream_t s : p.lanes)
+			if (s) (void)hipStreamSynchronize(s);
 		(void)hipStreamSynchronize(p.e->stream);
-		for (hipEvent_t ev : p.arrived)
-			if (ev) (void)hipEventDestroy(ev);
-		if (p.narrowed) (void)hipEventDestroy(p.narrowed);
-		if (p.summed) (void)hipEventDestroy(p.summed);
-		if (p.narrow) (void)hipFree(p.narrow);
-		if (p.recv) (void)hipFree(p.recv);
 	}
 }
 // full-width fold of a small array of every engine into the root's (nthll registers: max; F1: sum)
@@ -1621,9 +1742,15 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 		for (int32_t j = 0; j < i; ++j)
 			if (engines[j] == e) return fail(NTC_ERR_ARG, "ntc_merge_devices: engine %d listed twice", i);
 	}
+	// every engine stays locked (in address order) from the applies to the last copy: a submit on one of them from another thread would
+	// race with the narrow / widen kernels on its sketch
+	std::vector<ntc_engine*> order(engines, engines + n_engines);
+	std::sort(order.begin(), order.end());
+	std::vector<std::unique_lock<std::mutex>> locks;
+	for (ntc_engine* e : order)
+		locks.emplace_back(e->mu);
 	// 1. pending increments first, everything quiescent
 	for (int32_t i = 0; i < n_engines; ++i) {
-		std::lock_guard<std::mutex> lk(engines[i]->mu);
 		HIP_TRY(hipSetDevice(engines[i]->device));
 		if (int rc = apply_log(engines[i])) return rc;
 		HIP_TRY(hipStreamSynchronize(engines[i]->stream));
@@ -1645,16 +1772,45 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 				MergePeer& p = peers[i];
 				p.e = engines[i];
 				HIP_TRY(hipSetDevice(p.e->device));
-				if (hipMalloc((void**)&p.narrow, counters * 2) != hipSuccess || hipMalloc((void**)&p.recv, (size_t)n * slice * 2) != hipSuccess)
-					return fail(NTC_ERR_MEMORY, "ntc_merge_devices: cannot allocate the %llu-byte exchange buffers on device %d", (unsigned long long)((counters + n * slice) * 2), p.e->device);
-				p.lanes.assign(n, nullptr);
-				p.arrived.assign(n, nullptr);
-				for (uint32_t j = 0; j < n; ++j) {
-					HIP_TRY(hipStreamCreateWithFlags(&p.lanes[j], hipStreamNonBlocking));
-					HIP_TRY(hipEventCreateWithFlags(&p.arrived[j], hipEventDisableTiming));
+				auto& mc = p.e->mc;
+				if (mc.narrow_cap < counters) {
+					if (mc.narrow) (void)hipFree(mc.narrow);
+					mc.narrow = nullptr;
+					mc.narrow_cap = 0;
+					if (hipMalloc((void**)&mc.narrow, counters * 2) != hipSuccess)
+						return fail(NTC_ERR_MEMORY, "ntc_merge_devices: cannot allocate the %llu-byte exchange buffer on device %d", (unsigned long long)(counters * 2), p.e->device);
+					mc.narrow_cap = counters;
+					++p.e->merge_allocs;
 				}
-				HIP_TRY(hipEventCreateWithFlags(&p.narrowed, hipEventDisableTiming));
-				HIP_TRY(hipEventCreateWithFlags(&p.summed, hipEventDisableTiming));
+				if (mc.recv_cap < (size_t)n * slice) {
+					if (mc.recv) (void)hipFree(mc.recv);
+					mc.recv = nullptr;
+					mc.recv_cap = 0;
+					if (hipMalloc((void**)&mc.recv, (size_t)n * slice * 2) != hipSuccess)
+						return fail(NTC_ERR_MEMORY, "ntc_merge_devices: cannot allocate the %llu-byte exchange buffer on device %d", (unsigned long long)((size_t)n * slice * 2), p.e->device);
+					mc.recv_cap = (size_t)n * slice;
+					++p.e->merge_allocs;
+				}
+				while (mc.lanes.size() < n) {
+					hipStream_t st = nullptr;
+					hipEvent_t ev = nullptr;
+					HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+					mc.lanes.push_back(st);
+					HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+					mc.arrived.push_back(ev);
+					p.e->merge_allocs += 2;
+				}
+				if (!mc.narrowed) {
+					HIP_TRY(hipEventCreateWithFlags(&mc.narrowed, hipEventDisableTiming));
+					HIP_TRY(hipEventCreateWithFlags(&mc.summed, hipEventDisableTiming));
+					p.e->merge_allocs += 2;
+				}
+				p.narrow = mc.narrow;
+				p.recv = mc.recv;
+				p.lanes.assign(mc.lanes.begin(), mc.lanes.begin() + n);
+				p.arrived.assign(mc.arrived.begin(), mc.arrived.begin() + n);
+				p.narrowed = mc.narrowed;
+				p.summed = mc.summed;
 			}
 			enable_peer_access(peers);
 			for (MergePeer& p : peers) { // narrow
@@ -1703,6 +1859,7 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 	}
 	// 4. everything now lives in engine 0 (counters as their value mod 2^16, which is all t_Counter ever held): the others start
 	//    from zero again, the sum stays what it was
+	locks.clear(); // (ntc_reset takes the engine's lock itself)
 	for (int32_t i = 1; i < n_engines; ++i)
 		if (int rc = ntc_reset(engines[i])) return rc;
 	HIP_TRY(hipSetDevice(root->device));
@@ -1915,6 +2072,14 @@ int ntc_apply_time(ntc_engine* e, double* ms_total, uint64_t* applies)
 	if (int rc = drain_events(e)) return rc;
 	if (ms_total) *ms_total = e->apply_ms;
 	if (applies) *applies = e->applies;
+	return 0;
+}
+
+int ntc_merge_allocations(ntc_engine* e, uint64_t* n)
+{
+	if (!e || !n) return fail(NTC_ERR_ARG, "ntc_merge_allocations: null argument");
+	std::lock_guard<std::mutex> lk(e->mu);
+	*n = e->merge_allocs;
 	return 0;
 }
 

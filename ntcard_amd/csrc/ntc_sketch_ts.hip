@@ -185,28 +185,7 @@ __device__ __forceinline__ void lds_wait_ge(const uint32_t* p, uint32_t v)
 	while ((int32_t)(lds_peek(p) - v) < 0)
 		__builtin_amdgcn_s_sleep(1);
 }
-#ifdef TS_TIMERS // instrumentation build (tools/dbg): cycles per role and per wait site, summed over waves into a.dbg (uint64 [4][8])
-#define TS_T(var) const uint64_t var = __builtin_readcyclecounter()
-#define TS_ACC(slot, t0, t1) tacc[slot] += (t1) - (t0)
-#define TS_WAIT(slot, p, v)                          \
-	do {                                             \
-		const uint64_t w0__ = __builtin_readcyclecounter(); \
-		lds_wait_ge(p, v);                           \
-		tacc[slot] += __builtin_readcyclecounter() - w0__;  \
-	} while (0)
-#define TS_FLUSH(role)                                                                                            \
-	do {                                                                                                          \
-		tacc[0] = __builtin_readcyclecounter() - t_start;                                                         \
-		if (lane == 0 && a.dbg)                                                                                   \
-			for (int i = 0; i < 8; ++i)                                                                           \
-				atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg) + (role) * 8 + i, (unsigned long long)tacc[i]); \
-	} while (0)
-#else
-#define TS_T(var)
-#define TS_ACC(slot, t0, t1)
-#define TS_WAIT(slot, p, v) lds_wait_ge(p, v)
-#define TS_FLUSH(role)
-#endif
+#include "ntc_instr.hpp" // TS_T / TS_ACC / TS_WAIT / TS_FLUSH: no-ops unless built with -DTS_TIMERS (tools/dbg)
 
 
 // ---- the resolve stage of ONE strand's candidates (shared by the two assistant waves of a team) -----------------------------
@@ -303,9 +282,7 @@ struct TsResolver {
 			uint32_t* dst = a->log + (uint64_t)lreg * a->log_region_cap + lfill + (hincl - nhit); // a lane's hits go behind those of the lanes below it
 #pragma unroll
 			for (int j = 0; j < N; ++j) {
-#ifndef TS_EXP_NOLOG
 				if (hit[j]) *dst = key[j];
-#endif
 				dst += hit[j];
 			}
 			lfill += total;
@@ -441,11 +418,7 @@ struct TsResolver {
 		for (int j = 0; j < NI; ++j)
 #pragma unroll
 			for (int i = 0; i < NG; ++i)
-#ifdef TS_EXP_NOTABLE
-				tv[j][i] = v4u32{toff[j][i], d0[j], d1[j], d2[j]};
-#else
 				tv[j][i] = *reinterpret_cast<const v4u32*>(t4 + (uint32_t)i * 4096u + toff[j][i]); // the group's 4 KiB rides in the offset field
-#endif
 		__builtin_amdgcn_sched_barrier(0);
 		uint32_t nhit = 0, anysus = 0;
 		uint32_t hit[NI], key[NI], sus[NI]; // 0 / 1
@@ -592,10 +565,6 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 	const uint64_t t_start = __builtin_readcyclecounter();
 #endif
 
-#ifdef TS_EXP_WALK_ONLY // timing experiment: the walkers alone, over whatever the ring holds, nobody to wait for
-	if (role >= 2u) return;
-#endif
-#ifndef TS_NO_A1
 	if (role == 2u) {
 		// =============================== A1: load, pack, publish; resolve the forward strand ===============================
 		__builtin_amdgcn_s_setprio(3); // the walkers run ahead of this wave anyway: when both want the SIMD, it goes first (measured: 0.87 -> 0.75 ms per 10 M reads)
@@ -637,7 +606,6 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 				// One resolver turn per chunk keeps the forward queue moving while the walkers have chunks ahead of them; more of them
 				// while the ring has no room for this chunk: its packed words overwrite chunk n - 5, which blocks <= n - 3 read (both
 				// strands' resolvers).  (ONE call site inside the chunk loop: the chunk in flight keeps 128 registers.)
-#ifndef TS_EXP_A1_FREE
 				{
 					TS_T(tg0);
 					while (true) {
@@ -656,7 +624,6 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					TS_T(tg1);
 					TS_ACC(1, tg0, tg1);
 				}
-#endif
 				const uint32_t slot = n % kRing;
 				uint32_t* pr = reinterpret_cast<uint32_t*>(tb + kOffPR) + slot * 2048u + lane;
 #ifdef TS_TIMERS
@@ -684,11 +651,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 					const uint32_t nv = rs.n_valid_last, groups = nv > (uint32_t)lane ? (nv - (uint32_t)lane + 63u) >> 6 : 0u; // read groups m with 64 m + lane < nv
 					dirtyword &= groups >= 32u ? 0xffffffffu : (1u << groups) - 1u;
 				}
-#if defined(TS_EXP_A1_FREE) || defined(TS_EXP_NODIRTY)
-				const uint64_t dm = 0;
-#else
 				const uint64_t dm = ballot(dirtyword != 0u);
-#endif
 				if (dm != 0) { // rare: hand the dirty pieces to A2 (F1 corrections)
 					const uint32_t cnt = (uint32_t)__popcll(dm);
 					while ((int32_t)(dq_tail + cnt - lds_peek(ctl + C_DQ_HEAD) - kDCap) > 0)
@@ -714,8 +677,6 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		return;
 	}
 
-#endif
-#ifndef TS_NO_W
 	if (role <= 1u) {
 		// =============================== F / R: walk one strand of the 31-bit half ===============================
 		auto walk = [&](auto fwd_c) {
@@ -735,19 +696,12 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 			uint32_t meta_tile = 0, nb0 = 0; // nb0: ring slot of chunk 0 of the current tile
 			auto push = [&](uint32_t h, uint32_t w) { // h: bit m set <=> read 64 m + lane is a candidate at window w
 				// straight-line: lanes without a candidate store to their spare slot behind the queue
-#ifdef TS_EXP_NOPUSH
-				h = 0u;
-#endif
 				h = w < W ? h : 0u;
 				const uint64_t m = ballot(h != 0u);
 				const uint32_t slot = (qtail + mbcnt(m)) & (kQCap - 1u);
 				queue[h != 0u ? slot : kQCap + (uint32_t)lane] = make_uint2(h, meta_tile | (((nb0 + (w >> 4)) % kRing) << 8) | (w << 11)); // wave-uniform arithmetic
 				qtail = rfl(qtail + (uint32_t)__popcll(m));
-#ifdef TS_EXP_WALK_ONLY
-				if (false) {
-#else
 				if (__builtin_expect(qtail - qhead_c > kQCap - 64u, 0)) { // the next step may not fit: let A2 catch up
-#endif
 					lds_publish(c_tail, qtail);
 					TS_T(tg0);
 					do {
@@ -780,9 +734,7 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 #pragma unroll 1
 				for (uint32_t c = 0; c < C; ++c, ++n) {
 					uint32_t I[32];
-#ifndef TS_EXP_WALK_ONLY
 					TS_WAIT(1, ctl + C_PR_READY, n + 1u);
-#endif
 					{ // the chunk's packed words of this lane's 32 reads -> 32 bit planes (both walkers do this: it is cheaper than a
 					  // third party publishing planes through one more LDS slot and one more hand-shake)
 						const uint32_t* pw = reinterpret_cast<const uint32_t*>(tb + kOffPR) + (n % kRing) * 2048u + lane;
@@ -855,8 +807,6 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		return;
 	}
 
-#endif
-#ifndef TS_NO_A2
 	// =============================== A2: resolve the reverse strand's candidates, settle dirty pieces, F1 ===============================
 	{
 		__builtin_amdgcn_s_setprio(3);
@@ -942,7 +892,6 @@ __global__ __launch_bounds__(512, 2) void sketch_ts_kernel(const TsArgs a)
 		if (lane == 0 && f1_add != 0) atomicAdd(a.f1, (unsigned long long)(f1_add - sub));
 		TS_FLUSH(3);
 	}
-#endif
 }
 
 // ---- instantiations -------------------------------------------------------------------------------------------

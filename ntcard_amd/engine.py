@@ -147,6 +147,12 @@ class Engine:
         check(self._lib.ntc_update_mode(self._h, C.byref(m)))
         return m.value
 
+    def merge_allocations(self):
+        """buffers / streams / events ntc_merge_devices has created for this engine (kept between merges)"""
+        n = C.c_uint64()
+        check(self._lib.ntc_merge_allocations(self._h, C.byref(n)))
+        return n.value
+
     def fixup_time(self):
         """milliseconds of K1f launches on the engine's side stream (FLAG_DEFER_REDO engines; 0 otherwise)"""
         ms = C.c_double()

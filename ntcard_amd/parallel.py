@@ -36,7 +36,38 @@ def reduce_sketch(sketch, f1, dst=0):
     return sketch, f1
 
 
-def exchange_and_sum_u16(sketch, shard):
+class _Phases:
+    """per-phase clock of the merge: HIP events on the current stream for device tensors, perf_counter for CPU tensors (gloo tests)"""
+
+    def __init__(self, device, enabled):
+        self.cuda = enabled and device.type == "cuda"
+        self.enabled = enabled
+        self.marks = []
+
+    def mark(self, name):
+        if not self.enabled:
+            return
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
+        else:
+            import time
+            self.marks.append((name, time.perf_counter()))
+
+    def result(self):
+        out = {}
+        if not self.enabled or len(self.marks) < 2:
+            return out
+        if self.cuda:
+            self.marks[-1][1].synchronize()
+        for (_, a), (name, b) in zip(self.marks, self.marks[1:]):
+            out[name + "_ms"] = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+        out["total_ms"] = sum(out.values())
+        return out
+
+
+def exchange_and_sum_u16(sketch, shard, phases=None):
     """Slice `rank` of the SUM over ranks of the counters modulo 2^16, as an int32 tensor of values 0..65535.
 
     t_Counter is uint16 with wrap-around (ntcard.cpp:142-143,439), so only the low 16 bits of every per-rank counter
@@ -49,6 +80,8 @@ def exchange_and_sum_u16(sketch, shard):
     world, rank = dist.get_world_size(), dist.get_rank()
     low = sketch.to(torch.int16)  # int32 -> int16 keeps the low 16 bits (two's complement)
     recv = torch.empty(world * shard, dtype=torch.int16, device=sketch.device)
+    if phases:
+        phases.mark("narrow")
     if dist.get_backend() == "gloo":
         ops = []
         for peer in range(world):
@@ -61,27 +94,35 @@ def exchange_and_sum_u16(sketch, shard):
             req.wait()
     else:
         dist.all_to_all_single(recv.view(torch.uint8), low.view(torch.uint8))  # bytes: RCCL has no 16-bit integer type, and none is needed to move them
+    if phases:
+        phases.mark("exchange")
     parts = recv.view(world, shard)
     acc = parts[0].clone()
     for r in range(1, world):
         acc += parts[r]  # int16 addition wraps: exactly the uint16 counter arithmetic
-    return acc.to(torch.int32) & 0xFFFF
+    out = acc.to(torch.int32) & 0xFFFF
+    if phases:
+        phases.mark("sum")
+    return out
 
 
-def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0):
+def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0, timings=None):
     """Multi-GPU merge for the estimator (compEst only needs the value histogram p[2][65536] of the SUMMED counters,
     ntcard.cpp:240-247): every rank ends up with one slice of the summed uint16 counters (exchange_and_sum_u16),
     histograms that slice locally, and only the histograms (256 KiB per plane) and F1 go to rank `dst`.
 
     sketch: int32 tensor [n_k * 2 * 2^r_bits] (uint32 counters), f1: int64 [n_k]; f1 is reduced in place.
     value_hist(counters_slice, hist_slice): accumulates the histogram of (counter & 0xffff) into an int32[65536] view.
-    Returns (p_hist int32 [n_k, 2, 65536], f1) — meaningful on rank dst."""
+    Returns (p_hist int32 [n_k, 2, 65536], f1) — meaningful on rank dst.  timings: a dict that receives narrow_ms / exchange_ms / sum_ms /
+    histogram_ms / reduce_ms / total_ms of this rank (bench.py reports them so that a scaling run separates hashing from the merge)."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    ph = _Phases(sketch.device, timings is not None)
+    ph.mark("start")
     plane = 1 << r_bits
     n = sketch.numel()
     assert n == n_k * 2 * plane and n % world == 0 and (n // world) % 4 == 0
     shard = n // world
-    mine = exchange_and_sum_u16(sketch, shard)
+    mine = exchange_and_sum_u16(sketch, shard, ph)
     hist = torch.zeros(n_k * 2 * 65536, dtype=torch.int32, device=sketch.device)
     pos, end = rank * shard, (rank + 1) * shard
     while pos < end:  # a slice may cover several (k, sample) planes, or a fraction of one
@@ -89,8 +130,12 @@ def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0):
         stop = min((pl + 1) * plane, end)
         value_hist(mine[pos - rank * shard:stop - rank * shard], hist[pl * 65536:(pl + 1) * 65536])
         pos = stop
+    ph.mark("histogram")
     dist.reduce(hist, dst=dst, op=dist.ReduceOp.SUM)
     dist.reduce(f1, dst=dst, op=dist.ReduceOp.SUM)
+    ph.mark("reduce")
+    if timings is not None:
+        timings.update(ph.result())
     return hist.view(n_k, 2, 65536), f1
 
 

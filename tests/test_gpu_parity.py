@@ -669,6 +669,35 @@ def test_native_merge_slices_and_wraps(nt, n_eng, r_bits):
     assert np.array_equal(more[0], want2[0]) and np.array_equal(more[2], want2[2])
 
 
+def test_native_merge_keeps_its_buffers(nt):
+    """the exchange buffers, copy streams and events of ntc_merge_devices live in the engines: a second merge of the same group creates
+    nothing (n^2 streams and events and two device buffers per call), and is still right"""
+    n, L, stride = 20_000, 150, 152
+    d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
+    nt.gen_reads_device(d.data_ptr(), 5, 0, n, L, stride, 1, genome_len=300_000)
+    engines = [nt.Engine([32], r_bits=18, s_bits=7) for _ in range(3)]
+    try:
+        for rnd in range(3):
+            for j, e in enumerate(engines):
+                e.submit_device(d.data_ptr() + (j * 6000) * stride, 6000, L, stride)
+            nt.merge_devices(engines)
+            if rnd == 0:
+                first = [e.merge_allocations() for e in engines]
+                assert all(x > 0 for x in first)
+            else:
+                assert [e.merge_allocations() for e in engines] == first
+        got = engines[0].finish(counters=True)
+    finally:
+        for e in engines:
+            e.close()
+    with nt.Engine([32], r_bits=18, s_bits=7) as e:
+        for rnd in range(3):
+            for j in range(3):
+                e.submit_device(d.data_ptr() + (j * 6000) * stride, 6000, L, stride)
+        want = e.finish(counters=True)
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
+
+
 def test_value_hist_device_matches_numpy(nt):
     rng = np.random.default_rng(3)
     c = rng.integers(0, 70000, size=1 << 20, dtype=np.uint32)

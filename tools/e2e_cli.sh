@@ -15,3 +15,12 @@ echo "== multi-k 16,24,32,48 -t 8"
 time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 16,24,32,48 -p refm $W/s_*.fq
 time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 16,24,32,48 -p gpum $W/s_*.fq
 for k in 16 24 32 48; do cmp refm_k$k.hist gpum_k$k.hist && echo IDENTICAL k$k; done
+echo "== kernels of one CLI run (rocprofv3 --kernel-trace --stats: which hash kernel the parsed reads reach)"
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/e2e_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof -o t -- $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p $W/prof $W/s_*.fq > /tmp/e2e_prof.log 2>&1
+f=$(find /tmp/e2e_prof -name '*kernel_stats.csv' | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+for row in csv.DictReader(open(sys.argv[1])):
+    print("%-70s calls %5s  total %9.3f ms" % (row["Name"][:70], row["Calls"], float(row["TotalDurationNs"]) / 1e6))
+PY
