@@ -1066,11 +1066,37 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	}
 	e->adaptive = !(cfg->flags & NTC_FLAG_ALWAYS_LOG);
 	e->partition_always = (cfg->flags & NTC_FLAG_PARTITION_ALWAYS) != 0;
-	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_DIRECT_ATOMICS) && plan_log(e, cfg->log_entries)) {
-		if (hipMalloc((void**)&e->d_log, e->log_cap * 4) != hipSuccess || hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) != hipSuccess ||
-		    hipMalloc((void**)&e->d_logmode, 4) != hipSuccess || hipMalloc((void**)&e->d_logstats, 24) != hipSuccess || hipMalloc((void**)&e->d_probe, 4u << 20) != hipSuccess) {
-			ntc_destroy(e);
-			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log on device", (unsigned long long)e->log_cap);
+	if (e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_DIRECT_ATOMICS)) {
+		// The log and the two partition work areas of the same total size (at the default of four entries per counter and rBits = 27:
+		// 4 + 5.4 + 7 GiB) are allocated HERE, so that memory runs out at create time and not in the middle of a run; when it does, the
+		// capacity is halved until it fits, and an engine that cannot even hold 2^18 entries increments with device atomics instead.
+		uint64_t want = cfg->log_entries;
+		while (plan_log(e, want)) {
+			const auto& ap = e->ap;
+			const size_t runs1 = ap.b1 ? (size_t)ap.g1 << ap.b1 : 0, runs2 = ap.b2 ? ((size_t)ap.parts2 << ap.b1) << ap.b2 : 0;
+			bool ok = hipMalloc((void**)&e->d_log, e->log_cap * 4) == hipSuccess && hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) == hipSuccess;
+			ok = ok && (e->d_logmode || hipMalloc((void**)&e->d_logmode, 4) == hipSuccess) && (e->d_logstats || hipMalloc((void**)&e->d_logstats, 24) == hipSuccess) &&
+			     (e->d_probe || hipMalloc((void**)&e->d_probe, 4u << 20) == hipSuccess);
+			ok = ok && (!runs1 || (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * 4) == hipSuccess && hipMalloc((void**)&e->d_c1, runs1 * 4) == hipSuccess));
+			ok = ok && (!runs2 || (hipMalloc((void**)&e->d_s2, runs2 * ap.cap2 * 4) == hipSuccess && hipMalloc((void**)&e->d_c2, runs2 * 4) == hipSuccess));
+			if (ok) break;
+			(void)hipGetLastError();
+			for (void** d : {(void**)&e->d_log, (void**)&e->d_logfill, (void**)&e->d_s1, (void**)&e->d_c1, (void**)&e->d_s2, (void**)&e->d_c2})
+				if (*d) {
+					(void)hipFree(*d);
+					*d = nullptr;
+				}
+			if (cfg->log_entries != 0 || e->log_cap <= (1ull << 18)) { // an explicit request that does not fit is an error; otherwise: no log
+				if (cfg->log_entries != 0) {
+					const unsigned long long asked = (unsigned long long)e->log_cap;
+					ntc_destroy(e);
+					return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log and its partition areas on device", asked);
+				}
+				e->log_regions = e->log_region_cap = 0;
+				e->log_cap = 0;
+				break;
+			}
+			want = e->log_cap / 2;
 		}
 	}
 	// K1b (bit-sliced filter walk) is instantiated for k = 32: such an engine gives it every large equal-length batch.  K1b
