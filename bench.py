@@ -235,7 +235,8 @@ def main():
         args.k, args.gap = 12, 2
     if args.layout == "auto":
         kl = klist_of(args)
-        args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and args.gap == 0 and args.s_bits >= 7 and not args.lane_kernel and not args.bitslice) else "rows"
+        k1h_gap = len(kl) == 1 and kl[0] == 12 and args.gap == 2 and not args.teams  # K1h's spaced-seed variant (config 5)
+        args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and (args.gap == 0 or k1h_gap) and args.s_bits >= 7 and not args.lane_kernel and not args.bitslice) else "rows"
     import torch
     import torch.distributed as dist
     import ntcard_amd as nt
@@ -382,8 +383,8 @@ def main():
         step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: K1f on the side stream, counted in full although it overlaps the next hash launch)
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
-        if (tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel
-                and not args.teams):
+        if (tiled and nk == 1 and ((klist[0] == 32 and not args.gap) or (klist[0] == 12 and args.gap == 2)) and args.s_bits >= 7
+                and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel and not args.teams):
             kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_f1 / k1h_suspect kernels (K1f, side stream)"
         elif tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
             kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"

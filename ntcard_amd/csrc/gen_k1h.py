@@ -35,7 +35,7 @@ Nothing is copied from the reference: the four seeds are its constants (nthash.h
 import os
 import sys
 
-from gen_bs import step_terms, ttbl, g_of, hseed, rol31, COMP, CODE2  # noqa: F401
+from gen_bs import step_terms, ttbl, g_of, hseed, rol31, tt4, COMP, CODE2  # noqa: F401
 from k1h_asm import Prog, v, s, vr, sr, schedule
 
 WAVES = 6                    # waves per workgroup = tiles in flight per CU
@@ -134,16 +134,25 @@ KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_
 
 
 class Gen:
-    def __init__(self, k, sb_class=7):
-        assert 12 <= k <= 32
+    def __init__(self, k, sb_class=7, gap=0):
+        assert 12 <= k <= 32 and 0 <= gap < k - 1
         self.k = k
         self.sb = sb_class
+        self.gap = gap                      # spaced seed "1" x (k-g)/2 "0" x g "1" x rest (ntcard.cpp:407-413): the g middle positions do not enter the hash
+        self.g0 = (k - gap) // 2            # first don't-care position
+        self.g1 = self.g0 + gap - 1         # last one
         self.phi = (k - 1) % 16
         self.j = (k - 1) // 16      # window start chunk = n - 1 - j
         self.ng = n_groups(k)
         self.p = Prog()
         self.uid = 0
         self.f_terms, self.r_terms = step_terms(k)
+        # spaced seed (nthash.hpp:641-646: the don't-care positions' terms are XORed out of fh / rh): shifting the window by one base changes
+        # two more terms per strand — the base that leaves the don't-care block at its low end comes in, the one that enters it at its high
+        # end goes out:  F'[j] ^= S[j-(k-g0)](leave) ^ S[j-(k-1-g1)](enter),  R'[j] ^= Sc[j+1-g0](leave) ^ Sc[j-g1](enter)
+        if gap:
+            self.fg_terms = [(tt4(jj - (k - self.g0)), tt4(jj - (k - 1 - self.g1))) for jj in range(31)]
+            self.rg_terms = [(tt4(jj + 1 - self.g0, True), tt4(jj - self.g1, True)) for jj in range(31)]
         self.exp = set(x for x in os.environ.get("K1H_EXP", "").split(",") if x)  # timing experiments (tools/k1h_variant.sh): WRONG results
 
     def lbl(self, base):
@@ -180,19 +189,28 @@ class Gen:
     def poly_a(self, strand):
         h = 0
         for t in range(self.k):
+            if self.gap and self.g0 <= t <= self.g1:
+                continue
             h ^= rol31(hseed("A"), self.k - 1 - t) if strand == "F" else rol31(hseed(COMP["A"]), t)
         return h
 
     # ---- one walk step -------------------------------------------------------------------------------------
+    def plane_back(self, a, d):
+        """register of plane bit 0 of the base d positions behind the one step a takes in (d = 0: the incoming base, d = k: the outgoing one)"""
+        q = self.phi + a - d                 # position relative to the start of chunk n - 1
+        if q >= 16:
+            return V_I + 2 * (q - 16)
+        if q >= 0:
+            return V_H1 + 2 * q
+        if q >= -16:
+            return V_H0 + 2 * (q + 16)
+        assert q == -17 and self.j == 1      # (n - 3, 15): saved before its registers took packed words
+        return V_CARRY0
+
     def planes_of_step(self, a):
         """registers of the incoming / outgoing base planes of step a"""
-        pos = self.phi + a
-        i0 = (V_H1 + 2 * pos) if pos < 16 else (V_I + 2 * (pos - 16))
-        if self.j == 1:
-            o0 = V_CARRY0 if a == 0 else V_H0 + 2 * (a - 1)
-        else:
-            o0 = V_H0 + 30 if a == 0 else V_H1 + 2 * (a - 1)
-        return i0, i0 + 1, o0, (V_CARRY1 if (self.j == 1 and a == 0) else o0 + 1)
+        i0, o0 = self.plane_back(a, 0), self.plane_back(a, self.k)
+        return i0, i0 + 1, o0, o0 + 1
 
     def fn_plane(self, cache, t4, b0, b1, tpool):
         """function plane of a 4-bit truth table over (b0, b1): -> (register or None, invert)"""
@@ -243,33 +261,49 @@ class Gen:
 
     def walk_step(self, a):
         i0, i1, o0, o1 = self.planes_of_step(a)
-        tpool = list(range(V_T0 + 13, V_T0 - 1 + 1, -1))  # temps V_T0+1 .. V_T0+13; V_T0 = the wrap-around copy
-        tpool = [V_T0 + 1 + i for i in range(12)][::-1]
-        cin, cout = {}, {}
+        tpool = [V_T0 + 1 + i for i in range(22)][::-1]  # function planes: V_T0 + 1 ..; V_T0 = the wrap-around copy
+        cin, cout, clv, cen = {}, {}, {}, {}
         tmp = V_T0
-        # forward: F'[j] = F[j-1] ^ in ^ out, in place from the top (F[30]'s old value feeds F[0])
-        plan = []
-        for strand, terms in (("F", self.f_terms), ("R", self.r_terms)):
+        if self.gap:
+            l0 = self.plane_back(a, self.k - self.g0)       # leaves the don't-care block (window index g0 -> g0 - 1)
+            e0 = self.plane_back(a, self.k - 1 - self.g1)   # enters it (g1 + 1 -> g1)
+        plan = {}
+        for strand, terms, gterms in (("F", self.f_terms, getattr(self, "fg_terms", None)), ("R", self.r_terms, getattr(self, "rg_terms", None))):
             for jj in range(31):
                 tin, tout = terms[jj]
                 x, xi = self.fn_plane(cin, tin, i0, i1, tpool)
                 y, yi = self.fn_plane(cout, tout, o0, o1, tpool)
-                plan.append((strand, jj, x, y, xi ^ yi))
-        fplan = {jj: (x, y, inv) for st, jj, x, y, inv in plan if st == "F"}
-        rplan = {jj: (x, y, inv) for st, jj, x, y, inv in plan if st == "R"}
+                inv = xi ^ yi
+                ops = [z for z in (x, y) if z is not None]
+                if self.gap:
+                    tl, te = gterms[jj]
+                    u, ui = self.fn_plane(clv, tl, l0, l0 + 1, tpool)
+                    w, wi = self.fn_plane(cen, te, e0, e0 + 1, tpool)
+                    inv ^= ui ^ wi
+                    ops += [z for z in (u, w) if z is not None]
+                plan[strand, jj] = (ops, inv)
+
+        def update(dst, prev, ops, inv):
+            # dst = prev ^ ops... ^ inv, three inputs per instruction
+            ops = list(ops)
+            cur = prev
+            first = True
+            while first or ops:
+                first = False
+                take, ops = ops[:2], ops[2:]
+                last = not ops
+                self.emit_update(dst, cur, take[0] if take else None, take[1] if len(take) > 1 else None, inv if last else 0)
+                cur = dst
+        # forward: F'[j] = F[j-1] ^ terms, in place from the top (F[30]'s old value feeds F[0])
         self.p.i("v_mov_b32", v(tmp), v(V_F + 30))
         for jj in range(30, 0, -1):
-            x, y, inv = fplan[jj]
-            self.emit_update(V_F + jj, V_F + jj - 1, x, y, inv)
-        x, y, inv = fplan[0]
-        self.emit_update(V_F + 0, tmp, x, y, inv)
-        # reverse: R'[j] = R[j+1] ^ in ^ out, in place from the bottom
+            update(V_F + jj, V_F + jj - 1, *plan["F", jj])
+        update(V_F + 0, tmp, *plan["F", 0])
+        # reverse: R'[j] = R[j+1] ^ terms, in place from the bottom
         self.p.i("v_mov_b32", v(tmp), v(V_R + 0))
         for jj in range(0, 30):
-            x, y, inv = rplan[jj]
-            self.emit_update(V_R + jj, V_R + jj + 1, x, y, inv)
-        x, y, inv = rplan[30]
-        self.emit_update(V_R + 30, tmp, x, y, inv)
+            update(V_R + jj, V_R + jj + 1, *plan["R", jj])
+        update(V_R + 30, tmp, *plan["R", 30])
 
     # ---- sample test of one strand: planes a (top bits == sample-1 pattern), g (>=), b (== sample-0 pattern), nz ----
     def strand_flags(self, base, out):
@@ -1020,22 +1054,23 @@ class Gen:
         return p
 
 
-def render_inc(k, sb):
-    g = Gen(k, sb)
+def render_inc(k, sb, gap=0):
+    g = Gen(k, sb, gap)
     prog = g.build()
     lines = prog.render(label_fmt=".Lk1h_{}_%=")
     body = "\n".join('\t"' + ln.replace('"', '\\"') + '\\n"' for ln in lines)
-    return f"// GENERATED by gen_k1h.py (k = {k}, sBits class {sb}): {prog.n_insts()} instructions\n#define K1H_ASM_K{k}_S{sb} \\\n" + \
+    return f"// GENERATED by gen_k1h.py (k = {k}, gap = {gap}, sBits class {sb}): {prog.n_insts()} instructions\n#define K1H_ASM_K{k}_G{gap}_S{sb} \\\n" + \
         "\n".join(ln + " \\" for ln in body.split("\n")) + "\n\n"
+
+
+VARIANTS = ((32, 0), (12, 2))  # (k, gap) the library is built with: BASELINE configs 2 / 3 and 5
 
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else "ntc_k1h_gen.inc"
-    ks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [32]
     with open(out, "w") as f:
         f.write("// ntc_k1h_gen.inc — GENERATED by gen_k1h.py (do not edit)\n")
-        f.write(f"#define K1H_N_INPUTS {len(INPUTS)}\n")
-        for k in ks:
+        for k, gap in VARIANTS:
             for sb in (7, 8):
-                f.write(render_inc(k, sb))
+                f.write(render_inc(k, sb, gap))
     print("wrote", out)

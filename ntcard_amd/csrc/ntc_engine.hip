@@ -261,7 +261,6 @@ struct ntc_engine {
 	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry, of klist[0] (NULL: neither is used by this engine)
 	std::vector<void*> d_t4s;       // K1c: one table per k of the list (d_t4s[0] == d_t4)
 	std::vector<uint32_t*> d_k1h_tabs; // K1h: closed-form table per k of the list (nullptr: K1c takes that k)
-	std::vector<void*> d_k1h_fix;      // K1f: per-byte rolling terms of that k
 	bool k1h_wanted = true;         // !NTC_FLAG_TILED_TEAMS
 	// What K1h hands to K1f (two bit arrays, the suspect list, a little state): two sets, so that — for a caller that promised to leave its
 	// batches alone until ntc_sync (NTC_FLAG_DEFER_REDO) — K1f of one batch runs on a side stream beside K1h of the next one (K1f waits on
@@ -926,7 +925,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				h.r_bits = e->r_bits;
 				ntc::K1hArgs launched;
 				uint32_t n_waves = 0;
-				HIP_TRY(ntc::launch_sketch_k1h(h, k, (unsigned)di.cus, e->stream, &launched, &n_waves));
+				HIP_TRY(ntc::launch_sketch_k1h(h, k, e->gap, (unsigned)di.cus, e->stream, &launched, &n_waves));
 				if (side) {
 					HIP_TRY(hipEventRecord(ks.k1h_done, e->stream));
 					HIP_TRY(hipStreamWaitEvent(e->k1f_stream, ks.k1h_done, 0));
@@ -936,7 +935,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 						HIP_TRY(hipEventCreate(&f1));
 						HIP_TRY(hipEventRecord(f0, e->k1f_stream));
 					}
-					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_k1h_fix[ki], e->d_t4s[ki], (unsigned)di.cus, e->k1f_stream));
+					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_t4s[ki], (unsigned)di.cus, e->k1f_stream));
 					if (e->profiling) {
 						HIP_TRY(hipEventRecord(f1, e->k1f_stream));
 						e->k1f_events.emplace_back(f0, f1);
@@ -944,7 +943,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 					HIP_TRY(hipEventRecord(ks.k1f_done, e->k1f_stream));
 					ks.k1f_pending = true;
 				} else {
-					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_k1h_fix[ki], e->d_t4s[ki], (unsigned)di.cus, e->stream));
+					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_t4s[ki], (unsigned)di.cus, e->stream));
 				}
 				continue;
 			}
@@ -1106,15 +1105,16 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
 	// K1c (tiled streaming kernel): every k of the list must have an instantiation (k = 12 .. 32); a list is served by one launch
 	// per k over the same resident tiles.  Its hit-log keys and its direct-atomics fallback are 32-bit counter indices.
-	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->gap == 0 && e->hll_bits == 0 &&
-	           e->klist.size() * e->plane_elems() <= (1ull << 32);
-	for (uint32_t k : e->klist)
-		e->ts_ok = e->ts_ok && ntc::sketch_ts_supports(k, e->s_bits) && ntc::sketch_ts_smem(k) <= 160 * 1024;
+	e->k1h_wanted = !(cfg->flags & NTC_FLAG_TILED_TEAMS);
+	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->hll_bits == 0 && e->klist.size() * e->plane_elems() <= (1ull << 32);
+	for (uint32_t k : e->klist) // every k of the list needs a tiled kernel: K1h (its (k, gap) variants) or K1c (k = 12 .. 32, no spaced seed)
+		e->ts_ok = e->ts_ok && ((e->k1h_wanted && ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits)) ||
+		                        (e->gap == 0 && ntc::sketch_ts_supports(k, e->s_bits) && ntc::sketch_ts_smem(k) <= 160 * 1024));
 	e->bs_ok = e->kernel_kind == KIND_HF && bs_wanted && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 && ntc::sketch_bs_supports(e->klist[0], e->s_bits);
 	if (e->bs_ok || e->ts_ok) {
 		for (size_t ki = 0; ki < (e->ts_ok ? e->klist.size() : 1); ++ki) {
 			std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[ki]) * 256 * 4);
-			ntc::build_t4(e->klist[ki], t4.data());
+			ntc::build_t4(e->klist[ki], t4.data(), (e->klist[ki] - e->gap) / 2, e->gap);
 			void* d = nullptr;
 			if (hipMalloc(&d, t4.size() * 4) != hipSuccess || hipMemcpy(d, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
 				if (d) (void)hipFree(d);
@@ -1126,16 +1126,14 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		e->d_t4 = e->d_t4s[0];
 	}
 	if (!e->d_t4) e->ts_ok = e->bs_ok = false;
-	// K1h (one wave per tile) takes the k it is generated for; K1c keeps the others of a list
-	e->k1h_wanted = !(cfg->flags & NTC_FLAG_TILED_TEAMS);
+	// K1h (one wave per tile) takes the (k, gap) it is generated for; K1c keeps the others of a list
 	e->d_k1h_tabs.assign(e->klist.size(), nullptr);
-	e->d_k1h_fix.assign(e->klist.size(), nullptr);
 	if (e->ts_ok && e->k1h_wanted) {
 		for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 			const uint32_t k = e->klist[ki];
-			if (!ntc::sketch_k1h_supports(k, e->s_bits, e->r_bits)) continue;
+			if (!ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits)) continue;
 			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);
-			ntc::build_k1h_table(k, e->r_bits, e->s_bits, tab.data());
+			ntc::build_k1h_table(k, e->gap, e->r_bits, e->s_bits, tab.data());
 			uint32_t* d = nullptr;
 			if (hipMalloc((void**)&d, tab.size() * 4) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
 				if (d) (void)hipFree(d);
@@ -1143,15 +1141,6 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the tiled kernel on device");
 			}
 			e->d_k1h_tabs[ki] = d;
-			std::vector<unsigned char> ftab(ntc::k1h_fix_tables_bytes());
-			ntc::build_k1h_fix_tables(k, ftab.data());
-			void* df = nullptr;
-			if (hipMalloc(&df, ftab.size()) != hipSuccess || hipMemcpy(df, ftab.data(), ftab.size(), hipMemcpyHostToDevice) != hipSuccess) {
-				if (df) (void)hipFree(df);
-				ntc_destroy(e);
-				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the fix-up tables of the tiled kernel on device");
-			}
-			e->d_k1h_fix[ki] = df;
 		}
 	}
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
@@ -1191,8 +1180,6 @@ void ntc_destroy(ntc_engine* e)
 	for (void* d : e->d_t4s)
 		if (d) (void)hipFree(d);
 	for (uint32_t* d : e->d_k1h_tabs)
-		if (d) (void)hipFree(d);
-	for (void* d : e->d_k1h_fix)
 		if (d) (void)hipFree(d);
 	for (hipStream_t st : e->mc.lanes)
 		if (st) {

@@ -145,14 +145,12 @@ struct K1hArgs {
 	uint32_t sus_cap, launch_id;
 	uint32_t* fix_state;          // K1f scratch: [0] = launch_id of the last launch that must take the slow path, [2..3] = F1 correction (uint64)
 };
-bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits);
+bool sketch_k1h_supports(uint32_t k, uint32_t gap, uint32_t s_bits, uint32_t r_bits);
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len);
-void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t s_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
+void build_k1h_table(uint32_t k, uint32_t gap, uint32_t r_bits, uint32_t s_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
 hipError_t set_sketch_k1h_smem_limit();
-void build_k1h_fix_tables(uint32_t k, void* out /* k1h_fix_tables_bytes() */);
-size_t k1h_fix_tables_bytes();
-hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves);
-hipError_t launch_k1h_fixup(const K1hArgs& launched, uint32_t k, uint32_t n_k1h_waves, const void* fix_tables, const void* t4 /* build_t4 */, unsigned cus, hipStream_t st);
+hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves);
+hipError_t launch_k1h_fixup(const K1hArgs& launched, uint32_t k, uint32_t n_k1h_waves, const void* t4 /* build_t4, with the engine's gap */, unsigned cus, hipStream_t st);
 // tiled layout -> row-major slots: device-side re-layout for the configurations the tiled kernels are not built for
 hipError_t launch_gen_tiled(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint32_t dist, uint64_t glen, hipStream_t st);
 hipError_t launch_untile(const unsigned char* tiles, unsigned char* slots, uint64_t n_reads, uint32_t read_len, uint32_t stride, hipStream_t st);

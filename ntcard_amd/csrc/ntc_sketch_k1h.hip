@@ -41,7 +41,7 @@ static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && of
 constexpr uint32_t kK1hWaves = 6;
 constexpr uint32_t kK1hWArea = 25600;
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
-constexpr uint32_t kK1hLdsBytes = kK1hTableOff + 2u * 11u * 256u; // exactly what the waves use: the 4.5 KiB left of a CU's LDS let k1h_f1_kernel's blocks in beside them
+constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + 2u * ((k + 2u) / 3u) * 256u; } // exactly what the waves use: what is left of a CU's LDS lets k1h_f1_kernel's blocks in beside them
 
 #define K1H_CLOBBERS_V                                                                                                                 \
 	"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20",   \
@@ -63,7 +63,7 @@ constexpr uint32_t kK1hLdsBytes = kK1hTableOff + 2u * 11u * 256u; // exactly wha
 
 } // namespace
 
-template <int K, int SB>
+template <int K, int SB, int GAP>
 __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -81,11 +81,14 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 	const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
 	const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)karg);
 	const uint32_t karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(karg >> 32));
-	static_assert(K == 32 && (SB == 7 || SB == 8), "gen_k1h.py emits this k for the two s_bits classes (7, >= 8)");
-	if constexpr (SB == 7)
-		asm volatile(K1H_ASM_K32_S7 ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S);
-	else
-		asm volatile(K1H_ASM_K32_S8 ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S);
+	// gen_k1h.py (VARIANTS) emits one body per (k, gap) and s_bits class (7, >= 8)
+#define K1H_BODY(text) asm volatile(text ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S)
+	if constexpr (K == 32 && GAP == 0 && SB == 7) K1H_BODY(K1H_ASM_K32_G0_S7);
+	else if constexpr (K == 32 && GAP == 0 && SB == 8) K1H_BODY(K1H_ASM_K32_G0_S8);
+	else if constexpr (K == 12 && GAP == 2 && SB == 7) K1H_BODY(K1H_ASM_K12_G2_S7);
+	else if constexpr (K == 12 && GAP == 2 && SB == 8) K1H_BODY(K1H_ASM_K12_G2_S8);
+	else static_assert(K < 0, "gen_k1h.py emits no body for this (k, gap)");
+#undef K1H_BODY
 }
 
 // ---- K1f ------------------------------------------------------------------------------------------------------------------------
@@ -101,15 +104,11 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 //                     slow path (a suspect region overflowed, or a table-slot byte turned up): every window of every dirty-affected
 //                     block is re-derived from the bytes with the rolling recurrence (nthash.hpp:242-257), suspects are ignored;
 //                     always: the windows of tie blocks that both strands flag, by the same walk.
-// The walk: a wave compacts items into an LDS queue and takes 64 at a time, one per lane; the lane's <= 6 raw pieces are staged in
-// LDS, then one step per position with the per-byte terms of two 256-entry tables
-//   in[b]  = { seed(b), srol^k(comp(b)) },  out[b] = { srol^k(seed(b)), comp(b) },  each 64-bit value as {H | L[32] << 31, L[0..31]}
-// (H: the 31-bit field, L: the 33-bit one, nthash.hpp:186-217); seed(b) == 0 marks a byte that is no base.  It starts from the hash of
-// k 'A's and lets 'A's leave the window until k real bases are in (as K1h does): no separate filling recurrence.
-struct FixTables {
-	uint4 in[256], out[256];
-	uint32_t poly_a[4]; // hash of k 'A's: {f.w0, f.w1, r.w0, r.w1}
-};
+// The slow path's walk: a wave compacts items into an LDS queue and takes 64 at a time, one per lane; the lane's <= 6 raw pieces are staged
+// in LDS, then one step per position: the byte's 2-bit code shifts into a 64-bit register (the last 32 bases), a counter tells how many
+// bases in a row were letters of the reference's table, and where a window ends its hash is the closed form over four bases per look-up
+// (nthash.hpp:220-239; K1c's table, built with the engine's spaced seed if it has one).  Bytes 1, 3, 4, 5, 7 are bases here, with the codes
+// and the complement rule of the reference's table (nthash.hpp:16,32).
 constexpr uint32_t kFixQCap = 128;
 constexpr uint32_t kFixStage = 6 * 16; // bytes per lane: up to 6 pieces (k - 1 + 48 positions from any offset in the first one)
 
@@ -284,21 +283,35 @@ __global__ __launch_bounds__(256) void k1h_suspect_kernel(const K1hArgs a, const
 	if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<unsigned long long*>(a.fix_state + 2) = 0ull; // (ready for the next launch; the slow path counts F1 itself)
 }
 
-__global__ __launch_bounds__(256) void k1h_slow_kernel(const K1hArgs a, const FixTables* __restrict__ ft, uint32_t k)
+// byte -> bits 0..2: code2 of the base (A 0, C 1, T/U 2, G 3; 4: no base), bits 4..5: the code whose letter-complement is what the
+// reference complements this byte to, table[byte & 7] (nthash.hpp:16,32).  For a letter that is its own code; for the table's slots
+// 1, 3, 4, 5, 7 — bases to the reference — it is not: their "complement" is the slot's own base.
+__device__ __forceinline__ uint32_t base_class(uint32_t c)
 {
-	__shared__ uint4 s_in[256], s_out[256];
+	auto code = [](uint32_t b) -> uint32_t { // 4: no base
+		switch (b) {
+		case 'A': case 'a': case 4: case 5: return 0u;
+		case 'C': case 'c': case 7: return 1u;
+		case 'T': case 't': case 'U': case 'u': case 1: return 2u;
+		case 'G': case 'g': case 3: return 3u;
+		default: return 4u;
+		}
+	};
+	const uint32_t f = code(c);
+	return f | (((code(c & 7u) ^ 2u) & 3u) << 4);
+}
+
+__global__ __launch_bounds__(256) void k1h_slow_kernel(const K1hArgs a, const void* __restrict__ t4, uint32_t k)
+{
 	__shared__ uint2 s_queue[4][kFixQCap];
 	__shared__ __align__(16) unsigned char s_stage[4][64 * kFixStage];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-	s_in[tid] = ft->in[tid];
-	s_out[tid] = ft->out[tid];
-	__syncthreads();
 	const uint32_t phi = (k - 1u) & 15u;
 	const uint32_t nb = ((a.read_len - 1u + 16u - phi) >> 4) + 1u, C = a.n_chunks;
 	const uint64_t n_dirty = (uint64_t)a.n_tiles * C * 64u, n_tie = (uint64_t)a.n_tiles * nb * 64u;
-	const uint32_t pa0 = ft->poly_a[0], pa1 = ft->poly_a[1], pa2 = ft->poly_a[2], pa3 = ft->poly_a[3];
 	const uint32_t s_bits = a.s_bits, r_bits = a.r_bits, L = a.read_len;
 	const uint32_t rmask = (1u << r_bits) - 1u;
+	const uint4* const t4v = reinterpret_cast<const uint4*>(t4);
 	uint2* const queue = s_queue[wv];
 	unsigned char* const stage = s_stage[wv] + lane * kFixStage;
 	uint32_t qhead = 0, qtail = 0; // wave-uniform
@@ -318,87 +331,64 @@ __global__ __launch_bounds__(256) void k1h_slow_kernel(const K1hArgs a, const Fi
 		e_lo = max(e_lo, (int)k - 1);
 		e_hi = min(e_hi, (int)L - 1);
 		const int p0 = e_lo - (int)k + 1;
-		int len = act && e_hi >= e_lo ? e_hi - p0 + 1 : 0; // positions to walk
+		const int len = act && e_hi >= e_lo ? e_hi - p0 + 1 : 0; // positions to walk
 		// stage the pieces [p0 >> 4, e_hi >> 4] of the read
-		const unsigned char* tile = a.tiles + (size_t)t * C * (kTileReads * 16u);
 		const int c0 = p0 >> 4, np = len > 0 ? (e_hi >> 4) - c0 + 1 : 0;
 #pragma unroll
 		for (int j = 0; j < 6; ++j)
-			if (j < np) *reinterpret_cast<uint4*>(stage + 16 * j) = *reinterpret_cast<const uint4*>(tile + ((size_t)(c0 + j) * kTileReads + r) * 16u);
+			if (j < np) *reinterpret_cast<tilebits::v4u32*>(stage + 16 * j) = raw_piece(a, t, (uint32_t)(c0 + j), r);
 		// (a lane reads back only what it wrote itself: no barrier)
-		uint32_t f0 = pa0, f1 = pa1, r0 = pa2, r1 = pa3; // strand states {H | L[32] << 31, L[0..31]}
-		uint32_t good = 0;
 		const uint32_t off0 = (uint32_t)(p0 & 15);
 		const int first_end = e_lo - p0; // step index of the first window end
 		int max_len = len;
 		for (int o = 32; o > 0; o >>= 1)
 			max_len = max(max_len, __shfl_xor(max_len, o));
-		// one rolling step per position; the byte and its two table entries are fetched one iteration ahead of their use (three LDS
-		// round trips in a row would otherwise be all a lone item-walk does)
-		uint32_t bi_n = stage[len > 0 ? off0 : 0u];
-		uint4 ein_n = s_in[bi_n];
-		uint4 eo_n = s_out[(uint32_t)'A'];
+		uint64_t fw = 0, rc = 0; // 2-bit codes of the last 32 bases, oldest lowest: the bases themselves / their complements
+		uint32_t good = 0;
 		for (int i = 0; i < max_len; ++i) {
-			const bool on = i < len;
-			const uint4 ein = ein_n, eo_real = eo_n;
-			{ // prefetch for position i + 1: its byte, and the byte that leaves the window there (position i + 1 - k, if staged)
-				const bool nx = i + 1 < len;
-				bi_n = stage[nx ? off0 + (uint32_t)(i + 1) : 0u];
-				const uint32_t bo_n = stage[nx && i + 1 >= (int)k ? off0 + (uint32_t)(i + 1) - k : 0u];
-				ein_n = s_in[bi_n];
-				eo_n = s_out[bo_n];
+			if (i >= len) continue;
+			const uint32_t cls = base_class(stage[off0 + (uint32_t)i]);
+			if ((cls & 4u) != 0u) { // not a base: the window restarts behind it
+				good = 0;
+			} else {
+				++good;
+				fw = (fw >> 2) | ((uint64_t)(cls & 3u) << 62);
+				rc = (rc >> 2) | ((uint64_t)((cls >> 4) & 3u) << 62);
 			}
-			if (on) {
-				if (ein.x == 0u) { // not a base: the window restarts behind it
-					good = 0;
-					f0 = pa0;
-					f1 = pa1;
-					r0 = pa2;
-					r1 = pa3;
+			if (i < first_end) continue;
+			if (good < k) {
+				if (!ties) ++f1_sub;
+				continue;
+			}
+			// the window's k bases, base i at bits 2i+1:2i -> four bases per look-up: fh = XOR srol^(k-1-i) seed(c_i), rh = XOR srol^i comp(c_i)
+			const uint64_t wf = fw >> (64u - 2u * k), wr = rc >> (64u - 2u * k);
+			uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+			for (uint32_t g = 0; g < (k + 3u) / 4u; ++g) {
+				const uint4 xf = t4v[g * 256u + (uint32_t)((wf >> (8u * g)) & 0xffu)];
+				f0 ^= xf.x;
+				f1 ^= xf.y;
+				const uint4 xr = t4v[g * 256u + (uint32_t)((wr >> (8u * g)) & 0xffu)];
+				r0 ^= xr.z;
+				r1 ^= xr.w;
+			}
+			const uint64_t fh = ((uint64_t)f1 << 32) | f0, rh = ((uint64_t)r1 << 32) | r0;
+			if (ties) {
+				const uint32_t f8 = (uint32_t)(fh >> 56), r8 = (uint32_t)(rh >> 56);
+				bool cf, cr;
+				if (s_bits == 7u) {
+					cf = ((f8 >> 1) == 0x3fu && (r8 >> 1) >= 0x3fu) || (f8 == 1u && r8 >= 1u);
+					cr = ((r8 >> 1) == 0x3fu && (f8 >> 1) >= 0x3fu) || (r8 == 1u && f8 >= 1u);
 				} else {
-					++good;
-					const uint4 eo = good > k ? eo_real : s_out[(uint32_t)'A']; // the first k bases of a run push out 'A's (the start state's)
-					// forward: srol by one, then the two terms (nthash.hpp:242-248)
-					const uint32_t nf1 = __builtin_amdgcn_alignbit(f1, f0, 31);
-					const uint32_t nf0 = ((f0 << 1) & 0x7ffffffeu) | ((f0 >> 30) & 1u) | (f1 & 0x80000000u);
-					f0 = nf0 ^ ein.x ^ eo.x;
-					f1 = nf1 ^ ein.y ^ eo.y;
-					// reverse: the two terms, then sror by one (nthash.hpp:251-257)
-					const uint32_t x0 = r0 ^ ein.z ^ eo.z, x1 = r1 ^ ein.w ^ eo.w;
-					r1 = __builtin_amdgcn_alignbit(x0 >> 31, x1, 1);
-					r0 = ((x0 & 0x7fffffffu) >> 1) | ((x0 & 1u) << 30) | (x1 << 31);
+					cf = (f8 == 0x7fu && r8 >= 0x7fu) || f8 == 0u;
+					cr = (r8 == 0x7fu && f8 >= 0x7fu) || r8 == 0u;
 				}
-				if (i >= first_end) {
-					if (good < k) {
-						if (!ties) ++f1_sub;
-					} else {
-						const uint32_t fH = f0 & 0x7fffffffu, rH = r0 & 0x7fffffffu;
-						// canonical strand (nthash.hpp:275-279): compare H, then L[32], then L[0..31]
-						const bool rev = rH != fH ? rH < fH : ((r0 ^ f0) >> 31) ? (r0 >> 31) < (f0 >> 31) : r1 < f1;
-						const uint32_t hH = rev ? rH : fH, hL = rev ? r1 : f1;
-						// ntComp (ntcard.cpp:132-145) on the top s_bits + 1 bits: all of them lie in H (s_bits <= 30)
-						uint32_t smp = 2;
-						if ((hH >> (30u - s_bits)) == 1u) smp = 0;
-						if ((hH >> (31u - s_bits)) == (1u << (s_bits - 1u)) - 1u) smp = 1;
-						if (smp < 2u) { // rare (2^(1 - s_bits))
-							bool take = true;
-							if (ties) {
-								const uint32_t f8 = fH >> 23, r8 = rH >> 23;
-								bool cf, cr;
-								if (s_bits == 7u) {
-									cf = ((f8 >> 1) == 0x3fu && (r8 >> 1) >= 0x3fu) || (f8 == 1u && r8 >= 1u);
-									cr = ((r8 >> 1) == 0x3fu && (f8 >> 1) >= 0x3fu) || (r8 == 1u && f8 >= 1u);
-								} else {
-									cf = (f8 == 0x7fu && r8 >= 0x7fu) || f8 == 0u;
-									cr = (r8 == 0x7fu && f8 >= 0x7fu) || r8 == 0u;
-								}
-								take = cf && cr;
-							}
-							if (take) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(hL & rmask), 1u);
-						}
-					}
-				}
+				if (!(cf && cr)) continue;
 			}
+			const uint64_t h = rh < fh ? rh : fh;                                                          // nthash.hpp:275-279
+			uint32_t smp = 2;                                                                             // ntcard.cpp:132-145
+			if ((h >> (63u - s_bits)) == 1ull) smp = 0;
+			if ((h >> (64u - s_bits)) == (1ull << (s_bits - 1u)) - 1ull) smp = 1;
+			if (smp < 2u) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(h & (uint64_t)rmask), 1u);
 		}
 		qhead += n_items;
 	};
@@ -466,46 +456,13 @@ __global__ __launch_bounds__(256) void k1h_slow_kernel(const K1hArgs a, const Fi
 	if (lane == 0u && f1_sub != 0u) atomicAdd(a.f1, (unsigned long long)0 - (unsigned long long)f1_sub);
 }
 
-void build_k1h_fix_tables(uint32_t k, void* out_)
-{
-	FixTables* out = static_cast<FixTables*>(out_);
-	auto seed_b = [](unsigned c) -> uint64_t { // the reference's byte table (nthash.hpp:31-64)
-		switch (c) {
-		case 'A': case 'a': case 4: case 5: return kSeed[0];
-		case 'C': case 'c': case 7: return kSeed[1];
-		case 'G': case 'g': case 3: return kSeed[2];
-		case 'T': case 't': case 'U': case 'u': case 1: return kSeed[3];
-		default: return 0;
-		}
-	};
-	auto w0 = [](uint64_t x) { return (uint32_t)(x >> 33) | ((uint32_t)((x >> 32) & 1u) << 31); };
-	auto w1 = [](uint64_t x) { return (uint32_t)x; };
-	for (unsigned c = 0; c < 256; ++c) {
-		const uint64_t sd = seed_b(c), sc = seed_b(c & 7u); // complement = the table at byte & 7 (nthash.hpp:16)
-		if (sd == 0) {
-			out->in[c] = make_uint4(0, 0, 0, 0);
-			out->out[c] = make_uint4(0, 0, 0, 0);
-			continue;
-		}
-		const uint64_t tsc = srol(sc, k), tsd = srol(sd, k);
-		out->in[c] = make_uint4(w0(sd), w1(sd), w0(tsc), w1(tsc));
-		out->out[c] = make_uint4(w0(tsd), w1(tsd), w0(sc), w1(sc));
-	}
-	uint64_t fh = 0, rh = 0;
-	for (unsigned i = 0; i < k; ++i) {
-		fh ^= srol(seed_of(0), i);
-		rh ^= srol(comp_of(0), i);
-	}
-	out->poly_a[0] = w0(fh);
-	out->poly_a[1] = w1(fh);
-	out->poly_a[2] = w0(rh);
-	out->poly_a[3] = w1(rh);
-}
-size_t k1h_fix_tables_bytes() { return sizeof(FixTables); }
 
 // the resolve pass works on ONE 32-bit word per candidate: the low r_bits bits of the hash, the bit that tells the samples apart, and
 // (s_bits >= 8) the s_bits - 7 bits between the 8-bit prefix the walk tests and the end of ntComp's patterns
-bool sketch_k1h_supports(uint32_t k, uint32_t s_bits, uint32_t r_bits) { return k == 32 && s_bits >= 7 && s_bits <= 30 && r_bits + 1 + (s_bits - 7) <= 32; }
+bool sketch_k1h_supports(uint32_t k, uint32_t gap, uint32_t s_bits, uint32_t r_bits)
+{
+	return ((k == 32 && gap == 0) || (k == 12 && gap == 2)) && s_bits >= 7 && s_bits <= 30 && r_bits + 1 + (s_bits - 7) <= 32;
+}
 
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len) { return ((read_len - 1u + 16u - ((k - 1u) & 15u)) >> 4) + 1u; }
 
@@ -513,7 +470,7 @@ uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len) { return ((read_len - 
 // of the group in bits 2t+1:2t).  Word = low r_bits bits of the strand's term (nthash.hpp:220-239: fh = XOR srol^(k-1-i) seed(c_i),
 // rh = XOR srol^i comp(c_i)) | its bit 62 << r_bits: ntComp's patterns differ in that bit, and the counter index is
 // key_base + (sample << r_bits) + (hash & (rBuck - 1)) (ntcard.cpp:132-145); s_bits >= 8: + hash bits 55 .. 63 - s_bits above that
-void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t s_bits, uint32_t* out)
+void build_k1h_table(uint32_t k, uint32_t gap, uint32_t r_bits, uint32_t s_bits, uint32_t* out)
 {
 	static const unsigned code_of_code2[4] = { 0, 1, 3, 2 };
 	const uint32_t ng = (k + 2) / 3;
@@ -524,6 +481,7 @@ void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t s_bits, uint32_t* out
 				for (uint32_t t = 0; t < 3; ++t) {
 					const uint32_t i = 3 * g + t;
 					if (i >= k) break;
+					if (gap && i >= (k - gap) / 2 && i < (k - gap) / 2 + gap) continue; // a don't-care position of the spaced seed (ntcard.cpp:407-413)
 					const unsigned c = code_of_code2[(v >> (2 * t)) & 3u];
 					x ^= st == 0 ? srol(seed_of(c), k - 1 - i) : srol(comp_of(c), i);
 				}
@@ -532,40 +490,50 @@ void build_k1h_table(uint32_t k, uint32_t r_bits, uint32_t s_bits, uint32_t* out
 			}
 }
 
+namespace {
+template <typename F>
+hipError_t for_each_k1h_kernel(F f) // every instantiation, with its k
+{
+	hipError_t rc = f(reinterpret_cast<const void*>(&sketch_k1h_kernel<32, 7, 0>), 32u);
+	if (rc == hipSuccess) rc = f(reinterpret_cast<const void*>(&sketch_k1h_kernel<32, 8, 0>), 32u);
+	if (rc == hipSuccess) rc = f(reinterpret_cast<const void*>(&sketch_k1h_kernel<12, 7, 2>), 12u);
+	if (rc == hipSuccess) rc = f(reinterpret_cast<const void*>(&sketch_k1h_kernel<12, 8, 2>), 12u);
+	return rc;
+}
+} // namespace
 hipError_t set_sketch_k1h_smem_limit()
 {
-	hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLdsBytes);
-	if (rc == hipSuccess) rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLdsBytes);
-	return rc;
+	return for_each_k1h_kernel([](const void* fn, uint32_t k) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k1h_lds_bytes(k)); });
 }
 
 // K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
-hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
+hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
 {
-	if (k != 32) return hipErrorInvalidValue;
+	if (!sketch_k1h_supports(k, gap, a.s_bits, a.r_bits)) return hipErrorInvalidValue;
 	const uint32_t nb = sketch_k1h_blocks(k, a.read_len);
 	const uint64_t total = (uint64_t)a.n_tiles * nb; // blocks of the batch, shared out evenly: a wave needs at least ~4 blocks to be worth its start-up
 	const unsigned grid = (unsigned)std::min<uint64_t>((total + 4 * kK1hWaves - 1) / (4 * kK1hWaves), cus);
 	K1hArgs b = a;
 	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
 	b.nb_magic = (uint32_t)((1ull << 32) / nb);
-	if (a.s_bits == 7)
-		hipLaunchKernelGGL((sketch_k1h_kernel<32, 7>), dim3(grid), dim3(384), kK1hLdsBytes, st, b);
-	else
-		hipLaunchKernelGGL((sketch_k1h_kernel<32, 8>), dim3(grid), dim3(384), kK1hLdsBytes, st, b);
+	const uint32_t lds = k1h_lds_bytes(k);
+	if (k == 32 && a.s_bits == 7) hipLaunchKernelGGL((sketch_k1h_kernel<32, 7, 0>), dim3(grid), dim3(384), lds, st, b);
+	else if (k == 32) hipLaunchKernelGGL((sketch_k1h_kernel<32, 8, 0>), dim3(grid), dim3(384), lds, st, b);
+	else if (a.s_bits == 7) hipLaunchKernelGGL((sketch_k1h_kernel<12, 7, 2>), dim3(grid), dim3(384), lds, st, b);
+	else hipLaunchKernelGGL((sketch_k1h_kernel<12, 8, 2>), dim3(grid), dim3(384), lds, st, b);
 	*args_out = b;
 	*n_waves = grid * kK1hWaves;
 	return hipGetLastError();
 }
 
 // K1f for a batch K1h has been launched over (same arguments), on any stream ordered behind that launch
-hipError_t launch_k1h_fixup(const K1hArgs& b, uint32_t k, uint32_t n_k1h_waves, const void* fix_tables, const void* t4, unsigned cus, hipStream_t st)
+hipError_t launch_k1h_fixup(const K1hArgs& b, uint32_t k, uint32_t n_k1h_waves, const void* t4, unsigned cus, hipStream_t st)
 {
 	const size_t rows = (size_t)b.n_tiles * b.n_chunks;
 	hipLaunchKernelGGL(k1h_f1_kernel, dim3((unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8)), dim3(256), 0, st, b, k, n_k1h_waves);
 	hipLaunchKernelGGL(k1h_suspect_kernel, dim3(2u * n_k1h_waves), dim3(256), 0, st, b, t4, k, n_k1h_waves);
 	// the slow path takes LDS and a CU's worth of blocks; it returns at once unless the launch is flagged
-	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus), dim3(256), 0, st, b, static_cast<const FixTables*>(fix_tables), k);
+	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus), dim3(256), 0, st, b, t4, k);
 	return hipGetLastError();
 }
 

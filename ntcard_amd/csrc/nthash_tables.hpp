@@ -120,7 +120,7 @@ inline void build_t2(unsigned k, uint32_t* out /* t2_pairs(k)*16*4 dwords */, un
 // code2 order (code2 = (ascii >> 1) & 3: A=0 C=1 T/U=2 G=3; base t of the group in bits 2t+1:2t):
 // entry (g, v) = XOR over t < 4, i = 4 g + t < k of  srol^(k-1-i)(seed(c_t))  and  srol^i(comp(c_t))   (nthash.hpp:220-239)
 inline unsigned t4_groups(unsigned k) { return (k + 3) / 4; }
-inline void build_t4(unsigned k, uint32_t* out /* t4_groups(k)*256*4 dwords */)
+inline void build_t4(unsigned k, uint32_t* out /* t4_groups(k)*256*4 dwords */, unsigned gap_first = 0, unsigned gap = 0)
 {
 	static const unsigned code_of_code2[4] = { 0, 1, 3, 2 }; // code2 -> the A C G T numbering of seed_of()
 	for (unsigned g = 0; g < t4_groups(k); ++g)
@@ -129,6 +129,7 @@ inline void build_t4(unsigned k, uint32_t* out /* t4_groups(k)*256*4 dwords */)
 			for (unsigned t = 0; t < 4; ++t) {
 				const unsigned i = 4 * g + t;
 				if (i >= k) break;
+				if (i >= gap_first && i < gap_first + gap) continue; // spaced seed: a don't-care position (nthash.hpp:641-646)
 				const unsigned c = code_of_code2[(v >> (2 * t)) & 3u];
 				f ^= srol(seed_of(c), k - 1 - i);
 				r ^= srol(comp_of(c), i);

@@ -24,7 +24,7 @@ CODE2_OF = {ord("A"): 0, ord("C"): 1, ord("T"): 2, ord("G"): 3, ord("U"): 2, ord
 BASE_OF_CODE2 = "ACTG"
 
 
-def build_table(k, r_bits, s_bits):
+def build_table(k, r_bits, s_bits, gap=0):
     """[2][ng][64] uint32: 3 bases per entry (code2, base t of the group in bits 2t+1:2t); word = low r_bits bits of the strand's
     closed-form term (nthash.hpp:220-239) | its bit 62 << r_bits (s_bits == 7: tells sample 1 from sample 0)"""
     L = orc.lib()
@@ -37,6 +37,8 @@ def build_table(k, r_bits, s_bits):
                 i = 3 * g + t
                 if i >= k:
                     break
+                if gap and (k - gap) // 2 <= i < (k - gap) // 2 + gap:
+                    continue  # a don't-care position of the spaced seed
                 base = BASE_OF_CODE2[(val >> (2 * t)) & 3]
                 f ^= L.orc_srol(L.orc_seed(ord(base)), k - 1 - i)
                 r ^= L.orc_srol(L.orc_seed_comp(ord(base)), i)
@@ -62,7 +64,7 @@ class Layout:
         return a
 
 
-def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096):
+def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096, gap=0):
     """-> dict(keys=uint32[], f1=int, dirty=[n_tiles][C][64], tie=[n_tiles][NB][64], insts=executed per wave)"""
     Cn = (read_len + 15) // 16
     n_tiles = (n_reads + 2047) // 2048
@@ -98,9 +100,9 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     m32[(a_karg + K["nb_magic"]) // 4] = (1 << 32) // NB
     m32[(a_karg + K["sus_cap"]) // 4] = sus_cap
     lds = np.zeros(gen_k1h.LDS_BYTES, dtype=np.uint8)
-    tab = build_table(k, r_bits, s_bits)
+    tab = build_table(k, r_bits, s_bits, gap)
     lds.view(np.uint32)[gen_k1h.TABLE_OFF // 4: gen_k1h.TABLE_OFF // 4 + tab.size] = tab.reshape(-1)
-    prog = gen_k1h.Gen(k, 7 if s_bits == 7 else 8).build(emu=True)
+    prog = gen_k1h.Gen(k, 7 if s_bits == 7 else 8, gap).build(emu=True)
     insts = []
     for w in range(n_waves):
         e = Emu(prog, mem, lds)
@@ -134,7 +136,20 @@ def flags_of(fh, rh, s_bits):
     return (fa and rg) or fb, (ra and fg) or rb
 
 
-def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_overflow=False):
+def window_hashes(win, k, gap):
+    """-> (ok, fh, rh) of one window; spaced seed: the don't-care positions' terms XORed out (nthash.hpp:641-646)"""
+    L = orc.lib()
+    fh, rh, bad = C.c_uint64(), C.c_uint64(), C.c_uint()
+    if not L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad)):
+        return False, 0, 0
+    f, r = fh.value, rh.value
+    for i in range((k - gap) // 2, (k - gap) // 2 + gap):
+        f ^= L.orc_srol(L.orc_seed(win[i]), k - 1 - i)
+        r ^= L.orc_srol(L.orc_seed_comp(win[i]), i)
+    return True, f, r
+
+
+def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_overflow=False, gap=0):
     """-> (keys list, f1_sub) of the fix-up kernel.
     F1: every window with a non-ACGTU byte leaves it (they all lie in dirty-affected blocks).
     Hits: suspects (K1h resolved them, K1f checks their bytes) — or, when the suspect list overflowed, every window of every
@@ -160,24 +175,25 @@ def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_over
             tb = (int(tie[t, b, lane]) >> m) & 1
             for e in range(max(16 * b - 16 + phi, k - 1), min(16 * b + phi - 1, read_len - 1) + 1):
                 win = seq[e - k + 1: e + 1]
-                ok = L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad))
+                ok, fv, rv = window_hashes(win, k, gap)
                 if not ok:
                     assert aff
                     f1_sub += 1
                     continue
                 if not sus_overflow:
                     continue
-                cf, cr = flags_of(fh.value, rh.value, s_bits)
+                cf, cr = flags_of(fv, rv, s_bits)
                 if aff or (tb and cf and cr):  # slow path: every window of a dirty-affected block, and the both-flag windows of tie blocks
-                    kk = key_of(min(fh.value, rh.value))
+                    kk = key_of(min(fv, rv))
                     if kk is not None:
                         keys.append(kk)
     if sus is not None and not sus_overflow:
         for _, t, rw, _ in sus:  # (K1f re-derives the hash: the entry's key is K1h's, of the strand the candidate was queued under)
             r, w = int(t) * 2048 + (int(rw) & 2047), int(rw) >> 11
             win = reads[r][w: w + k]
-            if L.orc_window_hash(win, k, C.byref(fh), C.byref(rh), C.byref(bad)):
-                kk = key_of(min(fh.value, rh.value))
+            ok, fv, rv = window_hashes(win, k, gap)
+            if ok:
+                kk = key_of(min(fv, rv))
                 assert kk is not None or s_bits > 7, (r, w)  # (s_bits >= 8: the walk tests a prefix of the patterns, a suspect may turn out to be none)
                 if kk is not None:
                     keys.append(kk)

@@ -18,17 +18,17 @@ def tile_array(arr):
     return np.ascontiguousarray(a.reshape(ntl, 2048, C16, 16).transpose(0, 2, 1, 3)).reshape(-1)
 
 
-def run(n, L, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, s_bits=7, **kw):
+def run(n, L, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, s_bits=7, gap=0, **kw):
     rng = np.random.default_rng(seed)
     alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
     arr = alpha[rng.integers(0, 4, size=(n, L))]
     if p_bad:
         arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
-    res = km.run_k1h(tile_array(arr), n, L, k, r_bits=r_bits, n_waves=n_waves, s_bits=s_bits, **kw)
+    res = km.run_k1h(tile_array(arr), n, L, k, r_bits=r_bits, n_waves=n_waves, s_bits=s_bits, gap=gap, **kw)
     reads = [arr[i].tobytes() for i in range(n)]
-    fk, f1_sub = km.k1f_model(reads, L, k, r_bits, s_bits, res["dirty"], res["tie"], res["sus"], res["sus_overflow"])
+    fk, f1_sub = km.k1f_model(reads, L, k, r_bits, s_bits, res["dirty"], res["tie"], res["sus"], res["sus_overflow"], gap=gap)
     got = np.bincount(np.concatenate([res["keys"], np.array(fk, dtype=np.uint32)]).astype(np.int64), minlength=2 << r_bits).astype(np.uint32) + res["sketch"]
-    oc, of1 = orc.sketch_reads(reads, [k], 0, r_bits, s_bits)
+    oc, of1 = orc.sketch_reads(reads, [k], gap, r_bits, s_bits)
     assert res["f1"] - f1_sub == int(of1[0])
     assert np.array_equal(got, oc[0].reshape(-1).astype(np.uint32))
     return res
@@ -65,3 +65,10 @@ def test_k1h_emulated_suspect_overflow_and_dense_non_bases():
 def test_k1h_emulated_larger_s_bits(s_bits):
     """sBits >= 8 (>= 50 GB of input, ntcard.cpp:427-431): the walk tests 8-bit prefixes of ntComp's patterns, the resolve pass the rest"""
     run(6000, 150, 32, 0.002, s_bits=s_bits, r_bits=12)
+
+
+@pytest.mark.parametrize("k,gap,L,s_bits", [(12, 2, 150, 7), (12, 2, 40, 7), (32, 8, 100, 7), (20, 4, 64, 9), (13, 1, 30, 7)])
+def test_k1h_emulated_spaced_seeds(k, gap, L, s_bits):
+    """stRead / NTMSM64 with ntcard's one seed "1" x (k-g)/2 "0" x g "1" x rest (ntcard.cpp:160-171,407-413): two more terms per strand and
+    step in the walk, a resolve table without the don't-care positions, a start state without them"""
+    run(3000, L, k, 0.004, gap=gap, s_bits=s_bits, r_bits=12)

@@ -206,7 +206,7 @@ def test_tiled_layout_falls_back_for_other_configurations(nt):
                 e.submit_tiled_device(t.data_ptr(), len(reads), 150)
 
 
-@pytest.mark.parametrize("name,R", [("cfg2", 10_000_000), ("cfg2u", 10_000_000), ("cfg3s", 10_000_000), ("cfg2", 50_000_000)])
+@pytest.mark.parametrize("name,R", [("cfg2", 10_000_000), ("cfg2u", 10_000_000), ("cfg3s", 10_000_000), ("cfg2", 50_000_000), ("cfg5", 10_000_000)])
 def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     """100 M synthetic reads through the tiled kernel against the digests of the REAL reference (see test_fullsize_gpu.py); the
     50 M-read batches make every team of waves walk ~48 tiles in one launch (tile tags of deferred work wrap many times)"""
@@ -215,7 +215,9 @@ def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     cfg = meta["configs"][name]
     n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
     buf = torch.empty(nt.tiled_bytes(R, L), dtype=torch.uint8, device="cuda")
-    with nt.Engine(cfg["klist"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
+    if cfg["gap"] and VARIANT_FLAGS:
+        pytest.skip("K1c has no spaced-seed form")
+    with nt.Engine(cfg["klist"], gap=cfg["gap"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
         for first in range(0, n, R):
             m = min(R, n - first)
             nt.gen_reads_tiled_device(buf.data_ptr(), meta["seed"], first, m, L, cfg["dist"], genome_len=100_000_000)
@@ -275,3 +277,25 @@ def test_tiled_reference_table_slot_bytes_and_suspect_overflow(nt):
     offs = np.arange(dense.shape[0] + 1, dtype=np.uint64) * np.uint64(64)
     of1 = orc.sketch_update(counters, np.ascontiguousarray(dense).reshape(-1), offs, [32], 0, 20, 7)
     assert np.array_equal(f1, of1) and np.array_equal(tc, counters)
+
+
+@pytest.mark.parametrize("n,L,p_bad,s_bits", [(6000, 150, 0.003, 7), (2049, 12, 0.01, 7), (3000, 13, 0.0, 8), (70000, 100, 0.001, 11), (400_000, 64, 0.2, 7)])
+def test_tiled_spaced_seed_k12_gap2(nt, n, L, p_bad, s_bits):
+    """stRead with ntcard's -g seed (ntcard.cpp:160-171,407-413) through the tiled layout: K1h's (k = 12, gap = 2) variant, K1f with the
+    spaced closed form (the last case overflows the suspect list: slow path)"""
+    if VARIANT_FLAGS:
+        pytest.skip("K1c has no spaced-seed form")
+    rng = np.random.default_rng(n + L)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    if p_bad:
+        arr = np.where(rng.random((n, L)) < p_bad, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    t = torch.from_numpy(tile_array(arr)).cuda()
+    with nt.Engine([12], gap=2, r_bits=18, s_bits=s_bits, flags=nt.FLAG_REQUIRE_TILED) as e:
+        e.submit_tiled_device(t.data_ptr(), n, L)
+        tc, ph, f1 = e.finish(counters=True)
+    counters = np.zeros((1, 2, 1 << 18), dtype=np.uint16)
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    of1 = orc.sketch_update(counters, np.ascontiguousarray(arr).reshape(-1), offs, [12], 2, 18, s_bits)
+    assert np.array_equal(f1, of1), (f1, of1)
+    assert np.array_equal(tc, counters)
