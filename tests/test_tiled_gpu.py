@@ -195,7 +195,7 @@ def test_tiled_layout_falls_back_for_other_configurations(nt):
     """a configuration the tiled kernel is not built for is re-laid out on the device and takes the general kernel"""
     reads = gen_host(5000, 150, 1)
     t = torch.from_numpy(nt.tile_reads(reads, 150)).cuda()
-    for klist, gap, s_bits in (([40], 0, 7), ([11], 0, 7), ([32, 64], 0, 7), ([12], 2, 7), ([32], 0, 5)):
+    for klist, gap, s_bits in (([40], 0, 7), ([11], 0, 7), ([32, 64], 0, 7), ([20], 4, 7), ([32], 0, 5)):  # (k = 12 / gap = 2 has a tiled kernel since round 4)
         with nt.Engine(klist, gap=gap, r_bits=16, s_bits=s_bits) as e:
             e.submit_tiled_device(t.data_ptr(), len(reads), 150)
             tc, ph, f1 = e.finish(counters=True)

@@ -42,17 +42,17 @@ def main():
     n_steps = (bench["steps"] + bench["warmup"]) if bench else None
     if ks and n_steps:
         for r in csv.DictReader(open(ks[0])):
-            if "sketch_" in r["Name"]:
+            if "sketch_" in r["Name"] or "k1h_" in r["Name"]:
                 lines.append("   -> %s: %d dispatches over %d bench steps = %.4f ms per step" %
                              (r["Name"][:48], int(r["Calls"]), n_steps, float(r["TotalDurationNs"]) / n_steps / 1e6))
     hash_kernels = {}
     for k, v in agg.items():
-        if any(t in k for t in ("sketch_", "split_kernel", "count_kernel", "finalize")):
+        if any(t in k for t in ("sketch_", "k1h_", "split_kernel", "count_kernel", "finalize")):
             lines.append(f"== counters (separate --pmc passes), mean per dispatch | per bench step: {k}")
             for c, vals in sorted(v.items()):
                 per_step = ("%18.1f" % (sum(vals) / n_steps)) if n_steps else "-"
                 lines.append("  %-28s %18.1f  n=%d | %s" % (c, sum(vals) / len(vals), len(vals), per_step))
-            if "sketch_" in k:
+            if "sketch_" in k or "k1h_" in k:
                 hash_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
     open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
     # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) of the hash kernels per bench step (K1 / K1b + its redo pass)
