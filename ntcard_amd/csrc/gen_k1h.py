@@ -127,7 +127,7 @@ assert S_END <= 100, S_END
 S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCAP = the last time stamp): no F1, no suspects
 
 # the asm statement's "s" operands, in order
-INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase"]
+INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase", "first_block", "end_block"]
 # byte offsets in struct K1hArgs (ntc_kernels.hpp); the kernel reads them with scalar loads
 KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_tiles=56, n_chunks=60, read_len=64, nv_last=68, key_base=72,
             rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128, s_bits=96)
@@ -811,18 +811,17 @@ class Gen:
         p.i("s_cbranch_scc0", "@" + nolog0)
         self.load_log_region()
         p.label(nolog0)
-        # This wave's share: the blocks of all tiles form one sequence (tile * NB + block); wave w owns [w T, (w + 1) T), T = blocks_per_wave
+        # This wave's share: the blocks of all tiles form one sequence (tile * NB + block); the wave owns [first_block, end_block) of it (the
+        # kernel's prologue shares a workgroup's blocks out by where its waves sit: a wave alone on its SIMD gets through more than one of a pair)
         # — tiles are split wherever a boundary falls (19 tiles per CU over 6 waves are 4 rounds of whole tiles but 3.2 of blocks).
         # A wave that starts inside a tile first walks up to two blocks it does not own, masked: they fill the window (k - 1 <= 31 bases).
-        p.i("s_load_dword", s(S_A), sr(S_KARG, 2), hex(KARG["blocks_per_wave"]))
         p.i("s_load_dword", s(S_B), sr(S_KARG, 2), hex(KARG["nb_magic"]))
         p.i("s_mul_i32", s(S_CC), s(S_NTILES), s(S_NB))          # blocks of the batch
+        p.i("s_mov_b32", s(S_F0), inp["first_block"])
+        p.i("s_min_u32", s(S_FEND), inp["end_block"], s(S_CC))
         p.i("s_waitcnt", "lgkmcnt(0)")
-        p.i("s_mul_i32", s(S_F0), s(S_WT), s(S_A))
-        p.i("s_cmp_lt_u32", s(S_F0), s(S_CC))
+        p.i("s_cmp_lt_u32", s(S_F0), s(S_FEND))
         p.i("s_cbranch_scc0", "@done")                           # nothing to walk: F1 += 0, no suspects
-        p.i("s_add_u32", s(S_FEND), s(S_F0), s(S_A))
-        p.i("s_min_u32", s(S_FEND), s(S_FEND), s(S_CC))
         p.i("s_mul_hi_u32", s(S_PT), s(S_F0), s(S_B))            # tile = F0 / NB with nb_magic = floor(2^32 / NB): never too large,
         p.i("s_mul_i32", s(S_A), s(S_PT), s(S_NB))
         p.i("s_sub_u32", s(S_PN), s(S_F0), s(S_A))               # block = F0 - tile NB ...

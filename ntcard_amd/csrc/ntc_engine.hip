@@ -262,18 +262,18 @@ struct ntc_engine {
 	std::vector<void*> d_t4s;       // K1c: one table per k of the list (d_t4s[0] == d_t4)
 	std::vector<uint32_t*> d_k1h_tabs; // K1h: closed-form table per k of the list (nullptr: K1c takes that k)
 	bool k1h_wanted = true;         // !NTC_FLAG_TILED_TEAMS
-	// What K1h hands to K1f (two bit arrays, the suspect list, a little state): two sets, so that — for a caller that promised to leave its
-	// batches alone until ntc_sync (NTC_FLAG_DEFER_REDO) — K1f of one batch runs on a side stream beside K1h of the next one (K1f waits on
-	// memory, K1h on instruction issue; K1h's six waves leave half of two SIMDs' registers free).
+	// What K1h hands to K1f (two bit arrays, the suspect list, a little state): one set per K1h launch whose K1f is still to come.  K1f's kernels
+	// wait on memory (a few dependent loads per dirty piece / suspect, ~45 us per kernel whatever the batch), so for a caller that promised to leave
+	// its batches alone until ntc_sync (NTC_FLAG_DEFER_REDO) the engine collects up to kK1fBatch K1h launches and sends ONE K1f over all of them;
+	// without the promise K1f follows its K1h launch at once (set 0).
 	struct K1hSet {
 		uint32_t *d_dirty = nullptr, *d_tie = nullptr;
 		size_t dirty_cap = 0, tie_cap = 0;
 		uint4* d_sus = nullptr;            // kK1hSusCap entries per wave of a launch
 		uint32_t *d_sus_count = nullptr, *d_fix_state = nullptr;
-		hipEvent_t k1h_done = nullptr, k1f_done = nullptr;
-		bool k1f_pending = false;
-	} k1h_set[2];
-	int k1h_cur = 0;
+	} k1h_set[ntc::kK1fBatch];
+	ntc::K1fBatch k1f_batch;        // the launches waiting for K1f (k1f_batch.item[i] uses k1h_set[i])
+	uint32_t k1f_n = 0;
 	// ntc_merge_devices: exchange buffers, copy streams and events, kept between merges (grow-only)
 	struct MergeCache {
 		uint16_t *narrow = nullptr, *recv = nullptr;
@@ -283,9 +283,8 @@ struct ntc_engine {
 		hipEvent_t narrowed = nullptr, summed = nullptr;
 	} mc;
 	uint64_t merge_allocs = 0; // device allocations + streams + events ntc_merge_devices has created for this engine
-	hipStream_t k1f_stream = nullptr;
 	uint32_t k1h_launch_id = 0;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: K1f on the side stream
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: deferred K1f launches (outside the hash kernels' events)
 	double k1f_ms = 0.0;
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
 	bool bs_ok = false;             // K1b (bit-sliced kernel over row slots) is
@@ -447,15 +446,26 @@ int flush_redo(ntc_engine* e)
 	return 0;
 }
 
-// K1f launches still under way on the side stream: the engine's stream waits for them (no host wait).  Before anything reads the counters or
-// F1, or touches the sketch without atomics (the apply's sweep does).
+// K1f over the K1h launches that still wait for it (asynchronous on the engine's stream).  Before anything reads the counters or F1, touches the
+// sketch without atomics (the apply's sweep does), or hands the batches back to the caller.
 int join_k1f(ntc_engine* e)
 {
-	for (auto& ks : e->k1h_set)
-		if (ks.k1f_pending) {
-			HIP_TRY(hipStreamWaitEvent(e->stream, ks.k1f_done, 0));
-			ks.k1f_pending = false;
-		}
+	if (e->k1f_n == 0) return 0;
+	DevInfo di;
+	if (int rc = device_info(e->device, di)) return rc;
+	hipEvent_t f0 = nullptr, f1 = nullptr;
+	if (e->profiling) {
+		HIP_TRY(hipEventCreate(&f0));
+		HIP_TRY(hipEventCreate(&f1));
+		HIP_TRY(hipEventRecord(f0, e->stream));
+	}
+	const uint32_t n = e->k1f_n;
+	e->k1f_n = 0;
+	HIP_TRY(ntc::launch_k1h_fixup(e->k1f_batch, n, (unsigned)di.cus, e->stream));
+	if (e->profiling) {
+		HIP_TRY(hipEventRecord(f1, e->stream));
+		e->k1f_events.emplace_back(f0, f1);
+	}
 	return 0;
 }
 
@@ -852,6 +862,8 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 		e->log_est += est;
 		e->log_pending = true;
 	}
+	if (e->k1f_n + e->klist.size() > ntc::kK1fBatch) // no set left for this batch's K1h launches: K1f over the waiting ones first
+		if (int rc = join_k1f(e)) return rc;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (e->profiling) {
 		HIP_TRY(hipEventCreate(&ev0));
@@ -869,13 +881,9 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 			if (need_d < (1ull << 32) && need_t < (1ull << 32)) {
 				constexpr uint32_t kK1hSusCap = 2048; // suspects per K1h wave (a 10 M-read batch with 0.05 % N leaves ~400); a wave that needs more sends the launch down K1f's slow path
 				const uint32_t max_waves = (uint32_t)di.cus * 6u;
-				const bool side = e->defer_redo; // K1f beside the next K1h only when the caller keeps its batches unchanged until ntc_sync
-				auto& ks = e->k1h_set[side ? e->k1h_cur : 0];
-				if (side) e->k1h_cur ^= 1;
-				if (ks.k1f_pending) { // the K1f launch that last used this set
-					HIP_TRY(hipStreamWaitEvent(e->stream, ks.k1f_done, 0));
-					ks.k1f_pending = false;
-				}
+				if (e->k1f_n == ntc::kK1fBatch) // (a k list longer than the sets)
+					if (int rc = join_k1f(e)) return rc;
+				auto& ks = e->k1h_set[e->k1f_n];
 				if (need_d > ks.dirty_cap || need_t > ks.tie_cap) {
 					HIP_TRY(hipStreamSynchronize(e->stream));
 					if (ks.d_dirty) (void)hipFree(ks.d_dirty);
@@ -893,10 +901,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 						return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
 					HIP_TRY(hipMemsetAsync(ks.d_fix_state, 0, 16, e->stream));
 					HIP_TRY(hipMemsetAsync(ks.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
-					HIP_TRY(hipEventCreateWithFlags(&ks.k1h_done, hipEventDisableTiming));
-					HIP_TRY(hipEventCreateWithFlags(&ks.k1f_done, hipEventDisableTiming));
 				}
-				if (side && !e->k1f_stream) HIP_TRY(hipStreamCreateWithFlags(&e->k1f_stream, hipStreamNonBlocking));
 				ntc::K1hArgs h;
 				std::memset(&h, 0, sizeof h);
 				h.sus = ks.d_sus;
@@ -926,25 +931,13 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				ntc::K1hArgs launched;
 				uint32_t n_waves = 0;
 				HIP_TRY(ntc::launch_sketch_k1h(h, k, e->gap, (unsigned)di.cus, e->stream, &launched, &n_waves));
-				if (side) {
-					HIP_TRY(hipEventRecord(ks.k1h_done, e->stream));
-					HIP_TRY(hipStreamWaitEvent(e->k1f_stream, ks.k1h_done, 0));
-					hipEvent_t f0 = nullptr, f1 = nullptr;
-					if (e->profiling) {
-						HIP_TRY(hipEventCreate(&f0));
-						HIP_TRY(hipEventCreate(&f1));
-						HIP_TRY(hipEventRecord(f0, e->k1f_stream));
-					}
-					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_t4s[ki], (unsigned)di.cus, e->k1f_stream));
-					if (e->profiling) {
-						HIP_TRY(hipEventRecord(f1, e->k1f_stream));
-						e->k1f_events.emplace_back(f0, f1);
-					}
-					HIP_TRY(hipEventRecord(ks.k1f_done, e->k1f_stream));
-					ks.k1f_pending = true;
-				} else {
-					HIP_TRY(ntc::launch_k1h_fixup(launched, k, n_waves, e->d_t4s[ki], (unsigned)di.cus, e->stream));
-				}
+				auto& it = e->k1f_batch.item[e->k1f_n++];
+				it.a = launched;
+				it.t4 = e->d_t4s[ki];
+				it.k = k;
+				it.n_waves = n_waves;
+				if (!e->defer_redo) // the caller may change the batch once the stream has passed this call: K1f now
+					if (int rc = join_k1f(e)) return rc;
 				continue;
 			}
 		}
@@ -1192,18 +1185,13 @@ void ntc_destroy(ntc_engine* e)
 	if (e->mc.summed) (void)hipEventDestroy(e->mc.summed);
 	if (e->mc.narrow) (void)hipFree(e->mc.narrow);
 	if (e->mc.recv) (void)hipFree(e->mc.recv);
-	if (e->k1f_stream) (void)hipStreamSynchronize(e->k1f_stream);
-	for (auto& ks : e->k1h_set) {
+	for (auto& ks : e->k1h_set)
 		for (void* d : {(void*)ks.d_dirty, (void*)ks.d_tie, (void*)ks.d_sus, (void*)ks.d_sus_count, (void*)ks.d_fix_state})
 			if (d) (void)hipFree(d);
-		if (ks.k1h_done) (void)hipEventDestroy(ks.k1h_done);
-		if (ks.k1f_done) (void)hipEventDestroy(ks.k1f_done);
-	}
 	for (auto& pr : e->k1f_events) {
 		(void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
-	if (e->k1f_stream) (void)hipStreamDestroy(e->k1f_stream);
 	for (void* d : e->d_t1) (void)hipFree(d);
 	if (e->d_gapt) (void)hipFree(e->d_gapt);
 	if (e->d_hll_thr) (void)hipFree(e->d_hll_thr);

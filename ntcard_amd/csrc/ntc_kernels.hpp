@@ -144,13 +144,25 @@ struct K1hArgs {
 	uint32_t* sus_count;          // [waves]: entries written (0xffffffff: the wave ran out of room — K1f then walks every dirty-affected block itself)
 	uint32_t sus_cap, launch_id;
 	uint32_t* fix_state;          // K1f scratch: [0] = launch_id of the last launch that must take the slow path, [2..3] = F1 correction (uint64)
+	uint32_t lone_weight;         // blocks a wave alone on its SIMD takes for every 16 of a wave that shares one (0: launch_sketch_k1h's default)
 };
 bool sketch_k1h_supports(uint32_t k, uint32_t gap, uint32_t s_bits, uint32_t r_bits);
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len);
 void build_k1h_table(uint32_t k, uint32_t gap, uint32_t r_bits, uint32_t s_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
 hipError_t set_sketch_k1h_smem_limit();
 hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves);
-hipError_t launch_k1h_fixup(const K1hArgs& launched, uint32_t k, uint32_t n_k1h_waves, const void* t4 /* build_t4, with the engine's gap */, unsigned cus, hipStream_t st);
+// K1f takes up to kK1fBatch K1h launches at a time (blockIdx.y = the launch): its kernels wait on memory, not on issue slots, so the launches of
+// several batches cost little more than those of one (an engine whose caller keeps the batches unchanged until ntc_sync defers them)
+constexpr uint32_t kK1fBatch = 8;
+struct K1fItem {
+	K1hArgs a;                    // as launched (launch_sketch_k1h's args_out)
+	const void* t4;               // build_t4 of this k, with the engine's gap
+	uint32_t k, n_waves;          // n_waves: K1h waves of the launch = suspect regions
+};
+struct K1fBatch {
+	K1fItem item[kK1fBatch];
+};
+hipError_t launch_k1h_fixup(const K1fBatch& b, uint32_t n_items, unsigned cus, hipStream_t st);
 // tiled layout -> row-major slots: device-side re-layout for the configurations the tiled kernels are not built for
 hipError_t launch_gen_tiled(unsigned char* out, uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint32_t dist, uint64_t glen, hipStream_t st);
 hipError_t launch_untile(const unsigned char* tiles, unsigned char* slots, uint64_t n_reads, uint32_t read_len, uint32_t stride, hipStream_t st);

@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "ntc_kernels.hpp"
 #include "ntc_tile_bits.hpp"
@@ -41,7 +42,8 @@ static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && of
 constexpr uint32_t kK1hWaves = 6;
 constexpr uint32_t kK1hWArea = 25600;
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
-constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + 2u * ((k + 2u) / 3u) * 256u; } // exactly what the waves use: what is left of a CU's LDS lets k1h_f1_kernel's blocks in beside them
+constexpr uint32_t k1h_table_bytes(uint32_t k) { return 2u * ((k + 2u) / 3u) * 256u; }
+constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k) + 32u; } // the wave areas, the table, the waves' SIMD numbers
 
 #define K1H_CLOBBERS_V                                                                                                                 \
 	"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20",   \
@@ -73,8 +75,32 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 		for (uint32_t i = threadIdx.x; i < n; i += 384u)
 			dst[i] = a.table[i];
 	}
-	__syncthreads();
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	// Six waves on four SIMDs: two SIMDs hold a pair, two a single wave.  A lone wave issues an instruction every ~4.4 clocks whatever it is; the
+	// waves of a pair take turns for everything that is not a plain bit operation (v_perm, shifts-and-or, compares, multiplies occupy the SIMD for 4 clocks:
+	// profiles/r04_ubench_issue.txt), so a pair's waves are slower by a quarter.  Every wave therefore tells the others which SIMD it runs on
+	// (HW_ID bits 5:4) and the workgroup's blocks are shared out by weight: lone_weight sixteenths to a lone wave for 16 to one of a pair.
+	volatile uint32_t* const simd_of = reinterpret_cast<volatile uint32_t*>(smem + kK1hTableOff + k1h_table_bytes(K));
+	if ((threadIdx.x & 63u) == 0u) simd_of[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // hwreg(HW_REG_HW_ID, 4, 2)
+	__syncthreads();
+	uint32_t first_block, end_block;
+	{
+		uint32_t wsum = 0, wbefore = 0, wmine = 0;
+		for (uint32_t i = 0; i < kK1hWaves; ++i) {
+			uint32_t same = 0;
+			for (uint32_t j = 0; j < kK1hWaves; ++j)
+				same += simd_of[j] == simd_of[i];
+			const uint32_t wt = same >= 2u ? 16u : a.lone_weight;
+			if (i < wave) wbefore += wt;
+			if (i == wave) wmine = wt;
+			wsum += wt;
+		}
+		const uint32_t quota = a.blocks_per_wave * kK1hWaves, wg0 = blockIdx.x * quota; // (n_tiles * blocks < 2^32 / 64: the products below fit 64 bits easily)
+		first_block = wg0 + (uint32_t)((uint64_t)quota * wbefore / wsum);
+		end_block = wg0 + (uint32_t)((uint64_t)quota * (wbefore + wmine) / wsum);
+		first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_block);
+		end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)end_block);
+	}
 	const uint32_t wave_gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kK1hWaves + wave));
 	const uint32_t n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * kK1hWaves));
 	const uint32_t lds_wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kK1hWArea));
@@ -82,7 +108,8 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 	const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)karg);
 	const uint32_t karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(karg >> 32));
 	// gen_k1h.py (VARIANTS) emits one body per (k, gap) and s_bits class (7, >= 8)
-#define K1H_BODY(text) asm volatile(text ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase) : K1H_CLOBBERS_V, K1H_CLOBBERS_S)
+#define K1H_BODY(text)                                                                                                                       \
+	asm volatile(text ::"s"(karg_lo), "s"(karg_hi), "s"(wave_gid), "s"(n_waves), "s"(lds_wbase), "s"(first_block), "s"(end_block) : K1H_CLOBBERS_V, K1H_CLOBBERS_S)
 	if constexpr (K == 32 && GAP == 0 && SB == 7) K1H_BODY(K1H_ASM_K32_G0_S7);
 	else if constexpr (K == 32 && GAP == 0 && SB == 8) K1H_BODY(K1H_ASM_K32_G0_S8);
 	else if constexpr (K == 12 && GAP == 2 && SB == 7) K1H_BODY(K1H_ASM_K12_G2_S7);
@@ -140,8 +167,11 @@ __device__ __forceinline__ bool has_slot_byte(const tilebits::v4u32 v)
 
 // F1 correction: a wave compacts the dirty pieces of its rows into an LDS queue and takes 64 at a time, one per lane (a scattered 16-byte
 // load each, all in flight together)
-__global__ __launch_bounds__(256) void k1h_f1_kernel(const K1hArgs a, uint32_t k, uint32_t n_sus_waves)
+__global__ __launch_bounds__(256) void k1h_f1_kernel(const K1fBatch batch)
 {
+	const K1fItem& item = batch.item[blockIdx.y];
+	const K1hArgs& a = item.a;
+	const uint32_t k = item.k, n_sus_waves = item.n_waves;
 	__shared__ uint2 s_q[4][128];
 	__shared__ uint32_t s_sum[4], s_slow[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -225,8 +255,12 @@ __global__ __launch_bounds__(256) void k1h_f1_kernel(const K1hArgs a, uint32_t k
 
 // fast path, after k1h_f1_kernel: the suspects, and the F1 correction it summed up.  No LDS, few registers: it runs beside the next
 // batch's K1h waves (the engine launches K1f on a side stream).
-__global__ __launch_bounds__(256) void k1h_suspect_kernel(const K1hArgs a, const void* __restrict__ t4, uint32_t k, uint32_t n_sus_waves)
+__global__ __launch_bounds__(256) void k1h_suspect_kernel(const K1fBatch batch)
 {
+	const K1fItem& item = batch.item[blockIdx.y];
+	const K1hArgs& a = item.a;
+	const void* const t4 = item.t4;
+	const uint32_t k = item.k, n_sus_waves = item.n_waves;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
 	const uint32_t rmask = (1u << r_bits) - 1u;
@@ -301,8 +335,12 @@ __device__ __forceinline__ uint32_t base_class(uint32_t c)
 	return f | (((code(c & 7u) ^ 2u) & 3u) << 4);
 }
 
-__global__ __launch_bounds__(256) void k1h_slow_kernel(const K1hArgs a, const void* __restrict__ t4, uint32_t k)
+__global__ __launch_bounds__(256) void k1h_slow_kernel(const K1fBatch batch)
 {
+	const K1fItem& item = batch.item[blockIdx.y];
+	const K1hArgs& a = item.a;
+	const void* const t4 = item.t4;
+	const uint32_t k = item.k;
 	__shared__ uint2 s_queue[4][kFixQCap];
 	__shared__ __align__(16) unsigned char s_stage[4][64 * kFixStage];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -506,6 +544,17 @@ hipError_t set_sketch_k1h_smem_limit()
 	return for_each_k1h_kernel([](const void* fn, uint32_t k) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k1h_lds_bytes(k)); });
 }
 
+// sixteenths of a paired wave's share that a wave alone on its SIMD takes (NTC_K1H_LONE_WEIGHT: tuning runs)
+static uint32_t k1h_lone_weight()
+{
+	static const uint32_t w = [] {
+		const char* s = std::getenv("NTC_K1H_LONE_WEIGHT");
+		const long v = s ? std::strtol(s, nullptr, 10) : 0;
+		return (uint32_t)(v >= 8 && v <= 64 ? v : 20);
+	}();
+	return w;
+}
+
 // K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
 hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
 {
@@ -516,6 +565,7 @@ hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigne
 	K1hArgs b = a;
 	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
 	b.nb_magic = (uint32_t)((1ull << 32) / nb);
+	if (b.lone_weight == 0) b.lone_weight = k1h_lone_weight();
 	const uint32_t lds = k1h_lds_bytes(k);
 	if (k == 32 && a.s_bits == 7) hipLaunchKernelGGL((sketch_k1h_kernel<32, 7, 0>), dim3(grid), dim3(384), lds, st, b);
 	else if (k == 32) hipLaunchKernelGGL((sketch_k1h_kernel<32, 8, 0>), dim3(grid), dim3(384), lds, st, b);
@@ -526,14 +576,20 @@ hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigne
 	return hipGetLastError();
 }
 
-// K1f for a batch K1h has been launched over (same arguments), on any stream ordered behind that launch
-hipError_t launch_k1h_fixup(const K1hArgs& b, uint32_t k, uint32_t n_k1h_waves, const void* t4, unsigned cus, hipStream_t st)
+// K1f for the batches K1h has been launched over (arguments as launched), on any stream ordered behind those launches
+hipError_t launch_k1h_fixup(const K1fBatch& b, uint32_t n_items, unsigned cus, hipStream_t st)
 {
-	const size_t rows = (size_t)b.n_tiles * b.n_chunks;
-	hipLaunchKernelGGL(k1h_f1_kernel, dim3((unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8)), dim3(256), 0, st, b, k, n_k1h_waves);
-	hipLaunchKernelGGL(k1h_suspect_kernel, dim3(2u * n_k1h_waves), dim3(256), 0, st, b, t4, k, n_k1h_waves);
+	if (n_items == 0 || n_items > kK1fBatch) return hipErrorInvalidValue;
+	size_t rows = 0;
+	uint32_t waves = 0;
+	for (uint32_t i = 0; i < n_items; ++i) { // (a block of a launch with fewer rows / regions finds its loops empty)
+		rows = std::max(rows, (size_t)b.item[i].a.n_tiles * b.item[i].a.n_chunks);
+		waves = std::max(waves, b.item[i].n_waves);
+	}
+	hipLaunchKernelGGL(k1h_f1_kernel, dim3((unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8), n_items), dim3(256), 0, st, b);
+	hipLaunchKernelGGL(k1h_suspect_kernel, dim3(2u * waves, n_items), dim3(256), 0, st, b);
 	// the slow path takes LDS and a CU's worth of blocks; it returns at once unless the launch is flagged
-	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus), dim3(256), 0, st, b, t4, k);
+	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus, n_items), dim3(256), 0, st, b);
 	return hipGetLastError();
 }
 

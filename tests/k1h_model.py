@@ -96,7 +96,8 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
                       ("s_bits", s_bits)):
         m32[(a_karg + K[name]) // 4] = val
     total = n_tiles * NB
-    m32[(a_karg + K["blocks_per_wave"]) // 4] = (total + n_waves - 1) // n_waves
+    bpw = (total + n_waves - 1) // n_waves
+    m32[(a_karg + K["blocks_per_wave"]) // 4] = bpw
     m32[(a_karg + K["nb_magic"]) // 4] = (1 << 32) // NB
     m32[(a_karg + K["sus_cap"]) // 4] = sus_cap
     lds = np.zeros(gen_k1h.LDS_BYTES, dtype=np.uint8)
@@ -110,6 +111,9 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
         e.V[:] = rng.integers(0, 1 << 32, size=e.V.shape, dtype=np.uint64).astype(np.uint32)  # registers start as garbage
         e.S[0], e.S[1] = a_karg & 0xFFFFFFFF, a_karg >> 32
         e.S[2], e.S[3], e.S[4] = w, n_waves, (w % gen_k1h.WAVES) * gen_k1h.WAREA
+        # the blocks the wave owns: the kernel's prologue weighs a workgroup's waves by SIMD sharing — here every other wave gets 3 parts to its neighbour's 2
+        wts = [2 + (i & 1) for i in range(n_waves)]
+        e.S[5], e.S[6] = total * sum(wts[:w]) // sum(wts), total * sum(wts[:w + 1]) // sum(wts)
         e.run()
         insts.append(e.executed)
     fill = m32[a_fill // 4: a_fill // 4 + log_regions]
