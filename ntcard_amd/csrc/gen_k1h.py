@@ -40,9 +40,9 @@ from k1h_asm import Prog, v, s, vr, sr, schedule
 
 WAVES = 6                    # waves per workgroup = tiles in flight per CU
 RING_BYTES = 3 * 8192        # three packed chunks
-QCAP = 128                   # queue items (8 bytes)
-WAREA = RING_BYTES + QCAP * 8  # 25600 = 25 KiB per wave, 1 KiB aligned
-TABLE_OFF = WAVES * WAREA    # 153600: [2 strands][NG][64] dwords
+QCAP = 128                   # queue items: three dwords each, kept as three arrays of QCAP dwords (hit word, meta, reverse-strand mask)
+WAREA = RING_BYTES + QCAP * 12  # 26112 bytes per wave
+TABLE_OFF = WAVES * WAREA    # 156672: [2 strands][NG][64] dwords
 LDS_BYTES = 160 * 1024
 
 
@@ -73,10 +73,10 @@ V_SXR = V_T + 6
 V_T0 = V_T + 4     # scratch of the walk / test / pack: V_T0 .. V_T0 + 29 (the suspect pairs are written behind the test, whose scratch they share)
 V_TP = V_T + 8     # scratch of the resolve pass: V_TP .. V_TP + 25; the transpose uses V_T .. V_T + 31
 # constants that VOP3 instructions cannot take as literals (gfx9: one SGPR or inline constant per instruction, no 32-bit literal)
-V_CMUL, V_CPERMLO, V_CPERMHI, V_CP16A, V_CP16B, V_CP8A, V_CP8B, V_CM4, V_CM2, V_CM1, V_CQMASK8 = [V_T0 + 30 + i for i in range(11)]
-assert V_CQMASK8 <= 254
+V_CMUL, V_CPERMLO, V_CPERMHI, V_CP16A, V_CP16B, V_CP8A, V_CP8B, V_CM4, V_CM2, V_CM1, V_CQMASK4 = [V_T0 + 30 + i for i in range(11)]
+assert V_CQMASK4 <= 254
 VCONST = ((V_CMUL, 0x00820820), (V_CPERMLO, 0x0c0c0703), (V_CPERMHI, 0x07030c0c), (V_CP16A, 0x05040100), (V_CP16B, 0x07060302),
-          (V_CP8A, 0x06020400), (V_CP8B, 0x07030501), (V_CM4, 0x0f0f0f0f), (V_CM2, 0x33333333), (V_CM1, 0x55555555), (V_CQMASK8, (QCAP - 1) * 8))
+          (V_CP8A, 0x06020400), (V_CP8B, 0x07030501), (V_CM4, 0x0f0f0f0f), (V_CM2, 0x33333333), (V_CM1, 0x55555555), (V_CQMASK4, (QCAP - 1) * 4))
 N_VGPRS = 255
 
 # SGPRs: s0 .. S_BASE - 1 are left to the compiler (the asm statement's few inputs live there)
@@ -118,7 +118,7 @@ S_QT, S_QN, S_QREAL = _salloc(), _salloc(), _salloc()  # chunk being loaded next
 S_PSOFF, S_QSOFF = _salloc(), _salloc()
 S_STEPMASK = _salloc()
 S_B0, S_B1, S_B2 = _salloc(), _salloc(), _salloc()
-S_QHEAD8, S_QTAIL8 = _salloc(), _salloc()
+S_QHEAD4, S_QTAIL4 = _salloc(), _salloc()
 S_N, S_A, S_B, S_CC = _salloc(), _salloc(), _salloc(), _salloc()  # scalar scratch
 S_SPARE = _salloc()
 S_END = _sn[0]
@@ -374,38 +374,34 @@ class Gen:
             p.label(nosus)
 
     def push_items(self, a, xf, xr, suspect):
-        """queue the two hit words (register pairs xf, xr: word + meta) of step a; resolve passes first while the queue lacks room"""
+        """queue the hit words of step a (xf: forward-strand candidates, xr: reverse; a read is never in both — ties are masked out or ride in
+        xf alone): ONE item per lane = (xf | xr, meta, xr); resolve passes first while the queue lacks room"""
         p = self.p
         T = V_TP
         chk, go = self.lbl("chk"), self.lbl("go")
         p.label(chk)
-        p.i("v_cmp_ne_u32_e64", sr(S_TMP, 2), 0, v(xf))
-        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(xr))
-        p.i("s_bcnt1_i32_b64", s(S_A), sr(S_TMP, 2))
-        p.i("s_bcnt1_i32_b64", s(S_B), "vcc")
-        p.i("s_sub_u32", s(S_N), s(S_QTAIL8), s(S_QHEAD8))
-        p.i("s_lshr_b32", s(S_N), s(S_N), 3)
+        p.i("v_or_b32", v(T + 2), v(xf), v(xr))
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(T + 2))
+        p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
+        p.i("s_sub_u32", s(S_N), s(S_QTAIL4), s(S_QHEAD4))
+        p.i("s_lshr_b32", s(S_N), s(S_N), 2)
         p.i("s_add_u32", s(S_N), s(S_N), s(S_A))
-        p.i("s_add_u32", s(S_N), s(S_N), s(S_B))
         p.i("s_cmp_le_u32", s(S_N), QCAP)
         p.i("s_cbranch_scc1", "@" + go)
-        self.call("pass")                                        # (keeps V_T .. V_T + 7: the four item pairs)
+        self.call("pass")                                        # (keeps V_T .. V_T + 7: the four hit words)
         p.i("s_branch", "@" + chk)
         p.label(go)
-        meta_f = (0 << 8) | ((2 * a) << 9) | (suspect << 15)
-        meta_r = (1 << 8) | ((2 * a) << 9) | (suspect << 15)
-        for strand, px, meta, msk, cnt in (("F", xf, meta_f, sr(S_TMP, 2), S_A), ("R", xr, meta_r, "vcc", S_B)):
-            lo = f"s{S_TMP}" if strand == "F" else "vcc_lo"
-            hi = f"s{S_TMP + 1}" if strand == "F" else "vcc_hi"
-            p.i("v_mbcnt_lo_u32_b32", v(T + 1), lo, 0)
-            p.i("v_mbcnt_hi_u32_b32", v(T + 1), hi, v(T + 1))
-            p.i("v_lshl_add_u32", v(T + 1), v(T + 1), 3, s(S_QTAIL8))
-            p.i("v_and_or_b32", v(T + 1), v(T + 1), v(V_CQMASK8), v(V_QBASE))
-            p.i("v_or_b32", v(px + 1), hex(meta), v(V_LANE4))
-            p.i("s_mov_b64", "exec", msk)
-            p.i("ds_write_b64", v(T + 1), vr(px, 2))
-            p.i("s_mov_b64", "exec", -1)
-            p.i("s_lshl3_add_u32", s(S_QTAIL8), s(cnt), s(S_QTAIL8))
+        meta = ((2 * a) << 9) | (suspect << 15)
+        p.i("v_mbcnt_lo_u32_b32", v(T + 1), "vcc_lo", 0)
+        p.i("v_mbcnt_hi_u32_b32", v(T + 1), "vcc_hi", v(T + 1))
+        p.i("v_lshl_add_u32", v(T + 1), v(T + 1), 2, s(S_QTAIL4))
+        p.i("v_and_or_b32", v(T + 1), v(T + 1), v(V_CQMASK4), v(V_QBASE))
+        p.i("v_or_b32", v(T + 3), hex(meta), v(V_LANE4))
+        p.i("s_mov_b64", "exec", "vcc")
+        p.i("ds_write2_b32", v(T + 1), v(T + 2), v(T + 3), mods=f"offset0:0 offset1:{QCAP}")
+        p.i("ds_write_b32", v(T + 1), v(xr), mods=f"offset:{QCAP * 8}")
+        p.i("s_mov_b64", "exec", -1)
+        p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
 
     # ---- pack one group of 64 pieces: RAW slot i -> packed word in register dst; then reload the slot ----
     def pack_group(self, i, dst, reload):
@@ -481,23 +477,30 @@ class Gen:
         p.label(skip)
         self.probe(1)
 
-    # ---- 32 x 32 bit transpose of H0 in place (temps: 32 registers from V_T) ----
-    def transpose(self):
+    # ---- 32 x 32 bit transpose of the packed words in H0 into I, and the rotation of the plane sets on the way (temps: 32 registers from V_T) ----
+    def transpose_rotate(self):
+        """(H0, H1, I) <- (H1, I, transpose(H0)): the first stage reads H0 into the temps, which frees H0 for H1's planes and H1 for I's; the
+        second stage lands in I and the last three run there in place (64 moves instead of the 64 two-slot swaps of a separate rotation)"""
         p = self.p
         A = [V_H0 + i for i in range(32)]
         B = [V_T + i for i in range(32)]
+        O = [V_I + i for i in range(32)]
         for kk in range(32):  # J = 16: A -> B
             if kk & 16 == 0:
                 p.i("v_perm_b32", v(B[kk]), v(A[kk + 16]), v(A[kk]), v(V_CP16A))
                 p.i("v_perm_b32", v(B[kk + 16]), v(A[kk + 16]), v(A[kk]), v(V_CP16B))
-        for kk in range(32):  # J = 8: B -> A
+        for i in range(32):
+            p.i("v_mov_b32", v(V_H0 + i), v(V_H1 + i))
+        for i in range(32):
+            p.i("v_mov_b32", v(V_H1 + i), v(V_I + i))
+        for kk in range(32):  # J = 8: B -> O
             if kk & 8 == 0:
-                p.i("v_perm_b32", v(A[kk]), v(B[kk + 8]), v(B[kk]), v(V_CP8A))
-                p.i("v_perm_b32", v(A[kk + 8]), v(B[kk + 8]), v(B[kk]), v(V_CP8B))
-        for J, msk in ((4, V_CM4), (2, V_CM2), (1, V_CM1)):  # in place: A[k] = bfi(m, x, y << J), A[k+J] = bfi(m, x >> J, y)
+                p.i("v_perm_b32", v(O[kk]), v(B[kk + 8]), v(B[kk]), v(V_CP8A))
+                p.i("v_perm_b32", v(O[kk + 8]), v(B[kk + 8]), v(B[kk]), v(V_CP8B))
+        for J, msk in ((4, V_CM4), (2, V_CM2), (1, V_CM1)):  # in place: O[k] = bfi(m, x, y << J), O[k+J] = bfi(m, x >> J, y)
             for kk in range(32):
                 if kk & J == 0:
-                    x, y = A[kk], A[kk + J]
+                    x, y = O[kk], O[kk + J]
                     p.i("v_lshlrev_b32", v(B[0]), J, v(y))
                     p.i("v_lshrrev_b32", v(B[1]), J, v(x))
                     p.i("v_bfi_b32", v(x), v(msk), v(x), v(B[0]))
@@ -514,24 +517,42 @@ class Gen:
         p.label("pass")
         self.probe(0)
         if "nopass" in self.exp:
-            p.i("s_mov_b32", s(S_QHEAD8), s(S_QTAIL8))
+            p.i("s_mov_b32", s(S_QHEAD4), s(S_QTAIL4))
             self.ret()
         # active lanes: items head .. head + n - 1, n = min(64, count)
-        p.i("s_sub_u32", s(S_N), s(S_QTAIL8), s(S_QHEAD8))
-        p.i("s_lshr_b32", s(S_N), s(S_N), 3)
+        p.i("s_sub_u32", s(S_N), s(S_QTAIL4), s(S_QHEAD4))
+        p.i("s_lshr_b32", s(S_N), s(S_N), 2)
         p.i("s_min_u32", s(S_N), s(S_N), 64)
         p.i("s_bfm_b64", "exec", s(S_N), 0)
         p.i("s_cmp_eq_u32", s(S_N), 64)
         p.i("s_cselect_b64", "exec", -1, "exec")
-        p.i("v_add_u32", v(t1), s(S_QHEAD8), v(V_LANE8))
-        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK8), v(V_QBASE))
-        p.i("ds_read_b64", vr(item, 2), v(t1))
-        p.i("s_lshl3_add_u32", s(S_QHEAD8), s(S_N), s(S_QHEAD8))
+        p.i("v_add_u32", v(t1), s(S_QHEAD4), v(V_LANE4))
+        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK4), v(V_QBASE))
+        zr = mid                                              # the item's reverse-strand mask (until the requeue below)
+        p.i("ds_read2_b32", vr(item, 2), v(t1), mods=f"offset0:0 offset1:{QCAP}")
+        p.i("ds_read_b32", v(zr), v(t1), mods=f"offset:{QCAP * 8}")
+        p.i("s_lshl2_add_u32", s(S_QHEAD4), s(S_N), s(S_QHEAD4))
         p.i("s_waitcnt", "lgkmcnt(0)")
         x, y = item, item + 1
         p.i("v_ffbl_b32", v(m), v(x))
         p.i("v_add_u32", v(rest), -1, v(x))
         p.i("v_and_b32", v(rest), v(rest), v(x))
+        p.i("v_lshrrev_b32", v(tb), v(m), v(zr))
+        p.i("v_and_b32", v(tb), 1, v(tb))                     # strand of the read being resolved
+        # ---- what is left of each word goes to the back of the queue (exec = the active items) ----
+        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
+        p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
+        p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
+        p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
+        p.i("v_lshl_add_u32", v(t1), v(t1), 2, s(S_QTAIL4))
+        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK4), v(V_QBASE))
+        p.i("s_and_b64", "exec", "exec", "vcc")
+        p.i("ds_write2_b32", v(t1), v(rest), v(y), mods=f"offset0:0 offset1:{QCAP}")
+        p.i("ds_write_b32", v(t1), v(zr), mods=f"offset:{QCAP * 8}")
+        p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
+        p.i("s_bfm_b64", "exec", s(S_N), 0)                  # the active items again
+        p.i("s_cmp_eq_u32", s(S_N), 64)
+        p.i("s_cselect_b64", "exec", -1, "exec")
         p.i("v_and_b32", v(col), 0xff, v(y))
         p.i("v_lshl_add_u32", v(col), v(m), 8, v(col))
         slots = (S_B0, S_B1, S_B2) if self.j == 1 else (S_B1, S_B2, S_B2)
@@ -542,7 +563,6 @@ class Gen:
         p.i("ds_read_b32", v(a1), v(a1))
         p.i("ds_read_b32", v(a2), v(a2))
         p.i("v_bfe_u32", v(t1), v(y), 9, 5)                   # shift = 2 x (window start within its chunk)
-        p.i("v_bfe_u32", v(tb), v(y), 8, 1)                   # strand
         p.i("v_mul_u32_u24", v(tb), hex(self.ng * 256), v(tb))
         p.i("v_add_u32", v(tb), TABLE_OFF, v(tb))             # the strand's table
         p.i("s_waitcnt", "lgkmcnt(0)")
@@ -598,20 +618,6 @@ class Gen:
             p.i("v_cmp_ne_u32_e32", "vcc", 0, v(smp))
             p.i("v_cndmask_b32_e64", v(mid), v(ext), v(mid), "vcc")     # 2 where the candidate's own pattern fails
             p.i("v_or_b32", v(sflag), v(sflag), v(mid))
-        # ---- what is left of each word goes to the back of the queue (exec = the active items) ----
-        p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
-        p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
-        p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
-        p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
-        p.i("v_lshl_add_u32", v(t1), v(t1), 3, s(S_QTAIL8))
-        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK8), v(V_QBASE))
-        p.i("v_mov_b32", v(x), v(rest))
-        p.i("s_and_b64", "exec", "exec", "vcc")
-        p.i("ds_write_b64", v(t1), vr(item, 2))
-        p.i("s_lshl3_add_u32", s(S_QTAIL8), s(S_A), s(S_QTAIL8))
-        p.i("s_bfm_b64", "exec", s(S_N), 0)                  # the active items again
-        p.i("s_cmp_eq_u32", s(S_N), 64)
-        p.i("s_cselect_b64", "exec", -1, "exec")
         # ---- clean hits: append to the hit log ----
         nolog, logged = self.lbl("nolog"), self.lbl("logged")
         p.label("logswitch_back")
@@ -790,8 +796,8 @@ class Gen:
         p.i("v_mov_b32", v(V_QBASE), s(S_A))
         p.i("s_add_u32", s(S_B1), s(S_B0), 8192)
         p.i("s_add_u32", s(S_B2), s(S_B0), 16384)
-        p.i("s_mov_b32", s(S_QHEAD8), 0)
-        p.i("s_mov_b32", s(S_QTAIL8), 0)
+        p.i("s_mov_b32", s(S_QHEAD4), 0)
+        p.i("s_mov_b32", s(S_QTAIL4), 0)
         p.i("s_mov_b64", sr(S_F1ACC, 2), 0)
         if "timers" in self.exp:
             p.i("s_mov_b32", s(S_SPARE), 0)
@@ -891,7 +897,7 @@ class Gen:
         # -- end of block: empty the queue (the ring slot of chunk n - 2 is about to be overwritten)
         drain, drained = self.lbl("drain"), self.lbl("drained")
         p.label(drain)
-        p.i("s_cmp_eq_u32", s(S_QTAIL8), s(S_QHEAD8))
+        p.i("s_cmp_eq_u32", s(S_QTAIL4), s(S_QHEAD4))
         p.i("s_cbranch_scc1", "@" + drained)
         self.call("pass")
         p.i("s_branch", "@" + drain)
@@ -920,13 +926,18 @@ class Gen:
         p.i("s_lshl_b32", s(S_A), s(S_A), 8)
         p.i("v_add_u32", v(V_T0), s(S_A), v(V_LANE4))
         p.i("global_store_dword", v(V_T0), v(V_DN), sr(S_DIRTY, 2))
-        self.transpose()
-        p.label(nopk)
         # -- rotate: planes (H0, H1, I) <- (H1, I, new), ring slots, dirty words
+        self.transpose_rotate()
+        rotated = self.lbl("rotated")
+        p.i("s_branch", "@" + rotated)
+        p.label(nopk)                                           # no chunk P (behind a tile's last one): its planes are all 'A'
         for i in range(32):
-            p.i("v_swap_b32", v(V_H0 + i), v(V_H1 + i))
+            p.i("v_mov_b32", v(V_H0 + i), v(V_H1 + i))
         for i in range(32):
-            p.i("v_swap_b32", v(V_H1 + i), v(V_I + i))
+            p.i("v_mov_b32", v(V_H1 + i), v(V_I + i))
+        for i in range(32):
+            p.i("v_mov_b32", v(V_I + i), 0)
+        p.label(rotated)
         p.i("s_mov_b32", s(S_A), s(S_B0))
         p.i("s_mov_b32", s(S_B0), s(S_B1))
         p.i("s_mov_b32", s(S_B1), s(S_B2))
@@ -1069,6 +1080,7 @@ if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else "ntc_k1h_gen.inc"
     with open(out, "w") as f:
         f.write("// ntc_k1h_gen.inc — GENERATED by gen_k1h.py (do not edit)\n")
+        f.write(f"#define K1H_GEN_WAVES {WAVES}\n#define K1H_GEN_WAREA {WAREA} // LDS bytes per wave: ring + queue\n")
         for k, gap in VARIANTS:
             for sb in (7, 8):
                 f.write(render_inc(k, sb, gap))

@@ -693,6 +693,25 @@ class Emu:
             val[em] = self.lds32[addr[em] // 4 + j]
             self.wr_v(("v", a + j, 1), val)
 
+    def op_ds_read2_b32(self, pc, o, m):
+        em = self.mask_arr()
+        base = self.rd_v(o[1]).astype(np.int64)
+        kind, a, n = o[0]
+        for j, key in enumerate(("offset0", "offset1")):
+            addr = base + 4 * m.get(key, 0)
+            assert np.all(addr[em] % 4 == 0) and np.all(addr[em] + 4 <= self.lds.size), "ds_read2_b32: bad address"
+            val = np.zeros(64, dtype=np.uint32)
+            val[em] = self.lds32[addr[em] // 4]
+            self.wr_v(("v", a + j, 1), val)
+
+    def op_ds_write2_b32(self, pc, o, m):
+        em = self.mask_arr()
+        base = self.rd_v(o[0]).astype(np.int64)
+        for j, key in enumerate(("offset0", "offset1")):
+            addr = base + 4 * m.get(key, 0)
+            assert np.all(addr[em] % 4 == 0) and np.all(addr[em] + 4 <= self.lds.size), "ds_write2_b32: bad address"
+            self.lds32[addr[em] // 4] = self.rd_v(o[1 + j])[em]
+
     def op_ds_write_b32(self, pc, o, m):
         em = self.mask_arr()
         addr = self._lds_addr(o[0], m)

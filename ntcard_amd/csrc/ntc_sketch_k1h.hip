@@ -39,8 +39,9 @@ static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && of
                   offsetof(K1hArgs, blocks_per_wave) == 104 && offsetof(K1hArgs, nb_magic) == 108 && offsetof(K1hArgs, sus) == 112 &&
                   offsetof(K1hArgs, sus_count) == 120 && offsetof(K1hArgs, sus_cap) == 128,
               "gen_k1h.KARG");
-constexpr uint32_t kK1hWaves = 6;
-constexpr uint32_t kK1hWArea = 25600;
+constexpr uint32_t kK1hWaves = K1H_GEN_WAVES;
+constexpr uint32_t kK1hWArea = K1H_GEN_WAREA;
+static_assert(kK1hWaves == 6, "the launch (384 threads) and the share-out by SIMD assume six waves per workgroup");
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
 constexpr uint32_t k1h_table_bytes(uint32_t k) { return 2u * ((k + 2u) / 3u) * 256u; }
 constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k) + 32u; } // the wave areas, the table, the waves' SIMD numbers

@@ -232,29 +232,35 @@ def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     assert out.read_bytes() == open(os.path.join(GOLD, pl["hist_file"]), "rb").read()
 
 
-def test_tiled_side_stream_fixups(nt):
-    """NTC_FLAG_DEFER_REDO: the caller leaves its batches alone until sync, so K1f of one batch runs on the engine's side stream beside K1h of
-    the next (two sets of hand-over arrays, used in turn); five batches with non-ACGTU bytes, several engines' worth of launches"""
+def test_tiled_deferred_fixups(nt):
+    """NTC_FLAG_DEFER_REDO: the caller leaves its batches alone until sync, so the engine collects up to eight K1h launches and sends ONE K1f over
+    all of them (blockIdx.y = the launch).  Eleven batches of different sizes and read lengths with non-ACGTU bytes: the ninth forces a K1f in
+    mid-run; one batch holds reference-table slot bytes (its launch alone takes K1f's slow path); a flush in between; more batches behind it"""
     rng = np.random.default_rng(77)
     alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
     parts, bufs = [], []
-    for i in range(5):
-        n, L = 30_000 + 4000 * i, 150
+    for i in range(11):
+        n, L = 30_000 + 4000 * i, (150, 97, 64)[i % 3]
         arr = alpha[rng.integers(0, 4, size=(n, L))]
         arr = np.where(rng.random((n, L)) < 0.003, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+        if i == 4 and VARIANT_FLAGS == 0:  # (K1c takes those bytes for non-bases: a documented deviation of that kernel only)
+            arr[rng.integers(0, n, size=50), rng.integers(0, L, size=50)] = np.array([1, 3, 4, 5, 7], dtype=np.uint8)[rng.integers(0, 5, size=50)]
         parts.append(arr)
         bufs.append(torch.from_numpy(tile_array(arr)).cuda())
+    order = list(range(11)) + [0, 1]
     with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | nt.FLAG_DEFER_REDO | VARIANT_FLAGS) as e:
-        for arr, t in zip(parts, bufs):
-            e.submit_tiled_device(t.data_ptr(), arr.shape[0], 150)
+        for i in order[:11]:
+            e.submit_tiled_device(bufs[i].data_ptr(), parts[i].shape[0], parts[i].shape[1])
         e.flush()
-        for arr, t in zip(parts[:2], bufs[:2]):  # and on after a flush
-            e.submit_tiled_device(t.data_ptr(), arr.shape[0], 150)
+        for i in order[11:]:  # and on after a flush
+            e.submit_tiled_device(bufs[i].data_ptr(), parts[i].shape[0], parts[i].shape[1])
         tc, ph, f1 = e.finish(counters=True)
-    allr = np.concatenate(parts + parts[:2])
     counters = np.zeros((1, 2, 1 << 20), dtype=np.uint16)
-    offs = np.arange(allr.shape[0] + 1, dtype=np.uint64) * np.uint64(150)
-    of1 = orc.sketch_update(counters, np.ascontiguousarray(allr).reshape(-1), offs, [32], 0, 20, 7)
+    of1 = np.zeros(1, dtype=np.uint64)
+    for i in order:
+        arr = parts[i]
+        offs = np.arange(arr.shape[0] + 1, dtype=np.uint64) * np.uint64(arr.shape[1])
+        of1 += orc.sketch_update(counters, np.ascontiguousarray(arr).reshape(-1), offs, [32], 0, 20, 7)
     assert np.array_equal(f1, of1) and np.array_equal(tc, counters)
 
 
