@@ -155,7 +155,7 @@ def live_pmc(argv_inner, n_steps):
                         if row["Counter_Name"] != ctr:
                             continue
                         kn = row["Kernel_Name"]
-                        is_hash = any(x in kn for x in ("sketch_hf_kernel", "sketch_bs_kernel", "sketch_ts_kernel", "sketch_k1h_kernel", "k1h_f1_kernel", "k1h_suspect_kernel", "k1h_slow_kernel", "append_slots"))
+                        is_hash = any(x in kn for x in ("sketch_hf_kernel", "sketch_bs_kernel", "sketch_ts_kernel", "sketch_k1h_kernel", "k1h_fix_kernel", "k1h_slow_kernel", "append_slots"))
                         is_apply = any(x in kn for x in ("split_kernel", "count_kernel", "log_atomics", "log_total", "log_probe", "log_decide"))
                         if is_hash or is_apply:
                             tot += float(row["Counter_Value"])

@@ -40,8 +40,9 @@ from k1h_asm import Prog, v, s, vr, sr, schedule
 
 WAVES = 6                    # waves per workgroup = tiles in flight per CU
 RING_BYTES = 3 * 8192        # three packed chunks
-QCAP = 128                   # queue items: three dwords each, kept as three arrays of QCAP dwords (hit word, meta, reverse-strand mask)
-WAREA = RING_BYTES + QCAP * 12  # 26112 bytes per wave
+QCAP = 128                   # queue items: three dwords each, kept as three arrays (hit word, meta, reverse-strand mask) of QCAP dwords + one
+QSTRIDE = QCAP + 1           # dummy slot: a lane with nothing to queue writes there, so the writes need no exec mask (an exec write costs ~2 issue slots)
+WAREA = RING_BYTES + QSTRIDE * 12  # 26124 bytes per wave
 TABLE_OFF = WAVES * WAREA    # 156672: [2 strands][NG][64] dwords
 LDS_BYTES = 160 * 1024
 
@@ -56,7 +57,7 @@ def table_bytes(k):
 
 # ---- register map ------------------------------------------------------------------------------------------
 # VGPRs
-V_LANE4, V_LANE16, V_LANE8, V_QBASE, V_WAVE4, V_ONE, V_EXP1, V_VMASK = range(0, 8)  # V_WAVE4: 4 x the wave's number in the launch
+V_LANE4, V_LANE16, V_QDUMMY, V_QBASE, V_WAVE4, V_ONE, V_EXP1, V_VMASK = range(0, 8)  # V_WAVE4: 4 x the wave's number in the launch
 V_D0, V_D1, V_D2, V_DN, V_CMASK, V_TACC, V_CARRY0, V_CARRY1, V_SPARE1 = range(8, 17)
 V_DMASK = 17       # reads of this block with a dirty piece in one of its three chunks (and valid): their candidates are SUSPECTS
 V_F = 18           # F[31]   (register tuples — loads, 64-bit LDS items — must start at even registers on gfx90a+)
@@ -395,12 +396,12 @@ class Gen:
         p.i("v_mbcnt_lo_u32_b32", v(T + 1), "vcc_lo", 0)
         p.i("v_mbcnt_hi_u32_b32", v(T + 1), "vcc_hi", v(T + 1))
         p.i("v_lshl_add_u32", v(T + 1), v(T + 1), 2, s(S_QTAIL4))
-        p.i("v_and_or_b32", v(T + 1), v(T + 1), v(V_CQMASK4), v(V_QBASE))
+        p.i("v_and_b32", v(T + 1), v(V_CQMASK4), v(T + 1))
         p.i("v_or_b32", v(T + 3), hex(meta), v(V_LANE4))
-        p.i("s_mov_b64", "exec", "vcc")
-        p.i("ds_write2_b32", v(T + 1), v(T + 2), v(T + 3), mods=f"offset0:0 offset1:{QCAP}")
-        p.i("ds_write_b32", v(T + 1), v(xr), mods=f"offset:{QCAP * 8}")
-        p.i("s_mov_b64", "exec", -1)
+        p.i("v_cndmask_b32_e64", v(T + 1), v(V_QDUMMY), v(T + 1), "vcc")   # V_QDUMMY = 4 QCAP: the dummy slot
+        p.i("v_add_u32", v(T + 1), v(V_QBASE), v(T + 1))
+        p.i("ds_write2_b32", v(T + 1), v(T + 2), v(T + 3), mods=f"offset0:0 offset1:{QSTRIDE}")
+        p.i("ds_write_b32", v(T + 1), v(xr), mods=f"offset:{QSTRIDE * 8}")
         p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
 
     # ---- pack one group of 64 pieces: RAW slot i -> packed word in register dst; then reload the slot ----
@@ -527,10 +528,11 @@ class Gen:
         p.i("s_cmp_eq_u32", s(S_N), 64)
         p.i("s_cselect_b64", "exec", -1, "exec")
         p.i("v_add_u32", v(t1), s(S_QHEAD4), v(V_LANE4))
-        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK4), v(V_QBASE))
+        p.i("v_and_b32", v(t1), v(V_CQMASK4), v(t1))
+        p.i("v_add_u32", v(t1), v(V_QBASE), v(t1))
         zr = mid                                              # the item's reverse-strand mask (until the requeue below)
-        p.i("ds_read2_b32", vr(item, 2), v(t1), mods=f"offset0:0 offset1:{QCAP}")
-        p.i("ds_read_b32", v(zr), v(t1), mods=f"offset:{QCAP * 8}")
+        p.i("ds_read2_b32", vr(item, 2), v(t1), mods=f"offset0:0 offset1:{QSTRIDE}")
+        p.i("ds_read_b32", v(zr), v(t1), mods=f"offset:{QSTRIDE * 8}")
         p.i("s_lshl2_add_u32", s(S_QHEAD4), s(S_N), s(S_QHEAD4))
         p.i("s_waitcnt", "lgkmcnt(0)")
         x, y = item, item + 1
@@ -545,14 +547,12 @@ class Gen:
         p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
         p.i("v_mbcnt_hi_u32_b32", v(t1), "vcc_hi", v(t1))
         p.i("v_lshl_add_u32", v(t1), v(t1), 2, s(S_QTAIL4))
-        p.i("v_and_or_b32", v(t1), v(t1), v(V_CQMASK4), v(V_QBASE))
-        p.i("s_and_b64", "exec", "exec", "vcc")
-        p.i("ds_write2_b32", v(t1), v(rest), v(y), mods=f"offset0:0 offset1:{QCAP}")
-        p.i("ds_write_b32", v(t1), v(zr), mods=f"offset:{QCAP * 8}")
+        p.i("v_and_b32", v(t1), v(V_CQMASK4), v(t1))
+        p.i("v_cndmask_b32_e64", v(t1), v(V_QDUMMY), v(t1), "vcc")   # (a spent word goes to the dummy slot)
+        p.i("v_add_u32", v(t1), v(V_QBASE), v(t1))
+        p.i("ds_write2_b32", v(t1), v(rest), v(y), mods=f"offset0:0 offset1:{QSTRIDE}")
+        p.i("ds_write_b32", v(t1), v(zr), mods=f"offset:{QSTRIDE * 8}")
         p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
-        p.i("s_bfm_b64", "exec", s(S_N), 0)                  # the active items again
-        p.i("s_cmp_eq_u32", s(S_N), 64)
-        p.i("s_cselect_b64", "exec", -1, "exec")
         p.i("v_and_b32", v(col), 0xff, v(y))
         p.i("v_lshl_add_u32", v(col), v(m), 8, v(col))
         slots = (S_B0, S_B1, S_B2) if self.j == 1 else (S_B1, S_B2, S_B2)
@@ -788,12 +788,12 @@ class Gen:
         p.i("v_mbcnt_lo_u32_b32", v(V_LANE4), -1, 0)
         p.i("v_mbcnt_hi_u32_b32", v(V_LANE4), -1, v(V_LANE4))
         p.i("v_lshlrev_b32", v(V_LANE16), 4, v(V_LANE4))
-        p.i("v_lshlrev_b32", v(V_LANE8), 3, v(V_LANE4))
         p.i("v_lshlrev_b32", v(V_LANE4), 2, v(V_LANE4))
         p.i("v_mov_b32", v(V_ONE), 1)
         p.i("v_mov_b32", v(V_EXP1), "0x43ff41ff")
         p.i("s_add_u32", s(S_A), s(S_B0), RING_BYTES)
         p.i("v_mov_b32", v(V_QBASE), s(S_A))
+        p.i("v_mov_b32", v(V_QDUMMY), QCAP * 4)
         p.i("s_add_u32", s(S_B1), s(S_B0), 8192)
         p.i("s_add_u32", s(S_B2), s(S_B0), 16384)
         p.i("s_mov_b32", s(S_QHEAD4), 0)

@@ -1125,6 +1125,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 			const uint32_t k = e->klist[ki];
 			if (!ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits)) continue;
+			if ((uint64_t)(ki + 1) * e->plane_elems() > (1ull << 32)) continue; // K1h / K1f index the counters with 32 bits
 			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);
 			ntc::build_k1h_table(k, e->gap, e->r_bits, e->s_bits, tab.data());
 			uint32_t* d = nullptr;

@@ -168,9 +168,8 @@ __device__ __forceinline__ bool has_slot_byte(const tilebits::v4u32 v)
 
 // F1 correction: a wave compacts the dirty pieces of its rows into an LDS queue and takes 64 at a time, one per lane (a scattered 16-byte
 // load each, all in flight together)
-__global__ __launch_bounds__(256) void k1h_f1_kernel(const K1fBatch batch)
+__device__ __forceinline__ void k1f_f1_role(const K1fItem& item, const uint32_t bx, const uint32_t nbx)
 {
-	const K1fItem& item = batch.item[blockIdx.y];
 	const K1hArgs& a = item.a;
 	const uint32_t k = item.k, n_sus_waves = item.n_waves;
 	__shared__ uint2 s_q[4][128];
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256) void k1h_f1_kernel(const K1fBatch batch)
 	const uint64_t n_rows = (uint64_t)a.n_tiles * C;
 	uint32_t f1_sub = 0;
 	bool slow = false;
-	for (uint32_t i = blockIdx.x * 256u + tid; i < n_sus_waves; i += gridDim.x * 256u)
+	for (uint32_t i = bx * 256u + tid; i < n_sus_waves; i += nbx * 256u)
 		slow |= a.sus_count[i] == 0xffffffffu; // a K1h wave ran out of room for its suspects
 	uint2* const queue = s_q[wv];
 	uint32_t qhead = 0, qtail = 0;
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(256) void k1h_f1_kernel(const K1fBatch batch)
 		}
 		qhead += n_items;
 	};
-	const uint64_t wave_g = (uint64_t)blockIdx.x * 4u + wv, n_wv = (uint64_t)gridDim.x * 4u;
+	const uint64_t wave_g = (uint64_t)bx * 4u + wv, n_wv = (uint64_t)nbx * 4u;
 	for (uint64_t row4 = wave_g * 4u; row4 < n_rows; row4 += n_wv * 4u) {
 		uint32_t w[6];
 #pragma unroll
@@ -254,68 +253,72 @@ __global__ __launch_bounds__(256) void k1h_f1_kernel(const K1fBatch batch)
 	}
 }
 
-// fast path, after k1h_f1_kernel: the suspects, and the F1 correction it summed up.  No LDS, few registers: it runs beside the next
-// batch's K1h waves (the engine launches K1f on a side stream).
-__global__ __launch_bounds__(256) void k1h_suspect_kernel(const K1fBatch batch)
+// the suspects (near a dirty piece, or with tied strands): the window's hash from its bytes — packed to 2 bits per base, four bases per look-up
+// in K1c's closed-form table (nthash.hpp:220-239) — counted iff every byte is a letter.  It runs BESIDE the F1 role (both wait on scattered
+// loads; side by side they take little longer than one of them), so it cannot know yet whether the launch must take the slow path (a table-slot
+// byte in some dirty piece): it counts, and leaves the counter it incremented in the entry (x = counter index, w = 1) — the slow path takes
+// those increments back before it re-derives everything from the bytes.  No LDS, few registers.
+__device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint32_t bx, const uint32_t nbx)
 {
-	const K1fItem& item = batch.item[blockIdx.y];
 	const K1hArgs& a = item.a;
-	const void* const t4 = item.t4;
 	const uint32_t k = item.k, n_sus_waves = item.n_waves;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
 	const uint32_t rmask = (1u << r_bits) - 1u;
-	const bool slow = a.fix_state[0] == a.launch_id; // (decided before this launch: a K1h wave's suspect region overflowed, or k1h_f1_kernel met a table-slot byte)
-	if (!slow) {
-		// ---- suspects (near a dirty piece, or with tied strands): the window's hash from its bytes — packed to 2 bits per base, four bases
-		// per look-up in K1c's closed-form table (nthash.hpp:220-239) — counted iff every byte is a letter (the fast path has made sure
-		// that no table-slot byte exists).  One block per K1h wave's region. ----
-		const uint4* const t4v = reinterpret_cast<const uint4*>(t4);
-		for (uint32_t hb = blockIdx.x; hb < 2u * n_sus_waves; hb += gridDim.x) { // half a region per block
-			const uint32_t reg = hb >> 1, n = a.sus_count[reg];
-			for (uint32_t i = (hb & 1u) * 256u + tid; i < n; i += 512u) {
-				const uint4 e = a.sus[(size_t)reg * a.sus_cap + i];
-				const uint32_t t = e.y, r = e.z & 2047u, w = e.z >> 11;
-				const uint32_t c0 = w >> 4, off = w & 15u;
-				uint32_t pk[3], bad[3];
-				uint64_t inv = 0;
+	const uint4* const t4v = reinterpret_cast<const uint4*>(item.t4);
+	for (uint32_t hb = bx; hb < 2u * n_sus_waves; hb += nbx) { // half a K1h wave's region per block
+		const uint32_t reg = hb >> 1;
+		uint32_t n = a.sus_count[reg];
+		if (n == 0xffffffffu) n = 0; // the region overflowed: the launch takes the slow path, which ignores the suspects
+		for (uint32_t i = (hb & 1u) * 256u + tid; i < n; i += 512u) {
+			uint4* const ep = a.sus + (size_t)reg * a.sus_cap + i;
+			const uint4 e = *ep;
+			const uint32_t t = e.y, r = e.z & 2047u, w = e.z >> 11;
+			const uint32_t c0 = w >> 4, off = w & 15u;
+			uint32_t pk[3], bad[3];
+			uint64_t inv = 0;
 #pragma unroll
-				for (uint32_t j = 0; j < 3; ++j) { // the window's <= 3 pieces
-					pk[j] = bad[j] = 0;
-					if (c0 + j < C && 16u * j < off + k) {
-						const tilebits::v4u32 v = raw_piece(a, t, c0 + j, r);
-						pk[j] = tilebits::pack16(v, bad[j]);
-						if (bad[j]) inv |= (uint64_t)tilebits::inv16(v) << (16u * j); // (rare-ish: the exact positions)
-					}
+			for (uint32_t j = 0; j < 3; ++j) { // the window's <= 3 pieces
+				pk[j] = bad[j] = 0;
+				if (c0 + j < C && 16u * j < off + k) {
+					const tilebits::v4u32 v = raw_piece(a, t, c0 + j, r);
+					pk[j] = tilebits::pack16(v, bad[j]);
+					if (bad[j]) inv |= (uint64_t)tilebits::inv16(v) << (16u * j); // (rare-ish: the exact positions)
 				}
-				const uint64_t win = k >= 64u ? ~0ull : (1ull << k) - 1ull;
-				if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
-				const uint32_t lo = tilebits::alignbit(pk[1], pk[0], 2u * off), hi = tilebits::alignbit(pk[2], pk[1], 2u * off);
-				uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
-				for (uint32_t g = 0; g < (k + 3u) / 4u; ++g) {
-					const uint32_t b = ((g < 4u ? lo : hi) >> (8u * (g & 3u))) & 0xffu;
-					const uint4 x = t4v[g * 256u + b];
-					f0 ^= x.x;
-					f1 ^= x.y;
-					r0 ^= x.z;
-					r1 ^= x.w;
-				}
-				const uint64_t fh = ((uint64_t)f1 << 32) | f0, rh = ((uint64_t)r1 << 32) | r0;
-				const uint64_t h = rh < fh ? rh : fh;                                                          // nthash.hpp:275-279
-				uint32_t smp = 2;                                                                             // ntcard.cpp:132-145
-				if ((h >> (63u - s_bits)) == 1ull) smp = 0;
-				if ((h >> (64u - s_bits)) == (1ull << (s_bits - 1u)) - 1ull) smp = 1;
-				if (smp < 2u) atomicAdd(a.sketch0 + (size_t)a.key_base + ((size_t)smp << r_bits) + (size_t)(h & (uint64_t)rmask), 1u);
+			}
+			const uint64_t win = k >= 64u ? ~0ull : (1ull << k) - 1ull;
+			if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
+			const uint32_t lo = tilebits::alignbit(pk[1], pk[0], 2u * off), hi = tilebits::alignbit(pk[2], pk[1], 2u * off);
+			uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+			for (uint32_t g = 0; g < (k + 3u) / 4u; ++g) {
+				const uint32_t b = ((g < 4u ? lo : hi) >> (8u * (g & 3u))) & 0xffu;
+				const uint4 x = t4v[g * 256u + b];
+				f0 ^= x.x;
+				f1 ^= x.y;
+				r0 ^= x.z;
+				r1 ^= x.w;
+			}
+			const uint64_t fh = ((uint64_t)f1 << 32) | f0, rh = ((uint64_t)r1 << 32) | r0;
+			const uint64_t h = rh < fh ? rh : fh;                                                          // nthash.hpp:275-279
+			uint32_t smp = 2;                                                                             // ntcard.cpp:132-145
+			if ((h >> (63u - s_bits)) == 1ull) smp = 0;
+			if ((h >> (64u - s_bits)) == (1ull << (s_bits - 1u)) - 1ull) smp = 1;
+			if (smp < 2u) {
+				const uint32_t idx = a.key_base + (smp << r_bits) + (uint32_t)(h & (uint64_t)rmask); // (engines with a hit log have < 2^32 counters; K1h itself keys them with 32 bits)
+				atomicAdd(a.sketch0 + idx, 1u);
+				ep->x = idx;
+				ep->w = 1u;
 			}
 		}
-		if (blockIdx.x == 0 && tid == 0) { // the F1 correction k1h_f1_kernel summed up
-			unsigned long long* fs = reinterpret_cast<unsigned long long*>(a.fix_state + 2);
-			const unsigned long long sub = *fs;
-			if (sub) atomicAdd(a.f1, (unsigned long long)0 - sub);
-			__threadfence();
-		}
 	}
-	if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<unsigned long long*>(a.fix_state + 2) = 0ull; // (ready for the next launch; the slow path counts F1 itself)
+}
+
+// K1f, first launch: the F1 role and the suspect role side by side (blocks [0, n_f1) and the rest), blockIdx.y = the K1h launch of the batch
+__global__ __launch_bounds__(256) void k1h_fix_kernel(const K1fBatch batch, const uint32_t n_f1_blocks)
+{
+	const K1fItem& item = batch.item[blockIdx.y];
+	if (blockIdx.x < n_f1_blocks) k1f_f1_role(item, blockIdx.x, n_f1_blocks);
+	else k1f_suspect_role(item, blockIdx.x - n_f1_blocks, gridDim.x - n_f1_blocks);
 }
 
 // byte -> bits 0..2: code2 of the base (A 0, C 1, T/U 2, G 3; 4: no base), bits 4..5: the code whose letter-complement is what the
@@ -355,10 +358,26 @@ __global__ __launch_bounds__(256) void k1h_slow_kernel(const K1fBatch batch)
 	unsigned char* const stage = s_stage[wv] + lane * kFixStage;
 	uint32_t qhead = 0, qtail = 0; // wave-uniform
 	uint32_t f1_sub = 0;
-	// only when the launch must take the slow path (a suspect region overflowed, or a table-slot byte turned up): otherwise k1h_f1_kernel
-	// and k1h_suspect_kernel have done everything
-	if (a.fix_state[0] != a.launch_id) return;
+	// The launch takes the slow path only when a suspect region overflowed or a table-slot byte turned up.  Otherwise k1h_fix_kernel has done
+	// everything but one subtraction: the F1 correction its F1 role summed up.
+	const bool flagged = a.fix_state[0] == a.launch_id;
+	if (blockIdx.x == 0 && tid == 0) {
+		unsigned long long* fs = reinterpret_cast<unsigned long long*>(a.fix_state + 2);
+		const unsigned long long sub = *fs;
+		if (!flagged && sub) atomicAdd(a.f1, (unsigned long long)0 - sub);
+		*fs = 0ull; // (ready for the next launch; the slow path counts F1 itself)
+	}
+	if (!flagged) return;
 	const bool slow = true;
+	// what the suspect role counted goes back first: every window of a dirty-affected block is re-derived below, tie windows included
+	for (uint32_t reg = blockIdx.x; reg < item.n_waves; reg += gridDim.x) {
+		uint32_t n = a.sus_count[reg];
+		if (n == 0xffffffffu) n = 0;
+		for (uint32_t i = tid; i < n; i += 256u) {
+			const uint4 e = a.sus[(size_t)reg * a.sus_cap + i];
+			if (e.w == 1u) atomicSub(a.sketch0 + e.x, 1u);
+		}
+	}
 
 	// ---- walk the 64 (or fewer) items at the head of the queue ----
 	auto walk = [&](uint32_t n_items) {
@@ -587,9 +606,9 @@ hipError_t launch_k1h_fixup(const K1fBatch& b, uint32_t n_items, unsigned cus, h
 		rows = std::max(rows, (size_t)b.item[i].a.n_tiles * b.item[i].a.n_chunks);
 		waves = std::max(waves, b.item[i].n_waves);
 	}
-	hipLaunchKernelGGL(k1h_f1_kernel, dim3((unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8), n_items), dim3(256), 0, st, b);
-	hipLaunchKernelGGL(k1h_suspect_kernel, dim3(2u * waves, n_items), dim3(256), 0, st, b);
-	// the slow path takes LDS and a CU's worth of blocks; it returns at once unless the launch is flagged
+	const unsigned n_f1 = (unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8);
+	hipLaunchKernelGGL(k1h_fix_kernel, dim3(n_f1 + 2u * waves, n_items), dim3(256), 0, st, b, n_f1);
+	// the F1 correction of the fast path; the slow path (LDS, a CU's worth of blocks) only for a flagged launch
 	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus, n_items), dim3(256), 0, st, b);
 	return hipGetLastError();
 }
