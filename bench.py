@@ -383,10 +383,10 @@ def main():
         step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: K1f on the side stream, counted in full although it overlaps the next hash launch)
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
-        if (tiled and nk == 1 and ((klist[0] == 32 and not args.gap) or (klist[0] == 12 and args.gap == 2)) and args.s_bits >= 7
+        if (tiled and ((all(12 <= k <= 32 for k in klist) and not args.gap) or (klist == [12] and args.gap == 2)) and args.s_bits >= 7
                 and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel and not args.teams):
             kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_f1 / k1h_suspect kernels (K1f, side stream)"
-        elif tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
+        elif tiled and all(12 <= k <= 32 for k in klist) and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
             kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"
         elif (nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255 and not tiled
               and (args.bitslice or (R >= 2048 * 128 and L - 31 >= 97 and not args.lane_kernel and not args.direct_atomics))):

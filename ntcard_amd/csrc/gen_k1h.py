@@ -1073,15 +1073,25 @@ def render_inc(k, sb, gap=0):
         "\n".join(ln + " \\" for ln in body.split("\n")) + "\n\n"
 
 
-VARIANTS = ((32, 0), (12, 2))  # (k, gap) the library is built with: BASELINE configs 2 / 3 and 5
+# (k, gap) the library is built with: every plain k of 12 .. 32, and ntcard's -g seed of BASELINE config 5 (k = 12, gap 2)
+VARIANTS = tuple((k, 0) for k in range(12, 33)) + ((12, 2),)
+PARTS = 4                      # the kernels are spread over this many objects (k % PARTS) so that `make -j` compiles them side by side
 
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else "ntc_k1h_gen.inc"
+    defs = out.replace(".inc", "_defs.inc")
+    with open(defs, "w") as f:
+        f.write("// ntc_k1h_gen_defs.inc — GENERATED by gen_k1h.py (do not edit): geometry and the list of kernel variants\n")
+        f.write(f"#define K1H_GEN_WAVES {WAVES}\n#define K1H_GEN_WAREA {WAREA} // LDS bytes per wave: ring + queue\n#define K1H_GEN_PARTS {PARTS}\n")
+        f.write("#define K1H_VARIANTS_ALL(X) " + " ".join(f"X({k}, {g})" for k, g in VARIANTS) + "\n")
+        for part in range(PARTS):
+            f.write(f"#define K1H_VARIANTS_P{part}(X) " + " ".join(f"X({k}, {g})" for k, g in VARIANTS if k % PARTS == part) + "\n")
     with open(out, "w") as f:
-        f.write("// ntc_k1h_gen.inc — GENERATED by gen_k1h.py (do not edit)\n")
-        f.write(f"#define K1H_GEN_WAVES {WAVES}\n#define K1H_GEN_WAREA {WAREA} // LDS bytes per wave: ring + queue\n")
+        f.write("// ntc_k1h_gen.inc — GENERATED by gen_k1h.py (do not edit): one assembly string per (k, gap, sBits class)\n")
         for k, gap in VARIANTS:
             for sb in (7, 8):
+                f.write(f"#if K1H_PART == {k % PARTS}\n")
                 f.write(render_inc(k, sb, gap))
-    print("wrote", out)
+                f.write("#endif\n")
+    print("wrote", out, "and", defs)
