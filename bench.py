@@ -176,7 +176,7 @@ def live_pmc(argv_inner, n_steps):
 def traffic_key(args, reads_per_launch):
     k = ",".join(map(str, klist_of(args)))
     return (f"dist={args.dist},L={args.read_len},k={k},gap={args.gap},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
-            + (",tiled" if args.layout == "tiled" else "") + (",bitslice" if args.bitslice else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
+            + (",tiled" if args.layout == "tiled" else "") + (",teams" if args.teams else "") + (",bitslice" if args.bitslice else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
             + (",always-log" if args.always_log else ""))
 
 

@@ -72,10 +72,12 @@ typedef struct {
                                       atomics when an apply finds few distinct counters per increment: repeats)       */
 #define NTC_FLAG_PARTITION_ALWAYS 16u /* validation: apply even a small hit log through the partition + histogram passes
                                          (by default fewer than 4 M pending entries are applied with plain atomics)   */
-#define NTC_FLAG_DEFER_REDO 128u    /* ntc_submit_device only: the caller promises to keep every submitted buffer valid AND UNCHANGED until
-                                      ntc_sync / ntc_finish returns.  The reads K1b hands back to the lane-per-read kernel (a non-ACGTU byte
-                                      somewhere, the batch tail) are then hashed in ONE pass shared by several batches instead of one per
-                                      batch.  Without the flag a buffer may be reused as soon as the stream has passed the submit call. */
+#define NTC_FLAG_DEFER_REDO 128u    /* device-resident batches (ntc_submit_device, ntc_submit_tiled_device): the caller promises to keep every
+                                      submitted buffer valid AND UNCHANGED until ntc_sync / ntc_finish returns.  The second passes over a batch's
+                                      reads with non-ACGTU bytes are then shared by several batches instead of run per batch: the fix-up
+                                      kernels K1f behind up to 8 launches of the one-wave-per-tile kernel K1h; the reads K1b hands back to the
+                                      lane-per-read kernel.  Without the flag a buffer may be reused as soon as the stream has passed the submit
+                                      call. */
 #define NTC_FLAG_REQUIRE_TILED 64u  /* validation: ntc_submit_tiled_device fails instead of re-laying a batch out for the general kernel */
 #define NTC_FLAG_TILED_TEAMS 256u   /* tiled batches: use K1c (teams of four specialised waves, round 3) instead of K1h (one wave per tile,
                                      * round 4) where both are built for the configuration (cross-check, A/B runs) */
@@ -117,7 +119,7 @@ int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, con
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
                       uint32_t stride);
 
-/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernel (K1c) streams:
+/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernels (K1h; K1c) stream:
  *     tile t   = reads [2048 t, 2048 t + 2048) of the batch,       n_chunks = ceil(read_len / 16)
  *     piece    = the 16 raw bytes of bases [16 c, 16 c + 16) of read i, at byte offset
  *                ((i / 2048 * n_chunks + c) * 2048 + i % 2048) * 16          (ntc_tiled_bytes() bytes in all)
@@ -126,10 +128,11 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
  * bytes as the parsers produce them (any case, N / IUPAC); bytes behind a read's end (inside its last piece) must hold a base
  * letter ('A'); the slots behind the batch's last read (the rest of the last tile) are ignored whatever they hold, so any
  * prefix of a tiled buffer is a valid batch.  All reads of a batch have the same length.  Asynchronous on the engine's
- * stream; the buffer may be reused as soon as the stream has passed the call (nothing refers to it afterwards).  A list of k is
- * served by one launch per k.  Configurations the tiled kernel is not built for (a k outside 12 .. 32, spaced seeds, nthll,
- * sBits < 7) are re-laid out on the device and take the general kernel: same results, not the fast path.  Host batches
- * (ntc_submit, ntc_submit_spans) use row slots.                                                                          */
+ * stream; the buffer may be reused as soon as the stream has passed the call — unless the engine was created with
+ * NTC_FLAG_DEFER_REDO, see there.  A list of k is served by one launch per k.  Configurations the tiled kernels are not
+ * built for (a k outside 12 .. 32, spaced seeds other than ntcard's -g seed at k = 12 / gap 2, nthll, sBits < 7) are re-laid
+ * out on the device and take the general kernel: same results, not the fast path.  Host batches of (mostly) equal-length
+ * reads reach the same kernels: ntc_submit / ntc_submit_spans pack them into tiles in pinned staging.                   */
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
 
@@ -224,8 +227,8 @@ int ntc_hll_estimate(const uint8_t *regs, uint32_t n_bits, double *est_out);
 int ntc_kernel_time(ntc_engine *e, double *ms_total, uint64_t *launches);
 /* same for the deferred sketch update (partition + count passes): milliseconds and number of applies */
 int ntc_apply_time(ntc_engine *e, double *ms_total, uint64_t *applies);
-/* same for the fix-up kernels of the one-wave-per-tile kernel when they run on the engine's side stream (NTC_FLAG_DEFER_REDO engines: beside
- * the next batch's hash kernel, so this time is NOT part of ntc_kernel_time; without the flag they run on the engine's stream and are) */
+/* same for the fix-up kernels K1f of the one-wave-per-tile kernel when the engine defers them (NTC_FLAG_DEFER_REDO: one K1f launch over up to 8
+ * batches, outside the hash kernels' events, so this time is NOT part of ntc_kernel_time; without the flag K1f follows every K1h launch and is) */
 int ntc_fixup_time(ntc_engine *e, double *ms_total);
 /* device buffers, copy streams and events ntc_merge_devices has created for this engine so far: they are kept between merges, so the count
  * stops growing after the first merge of a given group of engines (diagnostic) */
