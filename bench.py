@@ -298,14 +298,14 @@ def main():
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_big = torch.zeros(nk + 8, dtype=torch.int64, device=dev)  # (a K1h timing build adds its section clocks behind F1: tools/k1h_variant.sh)
     f1_dev = f1_big[:nk]
-    # the resident batches stay untouched until the end of the run: the engine may share one pass over the reads K1b hands back
-    # between batches (NTC_FLAG_DEFER_REDO); the tiled path needs no such promise
+    # the resident batches stay untouched until the end of the run: the engine may share its second passes (K1f behind K1h; the reads K1b
+    # hands back) between batches (NTC_FLAG_DEFER_REDO)
     eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream, ext_sketch=sketch, ext_f1=f1_dev,
                     log_entries=args.log_entries,
                     flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
                     | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0) | (nt.FLAG_TILED_TEAMS if args.teams else 0)
                     | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0)
-                    | nt.FLAG_DEFER_REDO)  # (tiled batches too: the fix-up kernels of batch i then run beside the hash kernel of batch i + 1)
+                    | nt.FLAG_DEFER_REDO)  # (tiled batches too: the fix-up kernels K1f then take up to 8 batches per launch)
 
     def submit(buf):
         if tiled:
@@ -380,12 +380,12 @@ def main():
         read_bytes = R * (L + 4)
         alg_bytes = read_bytes + 4.0 * per_step_hits
         hash_ms = ker_ms / max(K, 1)
-        step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: K1f on the side stream, counted in full although it overlaps the next hash launch)
+        step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: the deferred K1f launches, one per up to 8 batches, on the engine's stream like everything else)
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
         if (tiled and ((all(12 <= k <= 32 for k in klist) and not args.gap) or (klist == [12] and args.gap == 2)) and args.s_bits >= 7
                 and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel and not args.teams):
-            kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_f1 / k1h_suspect kernels (K1f, side stream)"
+            kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_fix_kernel / k1h_slow_kernel (K1f: one launch per up to 8 batches)"
         elif tiled and all(12 <= k <= 32 for k in klist) and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
             kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"
         elif (nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255 and not tiled
