@@ -72,3 +72,24 @@ def test_k1h_emulated_spaced_seeds(k, gap, L, s_bits):
     """stRead / NTMSM64 with ntcard's one seed "1" x (k-g)/2 "0" x g "1" x rest (ntcard.cpp:160-171,407-413): two more terms per strand and
     step in the walk, a resolve table without the don't-care positions, a start state without them"""
     run(3000, L, k, 0.004, gap=gap, s_bits=s_bits, r_bits=12)
+
+
+@pytest.mark.parametrize("k", [13, 14, 15, 17, 19, 23, 24, 27, 28, 29, 30])
+def test_k1h_emulated_other_k(k):
+    """the library is built with every k of 12 .. 32 (gen_k1h.VARIANTS): phases (k - 1) mod 16 and table sizes the cases above do not touch"""
+    run(2100, k + 29, k, 0.01, n_waves=2, seed=k)
+
+
+def test_k1h_generator_budgets():
+    """every variant the library is built with fits the machine: 255 VGPRs, SGPRs below the compiler's reserved ones, six wave areas + table
+    + the SIMD numbers inside a CU's 160 KiB of LDS"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ntcard_amd", "csrc"))
+    import gen_k1h
+    assert gen_k1h.S_END <= 100 and gen_k1h.V_CQMASK4 <= 254
+    for k, gap in gen_k1h.VARIANTS:
+        assert gen_k1h.TABLE_OFF + gen_k1h.table_bytes(k) + 32 <= gen_k1h.LDS_BYTES
+        for sb in (7, 8):
+            prog = gen_k1h.Gen(k, sb, gap).build()
+            assert 3500 < prog.n_insts() < 5500
