@@ -284,6 +284,11 @@ struct ntc_engine {
 	} mc;
 	uint64_t merge_allocs = 0; // device allocations + streams + events ntc_merge_devices has created for this engine
 	uint32_t k1h_launch_id = 0;
+	// profiling of the tiled path: ONE pair of events brackets a RUN of hash launches (a pair per launch costs 10 - 20 us of stream bubbles per
+	// launch, measured); the run ends when anything else is about to enter the stream (K1f, an apply, another kind of batch, a sync)
+	hipEvent_t run_ev0 = nullptr;
+	std::vector<uint64_t> pending_runs; // hash submits bracketed by pending[i] when that is more than one (index-aligned with `pending`; 0 = one)
+	uint64_t run_submits = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: deferred K1f launches (outside the hash kernels' events)
 	double k1f_ms = 0.0;
 	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
@@ -338,18 +343,23 @@ struct ntc_engine {
 
 namespace {
 
+int close_run(ntc_engine* e);
+
 int drain_events(ntc_engine* e)
 {
+	if (int rc = close_run(e)) return rc;
 	for (auto& pr : e->pending) {
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(pr.second));
 		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
 		e->ms_total += ms;
-		e->launches += 1;
+		const size_t idx = (size_t)(&pr - e->pending.data());
+		e->launches += idx < e->pending_runs.size() && e->pending_runs[idx] ? e->pending_runs[idx] : 1;
 		(void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
 	e->pending.clear();
+	e->pending_runs.clear();
 	for (auto& pr : e->apply_pending) {
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(pr.second));
@@ -409,6 +419,7 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 int flush_redo(ntc_engine* e)
 {
 	if (!e->redo_pending) return 0;
+	if (int rc = close_run(e)) return rc;
 	e->redo_pending = false;
 	HfPlan hp;
 	if (int rc = hf_plan(e->device, std::max<uint64_t>(e->redo_bound, 64), e->redo_stride, &e->klist[0], 1, 0, hp)) return rc;
@@ -448,8 +459,23 @@ int flush_redo(ntc_engine* e)
 
 // K1f over the K1h launches that still wait for it (asynchronous on the engine's stream).  Before anything reads the counters or F1, touches the
 // sketch without atomics (the apply's sweep does), or hands the batches back to the caller.
+int close_run(ntc_engine* e) // the end of a bracketed run of tiled hash launches (see run_ev0)
+{
+	if (!e->run_ev0) return 0;
+	hipEvent_t ev1 = nullptr;
+	HIP_TRY(hipEventCreate(&ev1));
+	HIP_TRY(hipEventRecord(ev1, e->stream));
+	e->pending_runs.resize(e->pending.size(), 0);
+	e->pending.emplace_back(e->run_ev0, ev1);
+	e->pending_runs.push_back(e->run_submits);
+	e->run_ev0 = nullptr;
+	e->run_submits = 0;
+	return 0;
+}
+
 int join_k1f(ntc_engine* e)
 {
+	if (int rc = close_run(e)) return rc;
 	if (e->k1f_n == 0) return 0;
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
@@ -575,6 +601,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
               uint32_t read_len, uint32_t stride, bool may_defer = false)
 {
 	if (n_slots == 0) return 0;
+	if (int rc = close_run(e)) return rc;
 	unsigned grid = 0;
 	size_t smem = 0;
 	const int kind = e->kernel_kind;
@@ -864,16 +891,19 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 	}
 	if (e->k1f_n + e->klist.size() > ntc::kK1fBatch) // no set left for this batch's K1h launches: K1f over the waiting ones first
 		if (int rc = join_k1f(e)) return rc;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	if (e->profiling) {
-		HIP_TRY(hipEventCreate(&ev0));
-		HIP_TRY(hipEventCreate(&ev1));
-		HIP_TRY(hipEventRecord(ev0, e->stream));
-	}
 	// ntRead's loop over kList (ntcard.cpp:147-158): one launch per k over the same resident batch
+	auto open_run = [&]() -> int { // (again behind a K1f that had to come in the middle of the list)
+		if (e->profiling && !e->run_ev0) {
+			HIP_TRY(hipEventCreate(&e->run_ev0));
+			HIP_TRY(hipEventRecord(e->run_ev0, e->stream));
+		}
+		return 0;
+	};
+	if (e->profiling) ++e->run_submits;
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
 		if (read_len < k) continue; // no window of this k (ntHashIterator.hpp:61-64)
+		if (int rc = open_run()) return rc;
 		if (e->d_k1h_tabs[ki] != nullptr) {
 			// K1h + K1f: one wave per tile; the two bit arrays between them are scratch of this launch pair
 			const uint32_t n_chunks = (read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, read_len);
@@ -965,10 +995,8 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 		const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 1) / 2, (uint64_t)di.cus);
 		HIP_TRY(ntc::launch_sketch_ts(a, grid, e->stream));
 	}
-	if (e->profiling) {
-		HIP_TRY(hipEventRecord(ev1, e->stream));
-		e->pending.emplace_back(ev0, ev1);
-	}
+	if (!e->profiling)
+		if (int rc = close_run(e)) return rc; // (profiling was switched off inside a run)
 	return 0;
 }
 
@@ -1160,6 +1188,7 @@ void ntc_destroy(ntc_engine* e)
 		(void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
+	if (e->run_ev0) (void)hipEventDestroy(e->run_ev0);
 	if (e->own_sketch && e->d_sketch) (void)hipFree(e->d_sketch);
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
