@@ -14,7 +14,7 @@ n, d, f = sys.argv[1:4]
 out = []
 for row in csv.DictReader(open(f)):
     nm = row["Name"]
-    for key in ("sketch_k1h", "k1h_f1", "k1h_fixup", "sketch_ts", "split_kernel", "count_kernel"):
+    for key in ("sketch_k1h", "k1h_fix", "k1h_slow", "sketch_ts", "split_kernel", "count_kernel"):
         if key in nm:
             out.append("%s %.1f us x%s" % (key, float(row["AverageNs"]) / 1000, row["Calls"]))
 print("%-10s dist=%s: %s" % (n, d, ";  ".join(out)))
