@@ -504,8 +504,9 @@ class Gen:
                     x, y = O[kk], O[kk + J]
                     p.i("v_lshlrev_b32", v(B[0]), J, v(y))
                     p.i("v_lshrrev_b32", v(B[1]), J, v(x))
-                    p.i("v_bfi_b32", v(x), v(msk), v(x), v(B[0]))
-                    p.i("v_bfi_b32", v(y), v(msk), v(B[1]), v(y))
+                    # (a bit-select as v_bitop3: two waves of a SIMD overlap those, v_bfi_b32 they take turns for)
+                    self.bitop3(v(x), v(msk), v(x), v(B[0]), lambda m, a, b: (m & a) | ((1 ^ m) & b))
+                    self.bitop3(v(y), v(msk), v(B[1]), v(y), lambda m, a, b: (m & a) | ((1 ^ m) & b))
 
     # ---- the resolve pass (subroutine) ----------------------------------------------------------------------
     def emit_pass(self):
@@ -919,8 +920,8 @@ class Gen:
         p.i("s_cmp_eq_u32", s(S_PREAL), 1)
         p.i("s_cbranch_scc0", "@" + nopk)
         p.i("v_add_u32", v(V_T0), s(S_B0), v(V_LANE4))
-        for mm in range(32):
-            p.i("ds_write_b32", v(V_T0), v(V_H0 + mm), mods=f"offset:{mm * 256}")
+        for mm in range(0, 32, 2):  # (offsets in units of 64 dwords: the slot's [m][lane] rows are 256 bytes apart)
+            p.i("ds_write2st64_b32", v(V_T0), v(V_H0 + mm), v(V_H0 + mm + 1), mods=f"offset0:{mm} offset1:{mm + 1}")
         p.i("s_mul_i32", s(S_A), s(S_PT), s(S_C))
         p.i("s_add_u32", s(S_A), s(S_A), s(S_PN))
         p.i("s_lshl_b32", s(S_A), s(S_A), 8)

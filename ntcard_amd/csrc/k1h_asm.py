@@ -712,6 +712,14 @@ class Emu:
             assert np.all(addr[em] % 4 == 0) and np.all(addr[em] + 4 <= self.lds.size), "ds_write2_b32: bad address"
             self.lds32[addr[em] // 4] = self.rd_v(o[1 + j])[em]
 
+    def op_ds_write2st64_b32(self, pc, o, m):
+        em = self.mask_arr()
+        base = self.rd_v(o[0]).astype(np.int64)
+        for j, key in enumerate(("offset0", "offset1")):
+            addr = base + 256 * m.get(key, 0)
+            assert np.all(addr[em] % 4 == 0) and np.all(addr[em] + 4 <= self.lds.size), "ds_write2st64_b32: bad address"
+            self.lds32[addr[em] // 4] = self.rd_v(o[1 + j])[em]
+
     def op_ds_write_b32(self, pc, o, m):
         em = self.mask_arr()
         addr = self._lds_addr(o[0], m)
