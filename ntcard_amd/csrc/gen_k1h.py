@@ -670,7 +670,7 @@ class Gen:
         p.i("v_add_u32", v(sx + 2), s(S_B), v(sx + 2))
         p.i("v_lshrrev_b32", v(sx + 3), 2, v(col))
         p.i("v_lshl_or_b32", v(sx + 2), v(sx + 2), 11, v(sx + 3))
-        p.i("v_mov_b32", v(sx + 3), 0)
+        p.i("v_and_b32", v(sx + 3), 2, v(sflag))              # 2: the candidate's own pattern fails below the walk's 8-bit prefix (s_bits >= 8) — no hit, whatever its bytes
         p.i("global_store_dwordx4", v(t1), vr(sx, 4), sr(S_SUS, 2))
         p.i("s_nop", 1)                                       # (a 128-bit store reads its data a little after it issues)
         p.label(susfull)                                      # no room: the count runs past the capacity, which K1f reads as "walk everything"

@@ -193,6 +193,7 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 	const uint32_t tid = threadIdx.x;
 	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
 	const uint32_t rmask = (1u << r_bits) - 1u;
+	const uint32_t phi = (k - 1u) & 15u, nb = ((a.read_len - 1u + 16u - phi) >> 4) + 1u; // K1h's blocks: block n = the window ends [16 n - 16 + phi, 16 n + phi)
 	const uint4* const t4v = reinterpret_cast<const uint4*>(item.t4);
 	for (uint32_t hb = bx; hb < 2u * n_sus_waves; hb += nbx) { // half a K1h wave's region per block
 		const uint32_t reg = hb >> 1;
@@ -203,6 +204,25 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 			const uint4 e = *ep;
 			const uint32_t t = e.y, r = e.z & 2047u, w = e.z >> 11;
 			const uint32_t c0 = w >> 4, off = w & 15u;
+			const uint32_t rl = r & 63u, rm = r >> 6; // the read's lane and bit in K1h's bit arrays
+			const uint64_t win = k >= 64u ? ~0ull : (1ull << k) - 1ull;
+			// Fast path: the block has no tie bit, so K1h's verdict on the candidate stands (the strand it resolved IS the canonical one, its
+			// counter index and pattern test are right) provided the window holds no non-base byte — and for that only the DIRTY pieces of the
+			// window need to be looked at (K1h's dirty bits say which: usually one).  A block with a tie bit (about one suspect in a hundred)
+			// takes the full path below: both strands' hashes from the bytes.
+			const uint32_t blk = (w + k - 1u - phi) / 16u + 1u;
+			if (((a.tie[((size_t)t * nb + blk) * 64u + rl] >> rm) & 1u) == 0u) {
+				if (e.w & 2u) continue; // (s_bits >= 8: the pattern fails below the walk's 8-bit prefix)
+				uint64_t inv = 0;
+#pragma unroll
+				for (uint32_t j = 0; j < 3; ++j)
+					if (c0 + j < C && 16u * j < off + k && ((a.dirty[((size_t)t * C + c0 + j) * 64u + rl] >> rm) & 1u))
+						inv |= (uint64_t)tilebits::inv16(raw_piece(a, t, c0 + j, r)) << (16u * j);
+				if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
+				atomicAdd(a.sketch0 + e.x, 1u);
+				ep->w = 1u; // (x already is the counter index)
+				continue;
+			}
 			uint32_t pk[3], bad[3];
 			uint64_t inv = 0;
 #pragma unroll
@@ -214,7 +234,6 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 					if (bad[j]) inv |= (uint64_t)tilebits::inv16(v) << (16u * j); // (rare-ish: the exact positions)
 				}
 			}
-			const uint64_t win = k >= 64u ? ~0ull : (1ull << k) - 1ull;
 			if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
 			const uint32_t lo = tilebits::alignbit(pk[1], pk[0], 2u * off), hi = tilebits::alignbit(pk[2], pk[1], 2u * off);
 			uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;

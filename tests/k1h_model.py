@@ -192,13 +192,20 @@ def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_over
                     if kk is not None:
                         keys.append(kk)
     if sus is not None and not sus_overflow:
-        for _, t, rw, _ in sus:  # (K1f re-derives the hash: the entry's key is K1h's, of the strand the candidate was queued under)
+        for x, t, rw, mark in sus:
             r, w = int(t) * 2048 + (int(rw) & 2047), int(rw) >> 11
             win = reads[r][w: w + k]
             ok, fv, rv = window_hashes(win, k, gap)
             if ok:
                 kk = key_of(min(fv, rv))
                 assert kk is not None or s_bits > 7, (r, w)  # (s_bits >= 8: the walk tests a prefix of the patterns, a suspect may turn out to be none)
+                # K1f's fast path: in a block without a tie bit K1h's own verdict stands — its counter index, and "no hit" (mark 2) where
+                # the pattern fails below the 8-bit prefix; only blocks with a tie bit need the hash again (the entry may be of the wrong strand)
+                tl, lane, m = r // 2048, (r % 2048) % 64, (r % 2048) // 64
+                blk = (w + k - 1 - phi) // 16 + 1
+                if not (int(tie[tl, blk, lane]) >> m) & 1:
+                    assert (int(mark) & 2 != 0) == (kk is None), (r, w, int(mark))
+                    assert kk is None or int(x) == kk, (r, w, int(x), kk)
                 if kk is not None:
                     keys.append(kk)
     return keys, f1_sub
