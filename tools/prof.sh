@@ -9,7 +9,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # PROF_DEFAULT=1: profile exactly the default bench command (what BENCH_rNN.json is measured with)
 if [ "${PROF_DEFAULT:-0}" = 1 ]; then ARGS="--no-cpu-baseline --no-live-pmc $*"; else ARGS="--steps 4 --warmup 1 --reads-per-step 4000000 --no-cpu-baseline --no-live-pmc $*"; fi
-python $ROOT/bench.py $ARGS 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+# PROF_PHASE=bench: only the unprofiled bench line; PROF_PHASE=counters: only the rocprofv3 passes (a bench run right behind PMC passes of
+# another command has measured up to 30 % slow — the clocks stay in the profiling state for a while — so the lines of all tags are taken first)
+if [ "${PROF_PHASE:-all}" != counters ]; then
+  python $ROOT/bench.py $ARGS 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+fi
+if [ "${PROF_PHASE:-all}" = bench ]; then exit 0; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
