@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
@@ -269,7 +270,8 @@ struct ntc_engine {
 	struct K1hSet {
 		uint32_t *d_dirty = nullptr, *d_tie = nullptr;
 		size_t dirty_cap = 0, tie_cap = 0;
-		uint4* d_sus = nullptr;            // kK1hSusCap entries per wave of a launch
+		uint4* d_sus = nullptr;            // sus_cap entries per wave of a launch
+		uint32_t sus_cap = 0;
 		uint32_t *d_sus_count = nullptr, *d_fix_state = nullptr;
 	} k1h_set[ntc::kK1fBatch];
 	ntc::K1fBatch k1f_batch;        // the launches waiting for K1f (k1f_batch.item[i] uses k1h_set[i])
@@ -909,8 +911,23 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 			const uint32_t n_chunks = (read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, read_len);
 			const size_t need_d = (size_t)n_tiles * n_chunks * 256, need_t = (size_t)n_tiles * nb * 256;
 			if (need_d < (1ull << 32) && need_t < (1ull << 32)) {
-				constexpr uint32_t kK1hSusCap = 2048; // suspects per K1h wave (a 10 M-read batch with 0.05 % N leaves ~400); a wave that needs more sends the launch down K1f's slow path
+				// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
+				// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N against 2.4 ms for K1c).  The share: the
+				// blocks a wave alone on its SIMD takes (launch_sketch_k1h / the kernel's prologue: 20 of a workgroup's 104 sixteenths) + 1, all of
+				// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
+				// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
+				// 2 GiB per set (beyond that a launch may still overflow: slow path, exact).
 				const uint32_t max_waves = (uint32_t)di.cus * 6u;
+				const uint64_t total_blocks = (uint64_t)n_tiles * nb;
+				const uint64_t launch_wgs = std::min<uint64_t>((total_blocks + 23) / 24, (uint64_t)di.cus); // (launch_sketch_k1h's grid)
+				const uint64_t quota = ((total_blocks + launch_wgs * 6 - 1) / (launch_wgs * 6)) * 6;        // blocks per workgroup
+				const double lone_blocks = std::ceil((double)quota * 20.0 / 104.0) + 1.0;
+				const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
+				uint32_t sus_cap = (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 31) / 16u / max_waves));
+				if (const char* ev = std::getenv("NTC_K1H_SUS_CAP")) { // tests: a short list forces the overflow path
+					const long v = std::strtol(ev, nullptr, 10);
+					if (v >= 1 && v <= (long)sus_cap) sus_cap = (uint32_t)v;
+				}
 				if (e->k1f_n == ntc::kK1fBatch) // (a k list longer than the sets)
 					if (int rc = join_k1f(e)) return rc;
 				auto& ks = e->k1h_set[e->k1f_n];
@@ -925,9 +942,17 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 					ks.dirty_cap = need_d;
 					ks.tie_cap = need_t;
 				}
-				if (!ks.d_sus) {
-					if (hipMalloc((void**)&ks.d_sus, (size_t)max_waves * kK1hSusCap * 16) != hipSuccess || hipMalloc((void**)&ks.d_sus_count, (size_t)max_waves * 4) != hipSuccess ||
-					    hipMalloc((void**)&ks.d_fix_state, 16) != hipSuccess)
+				if (sus_cap > ks.sus_cap) {
+					HIP_TRY(hipStreamSynchronize(e->stream));
+					if (ks.d_sus) (void)hipFree(ks.d_sus);
+					ks.d_sus = nullptr;
+					ks.sus_cap = 0;
+					if (hipMalloc((void**)&ks.d_sus, (size_t)max_waves * sus_cap * 16) != hipSuccess)
+						return fail(NTC_ERR_MEMORY, "cannot allocate the %zu-byte suspect list of the tiled kernel on device", (size_t)max_waves * sus_cap * 16);
+					ks.sus_cap = sus_cap;
+				}
+				if (!ks.d_sus_count) {
+					if (hipMalloc((void**)&ks.d_sus_count, (size_t)max_waves * 4) != hipSuccess || hipMalloc((void**)&ks.d_fix_state, 16) != hipSuccess)
 						return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
 					HIP_TRY(hipMemsetAsync(ks.d_fix_state, 0, 16, e->stream));
 					HIP_TRY(hipMemsetAsync(ks.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
@@ -936,7 +961,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				std::memset(&h, 0, sizeof h);
 				h.sus = ks.d_sus;
 				h.sus_count = ks.d_sus_count;
-				h.sus_cap = kK1hSusCap;
+				h.sus_cap = sus_cap; // (<= the allocation's)
 				h.launch_id = ++e->k1h_launch_id;
 				if (h.launch_id == 0) h.launch_id = ++e->k1h_launch_id;
 				h.fix_state = ks.d_fix_state;

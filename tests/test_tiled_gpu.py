@@ -276,13 +276,19 @@ def test_tiled_reference_table_slot_bytes_and_suspect_overflow(nt):
         check(nt, [arr[i].tobytes() for i in range(n)], L)
     dense = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(400_000, 64))].astype(np.uint8)
     t = torch.from_numpy(tile_array(dense)).cuda()
-    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
-        e.submit_tiled_device(t.data_ptr(), dense.shape[0], 64)
-        tc, ph, f1 = e.finish(counters=True)
     counters = np.zeros((1, 2, 1 << 20), dtype=np.uint16)
     offs = np.arange(dense.shape[0] + 1, dtype=np.uint64) * np.uint64(64)
     of1 = orc.sketch_update(counters, np.ascontiguousarray(dense).reshape(-1), offs, [32], 0, 20, 7)
-    assert np.array_equal(f1, of1) and np.array_equal(tc, counters)
+    for cap in ("", "64"):  # the engine's own list (sized for every candidate: fast path), then a short one: the launch overflows -> slow path
+        if cap:
+            os.environ["NTC_K1H_SUS_CAP"] = cap
+        try:
+            with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
+                e.submit_tiled_device(t.data_ptr(), dense.shape[0], 64)
+                tc, ph, f1 = e.finish(counters=True)
+        finally:
+            os.environ.pop("NTC_K1H_SUS_CAP", None)
+        assert np.array_equal(f1, of1) and np.array_equal(tc, counters), cap
 
 
 @pytest.mark.parametrize("n,L,p_bad,s_bits", [(6000, 150, 0.003, 7), (2049, 12, 0.01, 7), (3000, 13, 0.0, 8), (70000, 100, 0.001, 11), (400_000, 64, 0.2, 7)])
