@@ -930,48 +930,59 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				}
 				if (e->k1f_n == ntc::kK1fBatch) // (a k list longer than the sets)
 					if (int rc = join_k1f(e)) return rc;
+				// the hand-over arrays of one set; an engine that defers K1f sizes ALL its sets at the first launch of a batch geometry (a set that grows
+				// later would stall the stream in the middle of a run)
+				auto ensure_set = [&](ntc_engine::K1hSet& s2) -> int {
+					if (need_d > s2.dirty_cap || need_t > s2.tie_cap || sus_cap > s2.sus_cap) HIP_TRY(hipStreamSynchronize(e->stream));
+					if (need_d > s2.dirty_cap || need_t > s2.tie_cap) {
+						if (s2.d_dirty) (void)hipFree(s2.d_dirty);
+						if (s2.d_tie) (void)hipFree(s2.d_tie);
+						s2.d_dirty = s2.d_tie = nullptr;
+						s2.dirty_cap = s2.tie_cap = 0;
+						if (hipMalloc((void**)&s2.d_dirty, need_d) != hipSuccess || hipMalloc((void**)&s2.d_tie, need_t) != hipSuccess)
+							return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
+						s2.dirty_cap = need_d;
+						s2.tie_cap = need_t;
+					}
+					if (sus_cap > s2.sus_cap) {
+						if (s2.d_sus) (void)hipFree(s2.d_sus);
+						s2.d_sus = nullptr;
+						s2.sus_cap = 0;
+						if (hipMalloc((void**)&s2.d_sus, (size_t)max_waves * sus_cap * 16) != hipSuccess)
+							return fail(NTC_ERR_MEMORY, "cannot allocate the %zu-byte suspect list of the tiled kernel on device", (size_t)max_waves * sus_cap * 16);
+						s2.sus_cap = sus_cap;
+					}
+					if (!s2.d_sus_count) {
+						if (hipMalloc((void**)&s2.d_sus_count, (size_t)max_waves * 4) != hipSuccess || hipMalloc((void**)&s2.d_fix_state, 16) != hipSuccess)
+							return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
+						HIP_TRY(hipMemsetAsync(s2.d_fix_state, 0, 16, e->stream));
+						HIP_TRY(hipMemsetAsync(s2.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
+					}
+					return 0;
+				};
 				auto& ks = e->k1h_set[e->k1f_n];
-				if (need_d > ks.dirty_cap || need_t > ks.tie_cap) {
-					HIP_TRY(hipStreamSynchronize(e->stream));
-					if (ks.d_dirty) (void)hipFree(ks.d_dirty);
-					if (ks.d_tie) (void)hipFree(ks.d_tie);
-					ks.d_dirty = ks.d_tie = nullptr;
-					ks.dirty_cap = ks.tie_cap = 0;
-					if (hipMalloc((void**)&ks.d_dirty, need_d) != hipSuccess || hipMalloc((void**)&ks.d_tie, need_t) != hipSuccess)
-						return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
-					ks.dirty_cap = need_d;
-					ks.tie_cap = need_t;
+				if (need_d > ks.dirty_cap || need_t > ks.tie_cap || sus_cap > ks.sus_cap || !ks.d_sus_count) {
+					if (e->k1f_n != 0) // the sets ahead are in use by launches whose K1f is still to come
+						if (int rc = join_k1f(e)) return rc;
+					for (uint32_t si = 0; si < (e->defer_redo ? ntc::kK1fBatch : 1u); ++si)
+						if (int rc = ensure_set(e->k1h_set[si])) return rc;
 				}
-				if (sus_cap > ks.sus_cap) {
-					HIP_TRY(hipStreamSynchronize(e->stream));
-					if (ks.d_sus) (void)hipFree(ks.d_sus);
-					ks.d_sus = nullptr;
-					ks.sus_cap = 0;
-					if (hipMalloc((void**)&ks.d_sus, (size_t)max_waves * sus_cap * 16) != hipSuccess)
-						return fail(NTC_ERR_MEMORY, "cannot allocate the %zu-byte suspect list of the tiled kernel on device", (size_t)max_waves * sus_cap * 16);
-					ks.sus_cap = sus_cap;
-				}
-				if (!ks.d_sus_count) {
-					if (hipMalloc((void**)&ks.d_sus_count, (size_t)max_waves * 4) != hipSuccess || hipMalloc((void**)&ks.d_fix_state, 16) != hipSuccess)
-						return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
-					HIP_TRY(hipMemsetAsync(ks.d_fix_state, 0, 16, e->stream));
-					HIP_TRY(hipMemsetAsync(ks.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
-				}
+				auto& ks0 = e->k1h_set[e->k1f_n]; // (k1f_n may be 0 now)
 				ntc::K1hArgs h;
 				std::memset(&h, 0, sizeof h);
-				h.sus = ks.d_sus;
-				h.sus_count = ks.d_sus_count;
+				h.sus = ks0.d_sus;
+				h.sus_count = ks0.d_sus_count;
 				h.sus_cap = sus_cap; // (<= the allocation's)
 				h.launch_id = ++e->k1h_launch_id;
 				if (h.launch_id == 0) h.launch_id = ++e->k1h_launch_id;
-				h.fix_state = ks.d_fix_state;
+				h.fix_state = ks0.d_fix_state;
 				h.tiles = d_tiles;
 				h.log = e->d_log;
 				h.log_fill = e->d_logfill;
 				h.sketch0 = e->d_sketch;
 				h.f1 = e->d_f1 + ki;
-				h.dirty = ks.d_dirty;
-				h.tie = ks.d_tie;
+				h.dirty = ks0.d_dirty;
+				h.tie = ks0.d_tie;
 				h.n_tiles = (uint32_t)n_tiles;
 				h.n_chunks = n_chunks;
 				h.read_len = read_len;
@@ -985,6 +996,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				h.r_bits = e->r_bits;
 				ntc::K1hArgs launched;
 				uint32_t n_waves = 0;
+				if (int rc = open_run()) return rc; // (a K1f above may have closed the bracket)
 				HIP_TRY(ntc::launch_sketch_k1h(h, k, e->gap, (unsigned)di.cus, e->stream, &launched, &n_waves));
 				auto& it = e->k1f_batch.item[e->k1f_n++];
 				it.a = launched;
