@@ -919,7 +919,8 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				// 2 GiB per set (beyond that a launch may still overflow: slow path, exact).
 				const uint32_t max_waves = (uint32_t)di.cus * 6u;
 				const uint64_t total_blocks = (uint64_t)n_tiles * nb;
-				const uint64_t launch_wgs = std::min<uint64_t>((total_blocks + 23) / 24, (uint64_t)di.cus); // (launch_sketch_k1h's grid)
+				const uint64_t per_wg = 6ull * ntc::sketch_k1h_min_blocks();
+				const uint64_t launch_wgs = std::min<uint64_t>((total_blocks + per_wg - 1) / per_wg, (uint64_t)di.cus); // (launch_sketch_k1h's grid)
 				const uint64_t quota = ((total_blocks + launch_wgs * 6 - 1) / (launch_wgs * 6)) * 6;        // blocks per workgroup
 				const double lone_blocks = std::ceil((double)quota * 20.0 / 104.0) + 1.0;
 				const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;

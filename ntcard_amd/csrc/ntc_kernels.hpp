@@ -148,6 +148,7 @@ struct K1hArgs {
 };
 bool sketch_k1h_supports(uint32_t k, uint32_t gap, uint32_t s_bits, uint32_t r_bits);
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len);
+uint32_t sketch_k1h_min_blocks(); // blocks per wave below which launch_sketch_k1h uses fewer workgroups
 void build_k1h_table(uint32_t k, uint32_t gap, uint32_t r_bits, uint32_t s_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
 hipError_t set_sketch_k1h_smem_limit();
 hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves);

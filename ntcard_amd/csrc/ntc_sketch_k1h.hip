@@ -35,6 +35,7 @@ namespace {
 constexpr uint32_t kK1hWaves = K1H_GEN_WAVES;
 constexpr uint32_t kK1hWArea = K1H_GEN_WAREA;
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
+constexpr uint32_t kK1hMinBlocks = 2;
 constexpr uint32_t k1h_table_bytes(uint32_t k) { return 2u * ((k + 2u) / 3u) * 256u; }
 constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k) + 32u; } // the wave areas, the table, the waves' SIMD numbers (ntc_sketch_k1h_body.hip)
 
@@ -519,13 +520,18 @@ static uint32_t k1h_lone_weight()
 	return w;
 }
 
+// Blocks a wave should have at least: a wave that starts inside a tile walks two masked blocks first (~1.2 blocks' worth of instructions), so a
+// small batch is better off with fewer, longer shares — down to this many (measured, ms per step at 0.5 / 1 / 2 M reads of 150 bp: at least
+// 4 blocks 0.126 / 0.141 / 0.199, at least 2 blocks 0.100 / 0.142 / 0.196: profiles/r04_batch_size_sweep.txt)
+uint32_t sketch_k1h_min_blocks() { return kK1hMinBlocks; }
+
 // K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
 hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
 {
 	if (!sketch_k1h_supports(k, gap, a.s_bits, a.r_bits)) return hipErrorInvalidValue;
 	const uint32_t nb = sketch_k1h_blocks(k, a.read_len);
 	const uint64_t total = (uint64_t)a.n_tiles * nb; // blocks of the batch, shared out evenly: a wave needs at least ~4 blocks to be worth its start-up
-	const unsigned grid = (unsigned)std::min<uint64_t>((total + 4 * kK1hWaves - 1) / (4 * kK1hWaves), cus);
+	const unsigned grid = (unsigned)std::min<uint64_t>((total + kK1hMinBlocks * kK1hWaves - 1) / (kK1hMinBlocks * kK1hWaves), cus);
 	K1hArgs b = a;
 	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
 	b.nb_magic = (uint32_t)((1ull << 32) / nb);
