@@ -154,6 +154,8 @@ class Gen:
         if gap:
             self.fg_terms = [(tt4(jj - (k - self.g0)), tt4(jj - (k - 1 - self.g1))) for jj in range(31)]
             self.rg_terms = [(tt4(jj + 1 - self.g0, True), tt4(jj - self.g1, True)) for jj in range(31)]
+        self.cold = []                      # out-of-line fragments (emitted behind the chunk loop): the common path of a test falls through —
+                                            # a taken branch costs a lone wave an instruction-buffer refill
         self.exp = set(x for x in os.environ.get("K1H_EXP", "").split(",") if x)  # timing experiments (tools/k1h_variant.sh): WRONG results
 
     def lbl(self, base):
@@ -388,9 +390,14 @@ class Gen:
         p.i("s_lshr_b32", s(S_N), s(S_N), 2)
         p.i("s_add_u32", s(S_N), s(S_N), s(S_A))
         p.i("s_cmp_le_u32", s(S_N), QCAP)
-        p.i("s_cbranch_scc1", "@" + go)
-        self.call("pass")                                        # (keeps V_T .. V_T + 7: the four hit words)
-        p.i("s_branch", "@" + chk)
+        full = self.lbl("qfull")
+        p.i("s_cbranch_scc0", "@" + full)                        # (rare: about one step in three runs a pass first)
+
+        def cold_pass(full=full, chk=chk):
+            p.label(full)
+            self.call("pass")                                    # (keeps V_T .. V_T + 7: the four hit words)
+            p.i("s_branch", "@" + chk)
+        self.cold.append(cold_pass)
         p.label(go)
         meta = ((2 * a) << 9) | (suspect << 15)
         p.i("v_mbcnt_lo_u32_b32", v(T + 1), "vcc_lo", 0)
@@ -462,13 +469,18 @@ class Gen:
             p.i("s_mov_b32", s(S_A), s(S_CC))
         p.i("s_add_u32", s(S_B), s(S_A), 4096)
         p.i("s_cmp_eq_u32", s(S_PREAL), 1)
-        p.i("s_cbranch_scc1", "@" + real)
-        for i in range(8):  # a chunk that does not exist: 'A's
-            p.i("v_mov_b32", v(V_H0 + 8 * b + i), 0)
-        if b == 3 and "noload" not in self.exp:          # the next chunk's first loads all the same
-            for i in range(8):
-                p.i("buffer_load_dwordx4", vr(V_RAW + 4 * i, 4), v(V_LANE16), sr(S_DESC, 4), s(S_A if i < 4 else S_B), mods=f"offen offset:{(i & 3) * 1024} nt")
-        p.i("s_branch", "@" + skip)
+        notreal = self.lbl("pk_none")
+        p.i("s_cbranch_scc0", "@" + notreal)
+
+        def cold_none(notreal=notreal, skip=skip, b=b):
+            p.label(notreal)
+            for i in range(8):  # a chunk that does not exist: 'A's
+                p.i("v_mov_b32", v(V_H0 + 8 * b + i), 0)
+            if b == 3 and "noload" not in self.exp:          # the next chunk's first loads all the same
+                for i in range(8):
+                    p.i("buffer_load_dwordx4", vr(V_RAW + 4 * i, 4), v(V_LANE16), sr(S_DESC, 4), s(S_A if i < 4 else S_B), mods=f"offen offset:{(i & 3) * 1024} nt")
+            p.i("s_branch", "@" + skip)
+        self.cold.append(cold_none)
         p.label(real)
         p.i("s_waitcnt", "vmcnt(0)")
         if "nopack" in self.exp:
@@ -1022,6 +1034,9 @@ class Gen:
             p.i("s_addc_u32", s(S_F1ACC + 1), s(S_F1ACC + 1), 0)
         self.probe(3)
         p.i("s_branch", "@iter")
+        for frag in self.cold:                                   # out-of-line: the rare sides of the loop's tests
+            frag()
+        self.cold = []
 
         # ================================ epilogue ================================
         p.label("done")
