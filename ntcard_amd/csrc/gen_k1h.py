@@ -482,10 +482,15 @@ class Gen:
             p.i("s_branch", "@" + skip)
         self.cold.append(cold_none)
         p.label(real)
-        p.i("s_waitcnt", "vmcnt(0)")
+        # Eight loads are in flight, issued in slot order, and loads return in order: when at most four vector-memory operations are outstanding
+        # the first four slots have arrived — and again, behind their four reloads, the other four.  vmcnt(0) would also wait for every STORE a
+        # resolve pass has just issued (hit log, suspects: stores count in vmcnt on gfx9 and take a microsecond to be acknowledged).
+        p.i("s_waitcnt", "vmcnt(4)")
         if "nopack" in self.exp:
             p.i("s_branch", "@" + skip)
         for i in range(8):
+            if i == 4:
+                p.i("s_waitcnt", "vmcnt(4)")
             self.pack_group(i, V_H0 + 8 * b + i, (S_A if i < 4 else S_B, (i & 3) * 1024))
         p.label(skip)
         self.probe(1)
