@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 (default) 100 M reads k=32 sBits=7; 3: 1 B reads in total, sBits=11, read-index ranges split "
                          "over the ranks (strong scaling); 4: k=32,64,96,128 in one run; 5: spaced seed k=12 g=2")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region (K steps + flush + merge) is run this many times in-process; ms_per_step / value "
+                                                            "are the MEDIAN repeat's, ms_per_step_min / _max give the spread (the clocks differ from lease to lease and ramp)")
+    ap.add_argument("--no-nodefer", action="store_true", help="skip the extra run without NTC_FLAG_DEFER_REDO (\"roofline_nodefer\": the default buffer contract of ntc_submit*_device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run this command under rocprofv3 --pmc for roofline.traffic / valu "
                                                                "(the committed table profiles/traffic_pmc.json is looked up instead)")
@@ -200,6 +203,23 @@ def pmc_traffic(args, reads_per_launch):
         return None
 
 
+def read_sclk_mhz(device_index=0):
+    """current shader clock of the device as rocm-smi reports it (MHz), or None; a reading taken right after a timed region shows what the
+    run was clocked at a moment earlier — the lease-to-lease spread of the headline is mostly this number"""
+    import re
+    import shutil
+    import subprocess
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.access(smi, os.X_OK):
+        return None
+    try:
+        r = subprocess.run([smi, "-d", str(device_index), "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz", r.stdout.decode(errors="replace"), re.I)
+        return int(m.group(1)) if m else None
+    except Exception:
+        return None
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: become `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N ... bench.py <same flags>` (one rank per GPU over RCCL).  Fails loudly when the node has fewer GPUs."""
@@ -300,18 +320,20 @@ def main():
     f1_dev = f1_big[:nk]
     # the resident batches stay untouched until the end of the run: the engine may share its second passes (K1f behind K1h; the reads K1b
     # hands back) between batches (NTC_FLAG_DEFER_REDO)
-    eng = nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream, ext_sketch=sketch, ext_f1=f1_dev,
-                    log_entries=args.log_entries,
-                    flags=(nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
-                    | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0) | (nt.FLAG_TILED_TEAMS if args.teams else 0)
-                    | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0)
-                    | nt.FLAG_DEFER_REDO)  # (tiled batches too: the fix-up kernels K1f then take up to 8 batches per launch)
+    base_flags = ((nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
+                  | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0) | (nt.FLAG_TILED_TEAMS if args.teams else 0)
+                  | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0))
 
-    def submit(buf):
+    def make_engine(flags):
+        return nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream, ext_sketch=sketch, ext_f1=f1_dev,
+                         log_entries=args.log_entries, flags=flags)
+    eng = make_engine(base_flags | nt.FLAG_DEFER_REDO)  # (tiled batches too: the fix-up kernels K1f then take up to 8 batches per launch)
+
+    def submit_to(e, buf):
         if tiled:
-            eng.submit_tiled_device(buf.data_ptr(), R, L)
+            e.submit_tiled_device(buf.data_ptr(), R, L)
         else:
-            eng.submit_device(buf.data_ptr(), R, L, stride)
+            e.submit_device(buf.data_ptr(), R, L, stride)
 
     def barrier():
         torch.cuda.synchronize()
@@ -319,41 +341,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(W):
-        submit(wb)
-    if W > 0:
-        eng.flush()  # warm the deferred sketch update too (allocates its partition scratch)
-    if use_dist and W > 0:  # warm the RCCL path too (same collectives as the timed merge)
-        parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits,
-                                           lambda c, h: nt.value_hist_device(c.data_ptr(), c.numel(), h.data_ptr(), device=local_rank, stream=stream), dst=0)
-    eng.sync()
-    eng.reset()
-    eng.set_profiling(True)
+    def value_hist(counters, hist):
+        nt.value_hist_device(counters.data_ptr(), counters.numel(), hist.data_ptr(), device=local_rank, stream=stream)
 
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(K):
-        submit(batches[s % nb])
-    eng.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter
-    ph_merged = None
-    if use_dist:
-        # the path's one exchange step: all-to-all of the 16-bit counter slices, wrapping local sums, per-rank value
-        # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms
-        def value_hist(counters, hist):
-            nt.value_hist_device(counters.data_ptr(), counters.numel(), hist.data_ptr(), device=local_rank, stream=stream)
-        merge_t = {}
-        ph_merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0, timings=merge_t)
-    barrier()
-    dt = time.perf_counter() - t0
+    def warm(e):
+        for _ in range(W):
+            submit_to(e, wb)
+        if W > 0:
+            e.flush()  # warm the deferred sketch update too (allocates its partition scratch)
+        if use_dist and W > 0:  # warm the RCCL path too (same collectives as the timed merge)
+            parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0)
+        e.sync()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    def timed_region(e):
+        """EXACTLY K steps + the flush (+ the multi-GPU merge), bracketed by barrier + synchronize on both sides; max over ranks"""
+        e.reset()
+        e.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(K):
+            submit_to(e, batches[s % nb])
+        e.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter
+        merged, merge_t = None, {}
+        if use_dist:
+            # the path's one exchange step: all-to-all of the 16-bit counter slices, wrapping local sums, per-rank value
+            # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms
+            merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0, timings=merge_t)
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ker, launches = e.kernel_time()
+        app, applies = e.apply_time()
+        return {"dt": float(tmax.item()), "ker_ms": ker, "launches": launches, "apply_ms": app, "applies": applies, "fix_ms": e.fixup_time(),
+                "merged": merged, "merge_t": merge_t}
 
-    ker_ms, launches = eng.kernel_time()
-    apply_ms, applies = eng.apply_time()
-    fix_ms = eng.fixup_time()
+    sclk_before = read_sclk_mhz(local_rank) if rank == 0 else None
+    warm(eng)
+    n_rep = max(1, args.repeats)
+    runs = [timed_region(eng) for _ in range(n_rep)]
+    sclk_after = read_sclk_mhz(local_rank) if rank == 0 else None
+    order = sorted(range(n_rep), key=lambda i: runs[i]["dt"])
+    med = runs[order[(n_rep - 1) // 2]]  # the median repeat (the lower one of an even count): every per-step figure below is THIS repeat's
+    dt_max = med["dt"]
+    ker_ms, launches, apply_ms, applies, fix_ms, merge_t = med["ker_ms"], med["launches"], med["apply_ms"], med["applies"], med["fix_ms"], med["merge_t"]
+    ph_merged = runs[-1]["merged"]  # (the counters on the device are the last repeat's; every repeat counts the same reads)
     update_mode = eng.update_mode()
     if ph_merged is not None:
         eng.sync()
@@ -402,6 +435,12 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": dt_max * 1e3 / K,
+            # the timed region was run `repeats` times in this process: every figure of this line is the MEDIAN repeat's; min / max / all give the spread
+            "repeats": n_rep,
+            "ms_per_step_min": runs[order[0]]["dt"] * 1e3 / K,
+            "ms_per_step_max": runs[order[-1]]["dt"] * 1e3 / K,
+            "ms_per_step_all": [r["dt"] * 1e3 / K for r in runs],
+            "sclk_mhz": {"before": sclk_before, "after": sclk_after, "source": "rocm-smi --showclocks (current sclk level), read before the warm-up and right behind the last repeat"},
             "higher_is_better": True,
             "scaling": "strong" if strong_total is not None else "weak",
             "vs_baseline": None,
@@ -443,11 +482,26 @@ def main():
         # roofline.traffic / valu: measured live (this command again under rocprofv3 --pmc, one counter per pass) at N = 1;
         # the committed table of the same passes (profiles/traffic_pmc.json, tools/prof.sh) is the fallback
         out["roofline"]["traffic_source"] = "profiles/traffic_pmc.json" if out["roofline"]["traffic"] is not None else None
+        # the same workload with the DEFAULT buffer contract of ntc_submit*_device (no NTC_FLAG_DEFER_REDO: the fix-up kernels follow every
+        # launch in stream order, the caller may refill a buffer as soon as its own stream-ordered work allows)
+        if world == 1 and not use_dist and not args.no_nodefer:
+            eng.close()
+            e2 = make_engine(base_flags)
+            warm(e2)
+            r2 = [timed_region(e2) for _ in range(min(3, n_rep))]
+            m2 = sorted(r2, key=lambda r: r["dt"])[(len(r2) - 1) // 2]
+            step2 = (m2["ker_ms"] + m2["apply_ms"] + m2["fix_ms"]) / max(K, 1)
+            ach2 = alg_bytes / (step2 * 1e-3) / 1e9 if step2 > 0 else 0.0
+            out["roofline_nodefer"] = {"achieved": ach2, "frac": ach2 / HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": m2["dt"] * 1e3 / K, "value": total_kmers / m2["dt"],
+                                       "avg_launch_ms": step2, "hash_ms": m2["ker_ms"] / max(K, 1), "apply_ms": m2["apply_ms"] / max(K, 1),
+                                       "fixup_ms": m2["fix_ms"] / max(K, 1), "repeats": len(r2),
+                                       "note": "engine without NTC_FLAG_DEFER_REDO: one K1f launch behind every K1h launch, in stream order (fixup_ms), instead of one per 8 batches"}
+            e2.close()
         if world == 1 and not use_dist and not args.no_live_pmc and not under_profiler():
             eng.close()
             del batches, wb
             torch.cuda.empty_cache()
-            inner = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline", "--no-live-pmc")] + ["--no-cpu-baseline", "--no-live-pmc"]
+            inner = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline", "--no-live-pmc", "--no-nodefer")] + ["--no-cpu-baseline", "--no-live-pmc", "--no-nodefer", "--repeats", "1"]
             live = live_pmc(inner, K + W)
             if live is not None:
                 # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KB; wide streaming reads are

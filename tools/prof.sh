@@ -15,6 +15,8 @@ if [ "${PROF_PHASE:-all}" != counters ]; then
   python $ROOT/bench.py $ARGS 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 fi
 if [ "${PROF_PHASE:-all}" = bench ]; then exit 0; fi
+# under the profiler: ONE timed region and no second engine, so that dispatches / (steps + warmup) is the per-step figure
+ARGS="$ARGS --repeats 1 --no-nodefer"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
