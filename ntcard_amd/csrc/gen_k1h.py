@@ -38,12 +38,14 @@ import sys
 from gen_bs import step_terms, ttbl, g_of, hseed, rol31, tt4, COMP, CODE2  # noqa: F401
 from k1h_asm import Prog, v, s, vr, sr, schedule
 
-WAVES = 6                    # waves per workgroup = tiles in flight per CU
-RING_BYTES = 3 * 8192        # three packed chunks
-QCAP = 128                   # queue items: three dwords each, kept as three arrays (hit word, meta, reverse-strand mask) of QCAP dwords + one
+WAVES = 8                    # waves per workgroup = tiles in flight per CU: two per SIMD (round 5; six in round 4, when a wave's ring was three whole chunks)
+QSLOT = 2048                 # one QUARTER of a packed chunk: 4 bases x 2048 reads = [8 rows][64 lanes] dwords, byte t of row i = the read 64 (i + 8 t) + lane
+RQ_MAX = 9                   # quarter-slots of the ring: 4 j + 5 are in use, j = (k - 1) div 16 (what 4 windows span, see quarter_enter)
+RING_BYTES = RQ_MAX * QSLOT  # 18 KiB (round 4: three packed chunks, 24 KiB)
+QCAP = 64                    # queue items: three dwords each, kept as three arrays (hit word, meta, reverse-strand mask) of QCAP dwords + one
 QSTRIDE = QCAP + 1           # dummy slot: a lane with nothing to queue writes there, so the writes need no exec mask (an exec write costs ~2 issue slots)
-WAREA = RING_BYTES + QSTRIDE * 12  # 26124 bytes per wave
-TABLE_OFF = WAVES * WAREA    # 156672: [2 strands][NG][64] dwords
+WAREA = (RING_BYTES + QSTRIDE * 12 + 15) // 16 * 16  # 19216 bytes per wave
+TABLE_OFF = WAVES * WAREA    # 153728: [2 strands][NG][64] dwords
 LDS_BYTES = 160 * 1024
 
 
@@ -71,22 +73,23 @@ V_PX = V_T         # forward candidate item (x, y)
 V_RX = V_T + 2     # reverse candidate item
 V_SXF = V_T + 4    # the same for suspects
 V_SXR = V_T + 6
+V_TIEW = V_T + 1   # windows of the step whose strands tie on the top bits
 V_T0 = V_T + 4     # scratch of the walk / test / pack: V_T0 .. V_T0 + 29 (the suspect pairs are written behind the test, whose scratch they share)
 V_TP = V_T + 8     # scratch of the resolve pass: V_TP .. V_TP + 25; the transpose uses V_T .. V_T + 31
 # constants that VOP3 instructions cannot take as literals (gfx9: one SGPR or inline constant per instruction, no 32-bit literal)
-V_CMUL, V_CPERMLO, V_CPERMHI, V_CP16A, V_CP16B, V_CP8A, V_CP8B, V_CM4, V_CM2, V_CM1, V_CQMASK4 = [V_T0 + 30 + i for i in range(11)]
-assert V_CQMASK4 <= 254
+V_CMUL, V_CPERMLO, V_CPERMHI, V_CP16A, V_CP16B, V_CP8A, V_CP8B, V_CM4, V_CM2, V_CM1, V_CQMASK4, V_CBYTE = [V_T0 + 30 + i for i in range(12)]
+assert V_CBYTE <= 254
 VCONST = ((V_CMUL, 0x00820820), (V_CPERMLO, 0x0c0c0703), (V_CPERMHI, 0x07030c0c), (V_CP16A, 0x05040100), (V_CP16B, 0x07060302),
-          (V_CP8A, 0x06020400), (V_CP8B, 0x07030501), (V_CM4, 0x0f0f0f0f), (V_CM2, 0x33333333), (V_CM1, 0x55555555), (V_CQMASK4, (QCAP - 1) * 4))
+          (V_CP8A, 0x06020400), (V_CP8B, 0x07030501), (V_CM4, 0x0f0f0f0f), (V_CM2, 0x33333333), (V_CM1, 0x55555555), (V_CQMASK4, (QCAP - 1) * 4), (V_CBYTE, 0x703))
 N_VGPRS = 255
 
 # SGPRs: s0 .. S_BASE - 1 are left to the compiler (the asm statement's few inputs live there)
-S_BASE = 34
+S_BASE = 26
 _sn = [S_BASE]
 
 
 def _salloc(n=1, align=1):
-    while _sn[0] % align:
+    while _sn[0] % align or (_sn[0] < 34 and _sn[0] + n > 32):  # s32 / s33 are the ABI's stack and frame pointer: reserved even in a kernel without a stack
         _sn[0] += 1
     r = _sn[0]
     _sn[0] += n
@@ -118,7 +121,7 @@ S_PT, S_PN, S_PREAL = _salloc(), _salloc(), _salloc()  # chunk being packed
 S_QT, S_QN, S_QREAL = _salloc(), _salloc(), _salloc()  # chunk being loaded next
 S_PSOFF, S_QSOFF = _salloc(), _salloc()
 S_STEPMASK = _salloc()
-S_B0, S_B1, S_B2 = _salloc(), _salloc(), _salloc()
+S_RQ = [_salloc() for _ in range(RQ_MAX)]  # LDS addresses of the ring's quarter-slots in window order: S_RQ[i] holds byte i of the oldest window still to be resolved
 S_QHEAD4, S_QTAIL4 = _salloc(), _salloc()
 S_N, S_A, S_B, S_CC = _salloc(), _salloc(), _salloc(), _salloc()  # scalar scratch
 S_SPARE = _salloc()
@@ -145,6 +148,9 @@ class Gen:
         self.phi = (k - 1) % 16
         self.j = (k - 1) // 16      # window start chunk = n - 1 - j
         self.ng = n_groups(k)
+        self.rq = 4 * self.j + 5    # quarter-slots of the ring in use: the 4 windows of a quarter start in one quarter of chunk n - 1 - j and end in chunk n
+        self.nby = (k + 6) // 4     # bytes (quarters) of the ring a window can touch: k bases from base 0 .. 3 of its first quarter
+        assert self.nby <= self.rq <= RQ_MAX
         self.p = Prog()
         self.uid = 0
         self.f_terms, self.r_terms = step_terms(k)
@@ -359,24 +365,37 @@ class Gen:
         sus = "timers" not in self.exp
         if sus:
             # suspects: candidates of reads with a dirty piece near by — resolved like the others, then parked for K1f, which knows the bytes
-            # ... and windows whose strands tie on the top bits: they ride along in the forward word (K1f re-derives every suspect's hash from
-            # the bytes, so the strand it is queued under does not matter)
-            p.i("v_and_b32", v(tie), v(tie), v(V_VMASK))
-            self.bitop3(v(V_SXF), v(cf), v(V_DMASK), v(tie), lambda x, y, z: (x & y) | z)
+            # ... and windows whose strands tie on the top bits: items of their own, marked as ties (K1f re-derives a tie's hash from the bytes, so
+            # the strand it is queued under does not matter; every other suspect keeps K1h's verdict and only has its dirty pieces looked at)
+            p.i("v_and_b32", v(V_TIEW), v(tie), v(V_VMASK))   # (kept in a register a resolve pass does not touch)
+            self.bitop3(v(V_SXF), v(cf), v(V_DMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
             self.bitop3(v(V_SXR), v(cr), v(V_DMASK), v(tie), lambda x, y, z: x & y & (1 ^ z))
-            p.i("v_or_b32", v(V_TACC), v(V_TACC), v(tie))  # (the tie array serves K1f's slow path only)
+            p.i("v_or_b32", v(V_TACC), v(V_TACC), v(V_TIEW))  # (the tie array serves K1f's slow path only)
         else:
             self.bitop3(v(V_TACC), v(V_TACC), v(tie), v(V_CMASK), lambda x, y, z: x | (y & z))
         self.push_items(a, V_PX, V_RX, 0)
         if sus:
-            nosus = self.lbl("nosus")
+            nosus, notdirty = self.lbl("nosus"), self.lbl("notdirty")
+            p.i("v_or3_b32", v(T + 4), v(V_SXF), v(V_SXR), v(V_TIEW))
+            p.i("v_cmp_ne_u32_e32", "vcc", 0, v(T + 4))
+            p.i("s_cbranch_vccz", "@" + nosus)                 # (the common case: no suspect in this step)
             p.i("v_or_b32", v(T + 4), v(V_SXF), v(V_SXR))
             p.i("v_cmp_ne_u32_e32", "vcc", 0, v(T + 4))
-            p.i("s_cbranch_vccz", "@" + nosus)
+            p.i("s_cbranch_vccz", "@" + notdirty)
             self.push_items(a, V_SXF, V_SXR, 1)
+            p.label(notdirty)
+            p.i("v_cmp_ne_u32_e32", "vcc", 0, v(V_TIEW))
+            tiep = self.lbl("tiepush")
+            p.i("s_cbranch_vccnz", "@" + tiep)                 # (rare: two windows per block — out of line)
             p.label(nosus)
 
-    def push_items(self, a, xf, xr, suspect):
+            def cold_tie(tiep=tiep, nosus=nosus, a=a):
+                p.label(tiep)
+                self.push_items(a, V_TIEW, V_TIEW, 1, tie=1)
+                p.i("s_branch", "@" + nosus)
+            self.cold.append(cold_tie)
+
+    def push_items(self, a, xf, xr, suspect, tie=0):
         """queue the hit words of step a (xf: forward-strand candidates, xr: reverse; a read is never in both — ties are masked out or ride in
         xf alone): ONE item per lane = (xf | xr, meta, xr); resolve passes first while the queue lacks room"""
         p = self.p
@@ -399,7 +418,7 @@ class Gen:
             p.i("s_branch", "@" + chk)
         self.cold.append(cold_pass)
         p.label(go)
-        meta = ((2 * a) << 9) | (suspect << 15)
+        meta = ((2 * a) << 9) | (suspect << 15) | (tie << 8)     # bits 0 .. 7: 4 x lane (added below)
         p.i("v_mbcnt_lo_u32_b32", v(T + 1), "vcc_lo", 0)
         p.i("v_mbcnt_hi_u32_b32", v(T + 1), "vcc_hi", v(T + 1))
         p.i("v_lshl_add_u32", v(T + 1), v(T + 1), 2, s(S_QTAIL4))
@@ -495,10 +514,15 @@ class Gen:
         p.label(skip)
         self.probe(1)
 
-    # ---- 32 x 32 bit transpose of the packed words in H0 into I, and the rotation of the plane sets on the way (temps: 32 registers from V_T) ----
-    def transpose_rotate(self):
-        """(H0, H1, I) <- (H1, I, transpose(H0)): the first stage reads H0 into the temps, which frees H0 for H1's planes and H1 for I's; the
-        second stage lands in I and the last three run there in place (64 moves instead of the 64 two-slot swaps of a separate rotation)"""
+    # ---- 32 x 32 bit transpose of the packed words in H0 into the planes I, in two parts (round 5) ----
+    # The two byte-level stages (J = 16, 8: v_perm) run at the end of the block and leave I QUARTER-MAJOR: I[8 q + i] holds, in byte t, the packed
+    # byte (4 bases) of quarter q of the read 64 (i + 8 t) + lane — exactly what one quarter-slot of the ring stores.  The three bit-level stages of
+    # quarter q (J = 4, 2, 1 stay inside the 8 registers of a quarter, and inside a byte) run in quarter_enter(q), right behind the ring write and
+    # before the walk takes in the first base of that quarter: the packed bytes of a chunk wait in the registers they will be planes in, so the ring
+    # in LDS never holds more than the 4 j + 5 quarters the 4 windows of a quarter span (round 4: three whole chunks, 24 KiB -> 18 KiB per wave).
+    def perm_rotate(self):
+        """(H0, H1, I) <- (H1, I, quarter-major bytes of the packed words in H0): the first stage reads H0 into the temps, which frees H0 for H1's planes
+        and H1 for I's; the second stage lands in I"""
         p = self.p
         A = [V_H0 + i for i in range(32)]
         B = [V_T + i for i in range(32)]
@@ -515,15 +539,55 @@ class Gen:
             if kk & 8 == 0:
                 p.i("v_perm_b32", v(O[kk]), v(B[kk + 8]), v(B[kk]), v(V_CP8A))
                 p.i("v_perm_b32", v(O[kk + 8]), v(B[kk + 8]), v(B[kk]), v(V_CP8B))
+
+    def transpose_quarter(self, q):
+        """I[8 q .. 8 q + 7]: quarter-major bytes -> the 8 planes of the bases 4 q .. 4 q + 3 (temps: V_T .. V_T + 7)"""
+        p = self.p
+        O = [V_I + 8 * q + i for i in range(8)]
+        n = 0
         for J, msk in ((4, V_CM4), (2, V_CM2), (1, V_CM1)):  # in place: O[k] = bfi(m, x, y << J), O[k+J] = bfi(m, x >> J, y)
-            for kk in range(32):
+            for kk in range(8):
                 if kk & J == 0:
                     x, y = O[kk], O[kk + J]
-                    p.i("v_lshlrev_b32", v(B[0]), J, v(y))
-                    p.i("v_lshrrev_b32", v(B[1]), J, v(x))
+                    b0, b1 = V_T + 2 * (n % 4), V_T + 2 * (n % 4) + 1  # (four pairs of temps: the pairs of a stage are independent of each other)
+                    n += 1
+                    p.i("v_lshlrev_b32", v(b0), J, v(y))
+                    p.i("v_lshrrev_b32", v(b1), J, v(x))
                     # (a bit-select as v_bitop3: two waves of a SIMD overlap those, v_bfi_b32 they take turns for)
-                    self.bitop3(v(x), v(msk), v(x), v(B[0]), lambda m, a, b: (m & a) | ((1 ^ m) & b))
-                    self.bitop3(v(y), v(msk), v(B[1]), v(y), lambda m, a, b: (m & a) | ((1 ^ m) & b))
+                    self.bitop3(v(x), v(msk), v(x), v(b0), lambda m, a, b: (m & a) | ((1 ^ m) & b))
+                    self.bitop3(v(y), v(msk), v(b1), v(y), lambda m, a, b: (m & a) | ((1 ^ m) & b))
+
+    def drain(self):
+        """resolve passes until the queue is empty"""
+        p = self.p
+        drain, drained = self.lbl("drain"), self.lbl("drained")
+        p.i("s_bitset1_b32", s(S_STEPMASK), 16)                # (bit 16 of the step mask: "the queue is being emptied", read by the pass)
+        p.label(drain)
+        p.i("s_cmp_eq_u32", s(S_QTAIL4), s(S_QHEAD4))
+        p.i("s_cbranch_scc1", "@" + drained)
+        self.call("pass")
+        p.i("s_branch", "@" + drain)
+        p.label(drained)
+        p.i("s_bitset0_b32", s(S_STEPMASK), 16)
+
+    def quarter_enter(self, q):
+        """before step 4 q of block n.  The 4 windows of the coming quarter start in quarter q of chunk n - 1 - j and end, at the latest, in quarter q of
+        chunk n: 4 j + 5 quarters.  Quarter q of chunk n takes the slot of quarter q - 1 of chunk n - 1 - j, which only the windows of the steps behind
+        us needed — so the queue is emptied first (q = 0: the end of the block has done that).  A resolve pass therefore only ever sees candidates of
+        ONE quarter, and S_RQ[0 .. 4 j + 4] are the slots of the bytes of their windows, in order."""
+        p = self.p
+        if q:
+            self.drain()
+            self.probe(0)
+        p.i("s_mov_b32", s(S_A), s(S_RQ[0]))
+        for i in range(self.rq - 1):
+            p.i("s_mov_b32", s(S_RQ[i]), s(S_RQ[i + 1]))
+        p.i("s_mov_b32", s(S_RQ[self.rq - 1]), s(S_A))
+        p.i("v_add_u32", v(V_T0 + 2), s(S_A), v(V_LANE4))
+        for i in range(0, 8, 2):  # (offsets in units of 64 dwords: the slot's rows are 256 bytes apart)
+            p.i("ds_write2st64_b32", v(V_T0 + 2), v(V_I + 8 * q + i), v(V_I + 8 * q + i + 1), mods=f"offset0:{i} offset1:{i + 1}")
+        self.transpose_quarter(q)
+        self.probe(3)
 
     # ---- the resolve pass (subroutine) ----------------------------------------------------------------------
     def emit_pass(self):
@@ -538,28 +602,38 @@ class Gen:
         if "nopass" in self.exp:
             p.i("s_mov_b32", s(S_QHEAD4), s(S_QTAIL4))
             self.ret()
-        # active lanes: items head .. head + n - 1, n = min(64, count)
+        # Items -> lanes, in rounds: the first round takes min(64, count) items.  A word with more than one candidate goes back to the END of the queue
+        # with its lowest bit cleared; when the round has taken everything the queue held, those words are the only items left and the lanes that
+        # are still idle take them in the next round (and so on for third candidates).  Without this a queue that has to be EMPTIED — before every
+        # quarter of a block, quarter_enter — would end in passes of a handful of second and third candidates: 13.9 passes per block measured
+        # against 8.6 with whole-chunk ring slots; with it a quarter's ~110 items are two passes.
+        zr = mid                                              # the item's reverse-strand mask (until the requeue below)
+        x, y = item, item + 1
+        p.i("s_mov_b32", s(S_CC), 0)                          # lanes filled so far
+        p.label("passload")
         p.i("s_sub_u32", s(S_N), s(S_QTAIL4), s(S_QHEAD4))
         p.i("s_lshr_b32", s(S_N), s(S_N), 2)
-        p.i("s_min_u32", s(S_N), s(S_N), 64)
-        p.i("s_bfm_b64", "exec", s(S_N), 0)
+        p.i("s_sub_u32", s(S_B), 64, s(S_CC))
+        p.i("s_min_u32", s(S_N), s(S_N), s(S_B))
+        p.i("s_bfm_b64", "exec", s(S_N), s(S_CC))
         p.i("s_cmp_eq_u32", s(S_N), 64)
         p.i("s_cselect_b64", "exec", -1, "exec")
-        p.i("v_add_u32", v(t1), s(S_QHEAD4), v(V_LANE4))
+        p.i("s_lshl_b32", s(S_B), s(S_CC), 2)
+        p.i("s_sub_u32", s(S_B), s(S_QHEAD4), s(S_B))        # lane l takes item l - filled
+        p.i("v_add_u32", v(t1), s(S_B), v(V_LANE4))
         p.i("v_and_b32", v(t1), v(V_CQMASK4), v(t1))
         p.i("v_add_u32", v(t1), v(V_QBASE), v(t1))
-        zr = mid                                              # the item's reverse-strand mask (until the requeue below)
         p.i("ds_read2_b32", vr(item, 2), v(t1), mods=f"offset0:0 offset1:{QSTRIDE}")
         p.i("ds_read_b32", v(zr), v(t1), mods=f"offset:{QSTRIDE * 8}")
         p.i("s_lshl2_add_u32", s(S_QHEAD4), s(S_N), s(S_QHEAD4))
+        p.i("s_add_u32", s(S_CC), s(S_CC), s(S_N))
         p.i("s_waitcnt", "lgkmcnt(0)")
-        x, y = item, item + 1
         p.i("v_ffbl_b32", v(m), v(x))
         p.i("v_add_u32", v(rest), -1, v(x))
         p.i("v_and_b32", v(rest), v(rest), v(x))
         p.i("v_lshrrev_b32", v(tb), v(m), v(zr))
         p.i("v_and_b32", v(tb), 1, v(tb))                     # strand of the read being resolved
-        # ---- what is left of each word goes to the back of the queue (exec = the active items) ----
+        # ---- what is left of each word goes to the back of the queue (exec = the items of this round) ----
         p.i("v_cmp_ne_u32_e32", "vcc", 0, v(rest))
         p.i("s_bcnt1_i32_b64", s(S_A), "vcc")
         p.i("v_mbcnt_lo_u32_b32", v(t1), "vcc_lo", 0)
@@ -571,21 +645,55 @@ class Gen:
         p.i("ds_write2_b32", v(t1), v(rest), v(y), mods=f"offset0:0 offset1:{QSTRIDE}")
         p.i("ds_write_b32", v(t1), v(zr), mods=f"offset:{QSTRIDE * 8}")
         p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
-        p.i("v_and_b32", v(col), 0xff, v(y))
-        p.i("v_lshl_add_u32", v(col), v(m), 8, v(col))
-        slots = (S_B0, S_B1, S_B2) if self.j == 1 else (S_B1, S_B2, S_B2)
-        p.i("v_add_u32", v(a0), s(slots[0]), v(col))
-        p.i("v_add_u32", v(a1), s(slots[1]), v(col))
-        p.i("v_add_u32", v(a2), s(slots[2]), v(col))
-        p.i("ds_read_b32", v(a0), v(a0))
-        p.i("ds_read_b32", v(a1), v(a1))
-        p.i("ds_read_b32", v(a2), v(a2))
-        p.i("v_bfe_u32", v(t1), v(y), 9, 5)                   # shift = 2 x (window start within its chunk)
+        p.i("s_bitcmp1_b32", s(S_STEPMASK), 16)               # another round?  only when the queue is being emptied (drain: a pass run for want of room
+        p.i("s_cbranch_scc0", "@passloaded")                  # leaves the words it puts back to the next one, which costs nothing) ...
+        p.i("s_cmp_lt_u32", s(S_CC), 64)                      # ... with idle lanes ...
+        p.i("s_cbranch_scc0", "@passloaded")
+        p.i("s_cmp_lg_u32", s(S_QTAIL4), s(S_QHEAD4))         # ... and items (then the queue holds nothing but the words this round has put back)
+        p.i("s_cbranch_scc1", "@passload")
+        p.label("passloaded")
+        p.i("s_bfm_b64", "exec", s(S_CC), 0)
+        p.i("s_cmp_eq_u32", s(S_CC), 64)
+        p.i("s_cselect_b64", "exec", -1, "exec")
+        # the window's bytes: byte i lies in quarter-slot S_RQ[i], row m & 7, lane, byte m >> 3 (every byte is loaded into a register of its own,
+        # zero-extended: a d16 load keeps or clears the other half of its register depending on the ECC mode of the part)
+        nby = self.nby
+        addr = fld[:nby]                                      # (address registers now, fields later)
+        byt = [a0, a1, a2, lo, hi, key, key1, fld[9], fld[10]][:nby]
+        p.i("v_and_b32", v(col), 0xff, v(y))                  # 4 x lane
+        p.i("v_lshl_or_b32", v(a0), v(m), 11, v(m))
+        p.i("v_lshrrev_b32", v(a0), 3, v(a0))
+        p.i("v_and_or_b32", v(col), v(a0), v(V_CBYTE), v(col))  # (m & 7) << 8 | 4 lane | m >> 3
+        for i in range(nby):
+            p.i("v_add_u32", v(addr[i]), s(S_RQ[i]), v(col))
+        for i in range(nby):
+            p.i("ds_read_u8", v(byt[i]), v(addr[i]))
+        p.i("v_bfe_u32", v(t1), v(y), 9, 3)                   # shift = 2 x (window start within its quarter)
         p.i("v_mul_u32_u24", v(tb), hex(self.ng * 256), v(tb))
         p.i("v_add_u32", v(tb), TABLE_OFF, v(tb))             # the strand's table
         p.i("s_waitcnt", "lgkmcnt(0)")
-        p.i("v_alignbit_b32", v(lo), v(a1), v(a0), v(t1))     # bases 0 .. 15 of the window
-        p.i("v_alignbit_b32", v(hi), v(a2), v(a1), v(t1))     # bases 16 .. 31
+
+        def word(bs):
+            """bs[0] = the bytes bs (registers, zero-extended) as one dword, lowest first"""
+            if len(bs) >= 2:
+                p.i("v_lshl_or_b32", v(bs[0]), v(bs[1]), 8, v(bs[0]))
+            if len(bs) == 4:
+                p.i("v_lshl_or_b32", v(bs[2]), v(bs[3]), 8, v(bs[2]))
+            if len(bs) >= 3:
+                p.i("v_lshl_or_b32", v(bs[0]), v(bs[2]), 16, v(bs[0]))
+            return bs[0]
+        w0 = word(byt[0:4])
+        w1 = word(byt[4:8]) if nby > 4 else None
+        w2 = byt[8] if nby > 8 else None
+        if w1 is None:
+            p.i("v_lshrrev_b32", v(lo), v(t1), v(w0))         # (k <= 13: the window lies in four bytes)
+        else:
+            p.i("v_alignbit_b32", v(lo), v(w1), v(w0), v(t1))  # bases 0 .. 15 of the window
+            if self.k > 16:
+                if w2 is None:
+                    p.i("v_lshrrev_b32", v(hi), v(t1), v(w1))
+                else:
+                    p.i("v_alignbit_b32", v(hi), v(w2), v(w1), v(t1))  # bases 16 .. 31
         # 3 bases per look-up: field g = bits [6 g, 6 g + 6) of hi:lo
         for g in range(self.ng):
             bit = 6 * g
@@ -685,9 +793,29 @@ class Gen:
         p.i("s_lshl_b32", s(S_B), s(S_B), 4)
         p.i("v_bfe_u32", v(sx + 2), v(y), 10, 4)
         p.i("v_add_u32", v(sx + 2), s(S_B), v(sx + 2))
-        p.i("v_lshrrev_b32", v(sx + 3), 2, v(col))
+        p.i("v_bfe_u32", v(sx + 3), v(y), 2, 6)               # lane
+        p.i("v_lshl_or_b32", v(sx + 3), v(m), 6, v(sx + 3))   # read of the tile = 64 m + lane
         p.i("v_lshl_or_b32", v(sx + 2), v(sx + 2), 11, v(sx + 3))
-        p.i("v_and_b32", v(sx + 3), 2, v(sflag))              # 2: the candidate's own pattern fails below the walk's 8-bit prefix (s_bits >= 8) — no hit, whatever its bytes
+        # marks: 2 = the candidate's own pattern fails below the walk's 8-bit prefix (s_bits >= 8: no hit, whatever its bytes); 4 = a tie (K1f re-derives
+        # both strands from the bytes); bits 4 .. 6 = the read's dirty bits in the block's three chunks n - 2 .. n (the dirty words live in the lane the
+        # item came from: fetched across lanes) — with them K1f reads nothing but the entry and the window's dirty pieces
+        dl, d0, d1, d2 = fld[5], fld[6], fld[7], fld[8]
+        p.i("s_mov_b64", sr(S_TMP, 2), "exec")
+        p.i("s_mov_b64", "exec", -1)                           # (a lane that is switched off would hand out nothing)
+        p.i("v_and_b32", v(dl), 0xff, v(y))                   # 4 x the item's lane
+        dsrc = (V_D0, V_D1, V_D2) if self.j == 1 else (V_D1, V_D2)   # the chunks the window starts in and the ones behind it
+        dregs = (d0, d1, d2)[:len(dsrc)]
+        for dj, src in zip(dregs, dsrc):
+            p.i("ds_bpermute_b32", v(dj), v(dl), v(src))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_mov_b64", "exec", sr(S_TMP, 2))
+        p.i("v_and_b32", v(sx + 3), 2, v(sflag))
+        p.i("v_bfe_u32", v(dl), v(y), 8, 1)
+        p.i("v_lshl_or_b32", v(sx + 3), v(dl), 2, v(sx + 3))
+        for j, dj in enumerate(dregs):
+            p.i("v_lshrrev_b32", v(dj), v(m), v(dj))
+            p.i("v_and_b32", v(dj), 1, v(dj))
+            p.i("v_lshl_or_b32", v(sx + 3), v(dj), 4 + j, v(sx + 3))
         p.i("global_store_dwordx4", v(t1), vr(sx, 4), sr(S_SUS, 2))
         p.i("s_nop", 1)                                       # (a 128-bit store reads its data a little after it issues)
         p.label(susfull)                                      # no room: the count runs past the capacity, which K1f reads as "walk everything"
@@ -777,7 +905,7 @@ class Gen:
         p.i("s_lshl_b32", s(S_A), s(S_WT), 2)
         p.i("v_mov_b32", v(V_WAVE4), s(S_A))
         p.i("s_mov_b32", s(S_NWAVES), inp["n_waves"])
-        p.i("s_mov_b32", s(S_B0), inp["lds_wbase"])
+        p.i("s_mov_b32", s(S_RQ[0]), inp["lds_wbase"])
         for reg, name in ((S_TILES, "tiles"), (S_SK, "sketch0"), (S_DIRTY, "dirty"), (S_TIE, "tie"), (S_SUS, "sus")):
             p.i("s_load_dwordx2", sr(reg, 2), sr(S_KARG, 2), hex(KARG[name]))
         for reg, name in ((S_NTILES, "n_tiles"), (S_C, "n_chunks"), (S_L, "read_len"), (S_NVLAST, "nv_last"), (S_KEYBASE, "key_base"), (S_RMASK2, "rmask2"),
@@ -809,11 +937,11 @@ class Gen:
         p.i("v_lshlrev_b32", v(V_LANE4), 2, v(V_LANE4))
         p.i("v_mov_b32", v(V_ONE), 1)
         p.i("v_mov_b32", v(V_EXP1), "0x43ff41ff")
-        p.i("s_add_u32", s(S_A), s(S_B0), RING_BYTES)
+        p.i("s_add_u32", s(S_A), s(S_RQ[0]), RING_BYTES)
         p.i("v_mov_b32", v(V_QBASE), s(S_A))
         p.i("v_mov_b32", v(V_QDUMMY), QCAP * 4)
-        p.i("s_add_u32", s(S_B1), s(S_B0), 8192)
-        p.i("s_add_u32", s(S_B2), s(S_B0), 16384)
+        for i in range(1, self.rq):
+            p.i("s_add_u32", s(S_RQ[i]), s(S_RQ[0]), i * QSLOT)
         p.i("s_mov_b32", s(S_QHEAD4), 0)
         p.i("s_mov_b32", s(S_QTAIL4), 0)
         p.i("s_mov_b64", sr(S_F1ACC, 2), 0)
@@ -888,6 +1016,8 @@ class Gen:
         # ================================ the chunk loop ================================
         p.label("iter")
         for a in range(16):
+            if a % 4 == 0:
+                self.quarter_enter(a // 4)
             self.walk_step(a)
             skip = self.lbl("nostep")
             p.i("s_bitcmp1_b32", s(S_STEPMASK), a)
@@ -912,14 +1042,8 @@ class Gen:
                 p.i("s_mov_b32", s(S_CC), s(S_QSOFF))
                 p.label(noq)
                 self.pack_batch(3)
-        # -- end of block: empty the queue (the ring slot of chunk n - 2 is about to be overwritten)
-        drain, drained = self.lbl("drain"), self.lbl("drained")
-        p.label(drain)
-        p.i("s_cmp_eq_u32", s(S_QTAIL4), s(S_QHEAD4))
-        p.i("s_cbranch_scc1", "@" + drained)
-        self.call("pass")
-        p.i("s_branch", "@" + drain)
-        p.label(drained)
+        # -- end of block: empty the queue (the next quarter_enter recycles the oldest quarter-slot of the ring)
+        self.drain()
         self.probe(0)
         # -- tie bits of this block -> tie[(WT * NB + WN) * 64 + lane]
         notie = self.lbl("notie")
@@ -931,21 +1055,18 @@ class Gen:
         p.i("global_store_dword", v(V_T0), v(V_TACC), sr(S_TIE, 2))
         p.label(notie)
         p.i("v_mov_b32", v(V_TACC), 0)
-        # -- chunk P: packed words -> ring slot of chunk n - 2, dirty bits -> dirty[(PT * C + PN) * 64 + lane], then planes
+        # -- chunk P: dirty bits -> dirty[(PT * C + PN) * 64 + lane], packed words -> quarter-major bytes in I (ring and planes: quarter_enter)
         p.i("v_bfrev_b32", v(V_DN), v(V_DN))
         nopk = self.lbl("nopk")
         p.i("s_cmp_eq_u32", s(S_PREAL), 1)
         p.i("s_cbranch_scc0", "@" + nopk)
-        p.i("v_add_u32", v(V_T0), s(S_B0), v(V_LANE4))
-        for mm in range(0, 32, 2):  # (offsets in units of 64 dwords: the slot's [m][lane] rows are 256 bytes apart)
-            p.i("ds_write2st64_b32", v(V_T0), v(V_H0 + mm), v(V_H0 + mm + 1), mods=f"offset0:{mm} offset1:{mm + 1}")
         p.i("s_mul_i32", s(S_A), s(S_PT), s(S_C))
         p.i("s_add_u32", s(S_A), s(S_A), s(S_PN))
         p.i("s_lshl_b32", s(S_A), s(S_A), 8)
         p.i("v_add_u32", v(V_T0), s(S_A), v(V_LANE4))
         p.i("global_store_dword", v(V_T0), v(V_DN), sr(S_DIRTY, 2))
-        # -- rotate: planes (H0, H1, I) <- (H1, I, new), ring slots, dirty words
-        self.transpose_rotate()
+        # -- rotate: planes (H0, H1, I) <- (H1, I, new), dirty words
+        self.perm_rotate()
         rotated = self.lbl("rotated")
         p.i("s_branch", "@" + rotated)
         p.label(nopk)                                           # no chunk P (behind a tile's last one): its planes are all 'A'
@@ -956,10 +1077,6 @@ class Gen:
         for i in range(32):
             p.i("v_mov_b32", v(V_I + i), 0)
         p.label(rotated)
-        p.i("s_mov_b32", s(S_A), s(S_B0))
-        p.i("s_mov_b32", s(S_B0), s(S_B1))
-        p.i("s_mov_b32", s(S_B1), s(S_B2))
-        p.i("s_mov_b32", s(S_B2), s(S_A))
         p.i("v_mov_b32", v(V_D0), v(V_D1))
         p.i("v_mov_b32", v(V_D1), v(V_D2))
         p.i("v_mov_b32", v(V_D2), v(V_DN))

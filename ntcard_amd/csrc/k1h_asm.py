@@ -345,6 +345,12 @@ class Emu:
         self.wr_s(o[0], r)
         self.scc = 1 if r else 0
 
+    def op_s_bitset1_b32(self, pc, o, m):
+        self.wr_s(o[0], self.rd_s(o[0]) | (1 << (self.rd_s(o[1]) & 31)))
+
+    def op_s_bitset0_b32(self, pc, o, m):
+        self.wr_s(o[0], self.rd_s(o[0]) & ~(1 << (self.rd_s(o[1]) & 31)))
+
     def op_s_bitcmp1_b32(self, pc, o, m):
         self.scc = (self.rd_s(o[0]) >> (self.rd_s(o[1]) & 31)) & 1
 
@@ -683,6 +689,22 @@ class Emu:
         val[em] = self.lds32[addr[em] // 4]
         self.wr_v(o[0], val)
 
+    def op_ds_bpermute_b32(self, pc, o, m):
+        """dst[lane] = src[(addr[lane] / 4) mod 64]; a source lane that is switched off hands out 0"""
+        em = self.mask_arr()
+        lane = (self.rd_v(o[1]).astype(np.int64) + m.get("offset", 0)) // 4 % 64
+        src = self.rd_v(o[2])
+        val = np.where(em[lane], src[lane], np.uint32(0)).astype(np.uint32)
+        self.wr_v(o[0], val)
+
+    def op_ds_read_u8(self, pc, o, m):
+        em = self.mask_arr()
+        addr = self._lds_addr(o[1], m)
+        assert np.all(addr[em] >= 0) and np.all(addr[em] < self.lds.size), "ds_read_u8: bad address"
+        val = np.zeros(64, dtype=np.uint32)
+        val[em] = self.lds[addr[em]]
+        self.wr_v(o[0], val)
+
     def op_ds_read_b64(self, pc, o, m):
         em = self.mask_arr()
         addr = self._lds_addr(o[1], m)
@@ -825,7 +847,7 @@ class Emu:
 # ready instructions, the one whose operands were produced longest ago.
 _BOUNDARY = {"s_memtime", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz", "s_cbranch_execz", "s_getpc_b64", "s_setpc_b64",
              "s_waitcnt", "s_endpgm", "s_nop", "s_sleep"}
-_SALU_NO_SCC = {"s_mov_b32", "s_mov_b64", "s_mul_i32", "s_mul_hi_u32", "s_bfm_b32", "s_bfm_b64", "s_load_dword", "s_load_dwordx2", "s_cselect_b32", "s_cselect_b64"}
+_SALU_NO_SCC = {"s_bitset0_b32", "s_bitset1_b32", "s_mov_b32", "s_mov_b64", "s_mul_i32", "s_mul_hi_u32", "s_bfm_b32", "s_bfm_b64", "s_load_dword", "s_load_dwordx2", "s_cselect_b32", "s_cselect_b64"}
 
 
 def _regs(op):
@@ -849,7 +871,7 @@ def defs_uses(mnem, ops):
     n = len(ops)
     if mnem.startswith("ds_write") or mnem.startswith("buffer_store") or mnem.startswith("global_store") or mnem.startswith("global_atomic"):
         return [], flat(range(n)) + ["exec"], True
-    if mnem.startswith("ds_read") or mnem.startswith("buffer_load") or mnem.startswith("global_load"):
+    if mnem.startswith("ds_read") or mnem.startswith("ds_bpermute") or mnem.startswith("buffer_load") or mnem.startswith("global_load"):
         return R[0], flat(range(1, n)) + ["exec"], True
     if mnem.startswith("s_load"):
         return R[0], flat(range(1, n)), True
@@ -872,6 +894,8 @@ def defs_uses(mnem, ops):
             d.append("scc")
         if mnem in ("s_addc_u32", "s_cselect_b32", "s_cselect_b64"):
             u.append("scc")
+        if mnem in ("s_bitset0_b32", "s_bitset1_b32"):  # read-modify-write of the destination
+            u += d
         return d, u, False
     raise NotImplementedError(f"scheduler: {mnem}")
 

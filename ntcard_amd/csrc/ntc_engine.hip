@@ -913,16 +913,16 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 			if (need_d < (1ull << 32) && need_t < (1ull << 32)) {
 				// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
 				// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N against 2.4 ms for K1c).  The share: the
-				// blocks a wave alone on its SIMD takes (launch_sketch_k1h / the kernel's prologue: 20 of a workgroup's 104 sixteenths) + 1, all of
+				// blocks of a wave (launch_sketch_k1h: even shares of a workgroup's quota) + 1, all of
 				// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
 				// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
 				// 2 GiB per set (beyond that a launch may still overflow: slow path, exact).
-				const uint32_t max_waves = (uint32_t)di.cus * 6u;
+				const uint32_t wpg = ntc::sketch_k1h_waves();                                              // waves per workgroup (one workgroup per CU)
+				const uint32_t max_waves = (uint32_t)di.cus * wpg;
 				const uint64_t total_blocks = (uint64_t)n_tiles * nb;
-				const uint64_t per_wg = 6ull * ntc::sketch_k1h_min_blocks();
+				const uint64_t per_wg = (uint64_t)wpg * ntc::sketch_k1h_min_blocks();
 				const uint64_t launch_wgs = std::min<uint64_t>((total_blocks + per_wg - 1) / per_wg, (uint64_t)di.cus); // (launch_sketch_k1h's grid)
-				const uint64_t quota = ((total_blocks + launch_wgs * 6 - 1) / (launch_wgs * 6)) * 6;        // blocks per workgroup
-				const double lone_blocks = std::ceil((double)quota * 20.0 / 104.0) + 1.0;
+				const double lone_blocks = (double)((total_blocks + launch_wgs * wpg - 1) / (launch_wgs * wpg)) + 1.0; // blocks per wave (even shares)
 				const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
 				uint32_t sus_cap = (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 31) / 16u / max_waves));
 				if (const char* ev = std::getenv("NTC_K1H_SUS_CAP")) { // tests: a short list forces the overflow path

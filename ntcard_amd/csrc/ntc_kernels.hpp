@@ -144,10 +144,10 @@ struct K1hArgs {
 	uint32_t* sus_count;          // [waves]: entries written (0xffffffff: the wave ran out of room — K1f then walks every dirty-affected block itself)
 	uint32_t sus_cap, launch_id;
 	uint32_t* fix_state;          // K1f scratch: [0] = launch_id of the last launch that must take the slow path, [2..3] = F1 correction (uint64)
-	uint32_t lone_weight;         // blocks a wave alone on its SIMD takes for every 16 of a wave that shares one (0: launch_sketch_k1h's default)
 };
 bool sketch_k1h_supports(uint32_t k, uint32_t gap, uint32_t s_bits, uint32_t r_bits);
 uint32_t sketch_k1h_blocks(uint32_t k, uint32_t read_len);
+uint32_t sketch_k1h_waves();
 uint32_t sketch_k1h_min_blocks(); // blocks per wave below which launch_sketch_k1h uses fewer workgroups
 void build_k1h_table(uint32_t k, uint32_t gap, uint32_t r_bits, uint32_t s_bits, uint32_t* out /* 2 * ceil(k / 3) * 64 dwords */);
 hipError_t set_sketch_k1h_smem_limit();

@@ -4,7 +4,7 @@
 // ACGTU bases the canonical ntHash (nthash.hpp:242-257,275-279), ntComp's two sampling patterns on its top bits, one increment
 // of t_Counter[sample][hash & (rBuck - 1)] per sampled window (as a hit-log entry, ntc_apply.hip), and F1.
 //
-// K1h (sketch_k1h_kernel): ONE wave per 2048-read tile, six waves per CU, no wave ever waits for another.  Its body is a
+// K1h (sketch_k1h_kernel): ONE wave per 2048-read tile, eight waves per CU (two on every SIMD), no wave ever waits for another.  Its body is a
 // generated assembly string (gen_k1h.py: explicit physical registers — 62 bit-sliced state planes, 96 base planes, 32 registers
 // of loads in flight, exactly 255 VGPRs; the same instruction list runs on the CPU in tests/test_k1h_emulator.py).  C++ here only
 // stages the closed-form table in LDS and hands the kernel-argument pointer to the asm statement.  K1h resolves every sampled
@@ -37,7 +37,7 @@ constexpr uint32_t kK1hWArea = K1H_GEN_WAREA;
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
 constexpr uint32_t kK1hMinBlocks = 2;
 constexpr uint32_t k1h_table_bytes(uint32_t k) { return 2u * ((k + 2u) / 3u) * 256u; }
-constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k) + 32u; } // the wave areas, the table, the waves' SIMD numbers (ntc_sketch_k1h_body.hip)
+constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k); } // the wave areas and the table (ntc_sketch_k1h_body.hip)
 
 } // namespace
 
@@ -194,30 +194,27 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 	const uint32_t tid = threadIdx.x;
 	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
 	const uint32_t rmask = (1u << r_bits) - 1u;
-	const uint32_t phi = (k - 1u) & 15u, nb = ((a.read_len - 1u + 16u - phi) >> 4) + 1u; // K1h's blocks: block n = the window ends [16 n - 16 + phi, 16 n + phi)
 	const uint4* const t4v = reinterpret_cast<const uint4*>(item.t4);
-	for (uint32_t hb = bx; hb < 2u * n_sus_waves; hb += nbx) { // half a K1h wave's region per block
-		const uint32_t reg = hb >> 1;
+	for (uint32_t reg = bx; reg < n_sus_waves; reg += nbx) { // a K1h wave's region per block (eight waves per CU: ~180 suspects per region and 10 M reads of dist g)
 		uint32_t n = a.sus_count[reg];
 		if (n == 0xffffffffu) n = 0; // the region overflowed: the launch takes the slow path, which ignores the suspects
-		for (uint32_t i = (hb & 1u) * 256u + tid; i < n; i += 512u) {
+		for (uint32_t i = tid; i < n; i += 256u) {
 			uint4* const ep = a.sus + (size_t)reg * a.sus_cap + i;
 			const uint4 e = *ep;
 			const uint32_t t = e.y, r = e.z & 2047u, w = e.z >> 11;
 			const uint32_t c0 = w >> 4, off = w & 15u;
-			const uint32_t rl = r & 63u, rm = r >> 6; // the read's lane and bit in K1h's bit arrays
 			const uint64_t win = k >= 64u ? ~0ull : (1ull << k) - 1ull;
-			// Fast path: the block has no tie bit, so K1h's verdict on the candidate stands (the strand it resolved IS the canonical one, its
+			// Fast path: the suspect is not a tie (mark 4), so K1h's verdict on the candidate stands (the strand it resolved IS the canonical one, its
 			// counter index and pattern test are right) provided the window holds no non-base byte — and for that only the DIRTY pieces of the
-			// window need to be looked at (K1h's dirty bits say which: usually one).  A block with a tie bit (about one suspect in a hundred)
-			// takes the full path below: both strands' hashes from the bytes.
-			const uint32_t blk = (w + k - 1u - phi) / 16u + 1u;
-			if (((a.tie[((size_t)t * nb + blk) * 64u + rl] >> rm) & 1u) == 0u) {
+			// window need to be looked at; the entry says which (marks 16, 32, 64: the read's dirty bits in the chunks c0, c0 + 1, c0 + 2 — round 5;
+			// round 4 fetched the tie word and three dirty words per suspect, four scattered 4-byte reads, to learn the same).  A tie (about one
+			// suspect in a hundred) takes the full path below: both strands' hashes from the bytes.
+			if ((e.w & 4u) == 0u) {
 				if (e.w & 2u) continue; // (s_bits >= 8: the pattern fails below the walk's 8-bit prefix)
 				uint64_t inv = 0;
 #pragma unroll
 				for (uint32_t j = 0; j < 3; ++j)
-					if (c0 + j < C && 16u * j < off + k && ((a.dirty[((size_t)t * C + c0 + j) * 64u + rl] >> rm) & 1u))
+					if (c0 + j < C && 16u * j < off + k && ((e.w >> (4u + j)) & 1u))
 						inv |= (uint64_t)tilebits::inv16(raw_piece(a, t, c0 + j, r)) << (16u * j);
 				if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
 				atomicAdd(a.sketch0 + e.x, 1u);
@@ -265,6 +262,10 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 __global__ __launch_bounds__(256) void k1h_fix_kernel(const K1fBatch batch, const uint32_t n_f1_blocks)
 {
 	const K1fItem& item = batch.item[blockIdx.y];
+	// (Blocks are handed out in index order, so the F1 role's blocks fill the device first and the suspect role follows as they retire.  Alternating
+	// the roles by block parity — both resident from the start — was measured SLOWER, 0.054 against 0.049 ms per 10 M reads of dist g: both roles are
+	// bound by the rate of scattered 16-byte fetches, F1 alone 0.029 ms, suspects alone 0.033 ms, and side by side they only disturb each other's
+	// locality: profiles/r05_k1f_roles.txt.)
 	if (blockIdx.x < n_f1_blocks) k1f_f1_role(item, blockIdx.x, n_f1_blocks);
 	else k1f_suspect_role(item, blockIdx.x - n_f1_blocks, gridDim.x - n_f1_blocks);
 }
@@ -509,21 +510,11 @@ hipError_t set_sketch_k1h_smem_limit()
 	return rc;
 }
 
-// sixteenths of a paired wave's share that a wave alone on its SIMD takes (NTC_K1H_LONE_WEIGHT: tuning runs)
-static uint32_t k1h_lone_weight()
-{
-	static const uint32_t w = [] {
-		const char* s = std::getenv("NTC_K1H_LONE_WEIGHT");
-		const long v = s ? std::strtol(s, nullptr, 10) : 0;
-		return (uint32_t)(v >= 8 && v <= 64 ? v : 20);
-	}();
-	return w;
-}
-
 // Blocks a wave should have at least: a wave that starts inside a tile walks two masked blocks first (~1.2 blocks' worth of instructions), so a
 // small batch is better off with fewer, longer shares — down to this many (measured, ms per step at 0.5 / 1 / 2 M reads of 150 bp: at least
 // 4 blocks 0.126 / 0.141 / 0.199, at least 2 blocks 0.100 / 0.142 / 0.196: profiles/r04_batch_size_sweep.txt)
 uint32_t sketch_k1h_min_blocks() { return kK1hMinBlocks; }
+uint32_t sketch_k1h_waves() { return kK1hWaves; } // waves per workgroup (the engine sizes the suspect regions by it)
 
 // K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
 hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
@@ -535,7 +526,6 @@ hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigne
 	K1hArgs b = a;
 	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
 	b.nb_magic = (uint32_t)((1ull << 32) / nb);
-	if (b.lone_weight == 0) b.lone_weight = k1h_lone_weight();
 	const uint32_t lds = k1h_lds_bytes(k);
 	const bool sb7 = a.s_bits == 7;
 	bool found = false;
@@ -561,7 +551,15 @@ hipError_t launch_k1h_fixup(const K1fBatch& b, uint32_t n_items, unsigned cus, h
 		waves = std::max(waves, b.item[i].n_waves);
 	}
 	const unsigned n_f1 = (unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8);
-	hipLaunchKernelGGL(k1h_fix_kernel, dim3(n_f1 + 2u * waves, n_items), dim3(256), 0, st, b, n_f1);
+	unsigned n_sus = waves;
+	if (const char* ev = std::getenv("NTC_K1F_TIME_ROLE")) { // timing experiments only (WRONG results): 1 = the F1 role alone, 2 = the suspect role alone
+		if (ev[0] == '1') n_sus = 0;
+		if (ev[0] == '2') {
+			hipLaunchKernelGGL(k1h_fix_kernel, dim3(waves, n_items), dim3(256), 0, st, b, 0u);
+			return hipGetLastError();
+		}
+	}
+	hipLaunchKernelGGL(k1h_fix_kernel, dim3(n_f1 + n_sus, n_items), dim3(256), 0, st, b, n_f1);
 	// the F1 correction of the fast path; the slow path (LDS, a CU's worth of blocks) only for a flagged launch
 	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus, n_items), dim3(256), 0, st, b);
 	return hipGetLastError();

@@ -1,5 +1,5 @@
 // ntc_sketch_k1h_body.hip — K1h's kernels: compiled K1H_GEN_PARTS times (-DK1H_PART=p: the variants with k % parts == p), see ntc_sketch_k1h.hip
-// for what the kernel pair computes.  C++ here only stages the closed-form table in LDS, shares the workgroup's blocks out among its waves
+// for what the kernel pair computes.  C++ here only stages the closed-form table in LDS, shares the workgroup's blocks out among its eight waves
 // and hands seven scalars to the generated assembly (gen_k1h.py: explicit physical registers, exactly 255 VGPRs).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -27,10 +27,11 @@ static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && of
               "gen_k1h.KARG");
 constexpr uint32_t kK1hWaves = K1H_GEN_WAVES;
 constexpr uint32_t kK1hWArea = K1H_GEN_WAREA;
-static_assert(kK1hWaves == 6, "the launch (384 threads) and the share-out by SIMD assume six waves per workgroup");
+static_assert(kK1hWaves == 8, "the launch (512 threads: two waves on every SIMD) assumes eight waves per workgroup");
+constexpr uint32_t kK1hThreads = kK1hWaves * 64u;
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
 constexpr uint32_t k1h_table_bytes(uint32_t k) { return 2u * ((k + 2u) / 3u) * 256u; }
-constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k) + 32u; } // the wave areas, the table, the waves' SIMD numbers
+constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k); } // the wave areas and the table
 
 #define K1H_CLOBBERS_V                                                                                                                 \
 	"v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20",   \
@@ -48,7 +49,7 @@ constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_b
 	    "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225",       \
 	    "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241",       \
 	    "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254"
-#define K1H_CLOBBERS_S "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "memory"
+#define K1H_CLOBBERS_S "s26", "s27", "s28", "s29", "s30", "s31", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "memory"
 
 // gen_k1h.py emits one body per (k, gap) and s_bits class (7, >= 8): an assembly string with explicit registers
 template <int K, int SB, int GAP> struct K1hBody;
@@ -71,41 +72,22 @@ K1H_MY_VARIANTS(K1H_BODY_SPECS)
 } // namespace
 
 template <int K, int SB, int GAP>
-__global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
+__global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	{ // the closed-form table: [2 strands][ceil(k / 3)][64] dwords behind the six wave areas
+	{ // the closed-form table: [2 strands][ceil(k / 3)][64] dwords behind the eight wave areas
 		constexpr uint32_t n = 2u * ((K + 2) / 3) * 64u;
 		uint32_t* dst = reinterpret_cast<uint32_t*>(smem + kK1hTableOff);
-		for (uint32_t i = threadIdx.x; i < n; i += 384u)
+		for (uint32_t i = threadIdx.x; i < n; i += kK1hThreads)
 			dst[i] = a.table[i];
 	}
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	// Six waves on four SIMDs: two SIMDs hold a pair, two a single wave.  A lone wave issues an instruction every ~4.4 clocks whatever it is; the
-	// waves of a pair take turns for everything that is not a plain bit operation (v_perm, shifts-and-or, compares, multiplies occupy the SIMD for 4 clocks:
-	// profiles/r04_ubench_issue.txt), so a pair's waves are slower by a quarter.  Every wave therefore tells the others which SIMD it runs on
-	// (HW_ID bits 5:4) and the workgroup's blocks are shared out by weight: lone_weight sixteenths to a lone wave for 16 to one of a pair.
-	volatile uint32_t* const simd_of = reinterpret_cast<volatile uint32_t*>(smem + kK1hTableOff + k1h_table_bytes(K));
-	if ((threadIdx.x & 63u) == 0u) simd_of[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // hwreg(HW_REG_HW_ID, 4, 2)
 	__syncthreads();
-	uint32_t first_block, end_block;
-	{
-		uint32_t wsum = 0, wbefore = 0, wmine = 0;
-		for (uint32_t i = 0; i < kK1hWaves; ++i) {
-			uint32_t same = 0;
-			for (uint32_t j = 0; j < kK1hWaves; ++j)
-				same += simd_of[j] == simd_of[i];
-			const uint32_t wt = same >= 2u ? 16u : a.lone_weight;
-			if (i < wave) wbefore += wt;
-			if (i == wave) wmine = wt;
-			wsum += wt;
-		}
-		const uint32_t quota = a.blocks_per_wave * kK1hWaves, wg0 = blockIdx.x * quota; // (n_tiles * blocks < 2^32 / 64: the products below fit 64 bits easily)
-		first_block = wg0 + (uint32_t)((uint64_t)quota * wbefore / wsum);
-		end_block = wg0 + (uint32_t)((uint64_t)quota * (wbefore + wmine) / wsum);
-		first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_block);
-		end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)end_block);
-	}
+	// Eight waves, two on every SIMD (round 4 ran six — two pairs and two lone waves — and weighed their shares by who sat alone): the workgroup's blocks
+	// are shared out evenly, as contiguous ranges of the flat sequence tile * NB + block.
+	const uint32_t quota = a.blocks_per_wave * kK1hWaves, wg0 = blockIdx.x * quota;
+	const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + wave * a.blocks_per_wave));
+	const uint32_t end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + (wave + 1u) * a.blocks_per_wave));
 	const uint32_t wave_gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kK1hWaves + wave));
 	const uint32_t n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * kK1hWaves));
 	const uint32_t lds_wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kK1hWArea));
@@ -119,8 +101,8 @@ __global__ __launch_bounds__(384) void sketch_k1h_kernel(const K1hArgs a)
 #define K1H_LAUNCH_CASE(kk, gg)                                                                                                                              \
 	if (k == kk && gap == gg) {                                                                                                                             \
 		*found = true;                                                                                                                                      \
-		if (sb7) hipLaunchKernelGGL((sketch_k1h_kernel<kk, 7, gg>), dim3(grid), dim3(384), lds, st, b);                                                      \
-		else hipLaunchKernelGGL((sketch_k1h_kernel<kk, 8, gg>), dim3(grid), dim3(384), lds, st, b);                                                          \
+		if (sb7) hipLaunchKernelGGL((sketch_k1h_kernel<kk, 7, gg>), dim3(grid), dim3(kK1hThreads), lds, st, b);                                                      \
+		else hipLaunchKernelGGL((sketch_k1h_kernel<kk, 8, gg>), dim3(grid), dim3(kK1hThreads), lds, st, b);                                                          \
 		return hipGetLastError();                                                                                                                           \
 	}
 #define K1H_SMEM_CASE(kk, gg)                                                                                                                                \

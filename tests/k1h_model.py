@@ -199,13 +199,20 @@ def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_over
             if ok:
                 kk = key_of(min(fv, rv))
                 assert kk is not None or s_bits > 7, (r, w)  # (s_bits >= 8: the walk tests a prefix of the patterns, a suspect may turn out to be none)
-                # K1f's fast path: in a block without a tie bit K1h's own verdict stands — its counter index, and "no hit" (mark 2) where
-                # the pattern fails below the 8-bit prefix; only blocks with a tie bit need the hash again (the entry may be of the wrong strand)
+                # K1f's fast path: K1h's own verdict stands for every suspect that is not marked as a tie (mark bit 2) — its counter index, and "no hit"
+                # (mark bit 1) where the pattern fails below the 8-bit prefix; a tie is re-derived from the bytes (the entry may be of the wrong strand).
+                # Mark bits 4 .. 6: the read's dirty bits in the chunks the window starts in and the two behind it — all K1f reads besides the entry.
                 tl, lane, m = r // 2048, (r % 2048) % 64, (r % 2048) // 64
                 blk = (w + k - 1 - phi) // 16 + 1
-                if not (int(tie[tl, blk, lane]) >> m) & 1:
+                c0 = w // 16
+                for j in range(3):
+                    if c0 + j < Cn and 16 * j < (w % 16) + k:
+                        assert (int(mark) >> (4 + j)) & 1 == (int(dirty[tl, c0 + j, lane]) >> m) & 1, (r, w, j, int(mark))
+                if not int(mark) & 4:
                     assert (int(mark) & 2 != 0) == (kk is None), (r, w, int(mark))
                     assert kk is None or int(x) == kk, (r, w, int(x), kk)
+                else:
+                    assert (int(tie[tl, blk, lane]) >> m) & 1, (r, w)
                 if kk is not None:
                     keys.append(kk)
     return keys, f1_sub

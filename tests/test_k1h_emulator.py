@@ -89,7 +89,7 @@ def test_k1h_generator_budgets():
     import gen_k1h
     assert gen_k1h.S_END <= 100 and gen_k1h.V_CQMASK4 <= 254
     for k, gap in gen_k1h.VARIANTS:
-        assert gen_k1h.TABLE_OFF + gen_k1h.table_bytes(k) + 32 <= gen_k1h.LDS_BYTES
+        assert gen_k1h.TABLE_OFF + gen_k1h.table_bytes(k) <= gen_k1h.LDS_BYTES
         for sb in (7, 8):
             prog = gen_k1h.Gen(k, sb, gap).build()
-            assert 3500 < prog.n_insts() < 5500
+            assert 3500 < prog.n_insts() < 6000  # (x ~8 bytes: inside the 64 KiB instruction cache two CUs share)

@@ -1,23 +1,12 @@
 #!/bin/bash
-# tools/k1h_ab.sh <variant names...> — average duration of the tiled kernels per variant library ("cur" = in-tree), from rocprofv3
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp && export TMPDIR=/tmp
-for n in "$@"; do
-  if [ "$n" = cur ]; then L=""; else L="--lib $ROOT/tools/lib_k1h_$n.so"; fi
-  for d in ${AB_DISTS:-u}; do
-    rm -rf /tmp/ab_$n
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$n -o t -- python $ROOT/bench.py --no-cpu-baseline --no-live-pmc --steps 10 --warmup 2 --dist $d $L ${AB_ARGS:-} > /tmp/ab_$n.log 2>&1
-    f=$(find /tmp/ab_$n -name '*kernel_stats.csv' | head -1)
-    python - "$n" "$d" "$f" <<'PY'
-import csv, sys
-n, d, f = sys.argv[1:4]
-out = []
-for row in csv.DictReader(open(f)):
-    nm = row["Name"]
-    for key in ("sketch_k1h", "k1h_fix", "k1h_slow", "sketch_ts", "split_kernel", "count_kernel"):
-        if key in nm:
-            out.append("%s %.1f us x%s" % (key, float(row["AverageNs"]) / 1000, row["Calls"]))
-print("%-10s dist=%s: %s" % (n, d, ";  ".join(out)))
-PY
+# tools/k1h_ab.sh [bench args] — the in-tree library against tools/lib_k1h_r04.so (the round-4 build: six waves per CU) inside ONE lease,
+# interleaved (new, old, new, old): hash / fix-up / apply ms per step of the median repeat
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc --no-nodefer $*"
+for i in 1 2; do
+  for lib in "" "--lib tools/lib_k1h_r04.so"; do
+    timeout 600 python bench.py $ARGS $lib 2>/dev/null | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); r=j['roofline']
+print('%-28s %.4f ms/step (min %.4f max %.4f)  %.3f T  hash %.4f  fixup %.4f  apply %.4f  frac %.3f  sclk %s' % ('$lib' or 'in-tree', j['ms_per_step'], j['ms_per_step_min'], j['ms_per_step_max'], j['value']/1e12, r['hash_ms'], r['fixup_ms'], r['apply_ms'], r['frac'], j['sclk_mhz']['after']))"
   done
 done
