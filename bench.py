@@ -58,13 +58,11 @@ def parse():
                                                                "(the committed table profiles/traffic_pmc.json is looked up instead)")
     ap.add_argument("--direct-atomics", action="store_true", help="A/B: one device atomic per sampled k-mer instead of the hit log")
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
-    ap.add_argument("--bitslice", action="store_true", help="A/B: the bit-sliced kernel K1b even for small batches (it is the default for k = 32 batches of >= 128 tiles)")
-    ap.add_argument("--lane-kernel", action="store_true", help="A/B: never use K1b, the lane-per-read kernel K1 takes every batch")
+    ap.add_argument("--lane-kernel", action="store_true", help="A/B: the lane-per-read kernel K1 takes every batch (tiled ones re-laid out as row slots)")
     ap.add_argument("--k1h-timers", action="store_true", help="print the section clocks a K1H_EXP=timers build of K1h left behind F1 (stderr)")
-    ap.add_argument("--teams", action="store_true", help="A/B: tiled batches through K1c (teams of four waves, round 3) instead of K1h (one wave per tile)")
     ap.add_argument("--layout", choices=["auto", "rows", "tiled"], default="auto",
-                    help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1b + K1), tiled = the tiled layout "
-                         "(ntc_submit_tiled_device: K1c, the streaming kernel with in-kernel N handling); auto = tiled where K1c is built "
+                    help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1), tiled = the tiled layout "
+                         "(ntc_submit_tiled_device: K1h + K1f); auto = tiled where K1h is built "
                          "for the configuration (every k of the list within 12..32, no gap, sBits >= 7), rows otherwise (a tiled batch would only be re-laid out)")
     ap.add_argument("--log-entries", type=int, default=0, help="capacity of the hit log in entries (0 = the engine's default: one per counter)")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
@@ -179,7 +177,7 @@ def live_pmc(argv_inner, n_steps):
 def traffic_key(args, reads_per_launch):
     k = ",".join(map(str, klist_of(args)))
     return (f"dist={args.dist},L={args.read_len},k={k},gap={args.gap},r={args.r_bits},s={args.s_bits},reads={reads_per_launch}"
-            + (",tiled" if args.layout == "tiled" else "") + (",teams" if args.teams else "") + (",bitslice" if args.bitslice else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
+            + (",tiled" if args.layout == "tiled" else "") + (",lane-kernel" if args.lane_kernel else "") + (",direct-atomics" if args.direct_atomics else "")
             + (",always-log" if args.always_log else ""))
 
 
@@ -255,8 +253,8 @@ def main():
         args.k, args.gap = 12, 2
     if args.layout == "auto":
         kl = klist_of(args)
-        k1h_gap = len(kl) == 1 and kl[0] == 12 and args.gap == 2 and not args.teams  # K1h's spaced-seed variant (config 5)
-        args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and (args.gap == 0 or k1h_gap) and args.s_bits >= 7 and not args.lane_kernel and not args.bitslice) else "rows"
+        k1h_gap = len(kl) == 1 and kl[0] == 12 and args.gap == 2  # K1h's spaced-seed variant (config 5)
+        args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and (args.gap == 0 or k1h_gap) and args.s_bits >= 7 and not args.lane_kernel) else "rows"
     import torch
     import torch.distributed as dist
     import ntcard_amd as nt
@@ -318,10 +316,10 @@ def main():
     sketch = torch.zeros(nk * (2 << args.r_bits), dtype=torch.int32, device=dev)
     f1_big = torch.zeros(nk + 8, dtype=torch.int64, device=dev)  # (a K1h timing build adds its section clocks behind F1: tools/k1h_variant.sh)
     f1_dev = f1_big[:nk]
-    # the resident batches stay untouched until the end of the run: the engine may share its second passes (K1f behind K1h; the reads K1b
-    # hands back) between batches (NTC_FLAG_DEFER_REDO)
-    base_flags = ((nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | (nt.FLAG_BITSLICE_KERNEL if args.bitslice else 0)
-                  | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0) | (nt.FLAG_TILED_TEAMS if args.teams else 0)
+    # the resident batches stay untouched until the end of the run: the engine may share K1f, the second pass behind K1h, between
+    # batches (NTC_FLAG_DEFER_REDO)
+    base_flags = ((nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
+                  | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0)
                   | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0))
 
     def make_engine(flags):
@@ -403,7 +401,7 @@ def main():
     if rank == 0:
         import numpy as np
         hits = int(sum((ph[ki].astype(np.uint64) * np.arange(65536, dtype=np.uint64)).sum() for ki in range(nk)))
-        # --- roofline, per step, this rank.  A step's kernels = the hash kernels (K1 / K1b + its K1 pass / K1c) AND its share of the
+        # --- roofline, per step, this rank.  A step's kernels = the hash kernels (K1h + K1f, or K1) AND its share of the
         # deferred sketch update (partition + count passes), both HIP-event timed on the engine's stream; the algorithmic bytes
         #  are the bases + 4 B per read, read once, and 2 B read + 2 B written per sampled increment — the increments
         # are carried out by the update kernels, so numerator and denominator cover the same work.  "roofline_hash" prices the hash
@@ -417,15 +415,10 @@ def main():
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
         if (tiled and ((all(12 <= k <= 32 for k in klist) and not args.gap) or (klist == [12] and args.gap == 2)) and args.s_bits >= 7
-                and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel and not args.teams):
-            kern = "sketch_k1h_kernel (K1h: one wave per tile) + k1h_fix_kernel / k1h_slow_kernel (K1f: one launch per up to 8 batches)"
-        elif tiled and all(12 <= k <= 32 for k in klist) and not args.gap and args.s_bits >= 7 and not args.lane_kernel:
-            kern = "sketch_ts_kernel (K1c: tiled streaming kernel)"
-        elif (nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and 128 <= stride <= 160 and L - 31 <= 255 and not tiled
-              and (args.bitslice or (R >= 2048 * 128 and L - 31 >= 97 and not args.lane_kernel and not args.direct_atomics))):
-            kern = "sketch_bs_kernel (K1b: whole 2048-read tiles) + sketch_hf_kernel (K1: handed-back reads and tail)"
+                and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel):
+            kern = "sketch_k1h_kernel (K1h: one wave per tile, eight waves per CU) + k1h_fix_kernel / k1h_slow_kernel (K1f: one launch per up to 8 batches)"
         else:
-            kern = "sketch_hf_kernel (K1)"
+            kern = "sketch_hf_kernel (K1: lane per read)"
         peak_valu = 256 * 4 * 2.4e9 / 2  # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD-32 for 2 clk
         out = {
             "metric": "k-mers/s hashed+sketched (whole node) at k=32, 150 bp reads",

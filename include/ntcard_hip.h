@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NTC_ABI_VERSION 4
+#define NTC_ABI_VERSION 5
 #define NTC_MAX_K_LIST 32
 
 typedef enum {
@@ -64,10 +64,8 @@ typedef struct {
 
 #define NTC_FLAG_NONE 0u
 #define NTC_FLAG_SIMPLE_KERNEL 1u  /* run the simple validation kernel instead of the production ones */
-#define NTC_FLAG_BITSLICE_KERNEL 4u /* use the bit-sliced kernel K1b for the whole 2048-read tiles of EVERY equal-length k = 32
-                                      batch, however small (by default it takes batches of >= 128 tiles of 128-159 bp reads; it always runs in
-                                      hit-log mode: an engine that can use it never switches to direct atomics)           */
-#define NTC_FLAG_LANE_KERNEL 32u    /* never use K1b: the lane-per-read kernel K1 takes every batch (cross-check, A/B runs)  */
+#define NTC_FLAG_LANE_KERNEL 32u    /* the lane-per-read kernel K1 takes every batch, tiled ones too (re-laid out as row slots): cross-check, A/B runs.
+                                      (Flag value 4, round 2-4's NTC_FLAG_BITSLICE_KERNEL, is unused since ABI 5: the bit-sliced row-slot kernel K1b is gone.) */
 #define NTC_FLAG_ALWAYS_LOG 8u      /* keep logging whatever the data looks like (by default the engine switches to direct
                                       atomics when an apply finds few distinct counters per increment: repeats)       */
 #define NTC_FLAG_PARTITION_ALWAYS 16u /* validation: apply even a small hit log through the partition + histogram passes
@@ -75,12 +73,9 @@ typedef struct {
 #define NTC_FLAG_DEFER_REDO 128u    /* device-resident batches (ntc_submit_device, ntc_submit_tiled_device): the caller promises to keep every
                                       submitted buffer valid AND UNCHANGED until ntc_sync / ntc_finish returns.  The second passes over a batch's
                                       reads with non-ACGTU bytes are then shared by several batches instead of run per batch: the fix-up
-                                      kernels K1f behind up to 8 launches of the one-wave-per-tile kernel K1h; the reads K1b hands back to the
-                                      lane-per-read kernel.  Without the flag a buffer may be reused as soon as the stream has passed the submit
-                                      call. */
+                                      kernels K1f behind up to 8 launches of the one-wave-per-tile kernel K1h.  Without the flag a buffer may be
+                                      reused as soon as the stream has passed the submit call. */
 #define NTC_FLAG_REQUIRE_TILED 64u  /* validation: ntc_submit_tiled_device fails instead of re-laying a batch out for the general kernel */
-#define NTC_FLAG_TILED_TEAMS 256u   /* tiled batches: use K1c (teams of four specialised waves, round 3) instead of K1h (one wave per tile,
-                                     * round 4) where both are built for the configuration (cross-check, A/B runs) */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 
@@ -119,7 +114,7 @@ int ntc_submit_spans(ntc_engine *e, const char *buf, const uint64_t *starts, con
 int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint32_t read_len,
                       uint32_t stride);
 
-/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernels (K1h; K1c) stream:
+/* The same for a DEVICE-resident batch in the engine's TILED slot layout — the layout the hot kernel pair (K1h + K1f) streams:
  *     tile t   = reads [2048 t, 2048 t + 2048) of the batch,       n_chunks = ceil(read_len / 16)
  *     piece    = the 16 raw bytes of bases [16 c, 16 c + 16) of read i, at byte offset
  *                ((i / 2048 * n_chunks + c) * 2048 + i % 2048) * 16          (ntc_tiled_bytes() bytes in all)

@@ -13,7 +13,7 @@ registers, the kernel body as one assembly string, and an emulator (k1h_asm.py) 
 
 Per chunk iteration (flat over the wave's tiles; block n of a tile = the 16 window ENDS e in [16 n - 16 + phi, 16 n + phi), phi =
 (k - 1) mod 16, so that the 16 windows of a block all START in one chunk: the resolve pass then reads wave-uniform ring slots):
-  * 16 walk steps, both strands bit-sliced (gen_bs.py: one VGPR = one bit of the 31-bit hash half for 32 reads).  Per step: function
+  * 16 walk steps, both strands bit-sliced (k1h_terms.py: one VGPR = one bit of the 31-bit hash half for 32 reads).  Per step: function
     planes of the incoming / outgoing base, 62 in-place state updates, then — only for steps that complete a window — the sample
     test.  With both strands in one wave the test is EXACT per strand: cf = this window is sampled and the forward strand is
     canonical, cr = ... reverse; cf & cr = the top bits tie (settled by K1f from the bytes).  Candidates go to an LDS queue as
@@ -30,12 +30,12 @@ of that read is dropped, the dirty bits and the tie bits go to two arrays at fix
 fixup_kernel) recomputes exactly those (read, block) pairs from the raw bytes with ntHashIterator's semantics
 (ntHashIterator.hpp:59-86).  F1 here counts every window; K1f takes the invalid ones back.
 
-Nothing is copied from the reference: the four seeds are its constants (nthash.hpp:25-28), everything else is derived (gen_bs.py).
+Nothing is copied from the reference: the four seeds are its constants (nthash.hpp:25-28), everything else is derived (k1h_terms.py).
 """
 import os
 import sys
 
-from gen_bs import step_terms, ttbl, g_of, hseed, rol31, tt4, COMP, CODE2  # noqa: F401
+from k1h_terms import step_terms, ttbl, g_of, hseed, rol31, tt4, COMP, CODE2  # noqa: F401
 from k1h_asm import Prog, v, s, vr, sr, schedule
 
 WAVES = 8                    # waves per workgroup = tiles in flight per CU: two per SIMD (round 5; six in round 4, when a wave's ring was three whole chunks)
@@ -194,7 +194,7 @@ class Gen:
         p.i("s_add_u32", s(S_TACC[sec]), s(S_TACC[sec]), s(S_N))
         p.i("s_mov_b32", s(S_SUSCAP), s(S_TMP))
 
-    # ---- poly-A start state (gen_ts.poly_a_state) ----
+    # ---- poly-A start state: the hash of k A s, the track every tile starts on ----
     def poly_a(self, strand):
         h = 0
         for t in range(self.k):

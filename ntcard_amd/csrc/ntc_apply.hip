@@ -31,8 +31,11 @@ namespace ntc {
 namespace {
 
 constexpr uint32_t kSplitThreads = 1024;
-constexpr uint32_t kSplitKeys = 8;                              // keys per thread and round
-constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;      // 8192 keys per workgroup round: runs of ~64 keys (256 B) per digit at 128 ways
+// keys per thread and round (template parameter of split_kernel): 8 -> 8192 keys per workgroup round, segments of ~64 keys (256 B) per digit at 128
+// ways; 4 -> 4096 keys for passes of <= 64 ways — the same 256-byte segments, and a pass whose input runs are short (the second pass of an apply
+// that comes long before the log is full: bench.py's 20 steps leave runs of ~11 K keys) wastes less of its last round per run (round 5: 1.36 rounds'
+// worth of keys took 2 rounds of 8192, now 2.7 take 3 of 4096)
+constexpr uint32_t kSplitKeysMax = 8;
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -47,8 +50,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 } // namespace
 
 // A1/A2: partition the keys of this workgroup's input runs by digit = (key >> shift) & (2^bits - 1).
+template <uint32_t kSplitKeys>
 __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 {
+	constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;
 	// hist: digit counts of the round; excl: their exclusive scan; rel: gcur - excl (run offset of sorted position 0 of a
 	// digit); gcur: keys this workgroup has written per digit so far
 	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256];
@@ -312,7 +317,9 @@ hipError_t launch_log_atomics(const uint32_t* log, uint32_t* fill, uint32_t regi
 
 hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st)
 {
-	hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(kSplitThreads), 0, st, a);
+	static_assert(kSplitKeysMax == 8, "two instantiations");
+	if (a.bits >= 7) hipLaunchKernelGGL(split_kernel<8>, dim3(grid), dim3(kSplitThreads), 0, st, a);
+	else hipLaunchKernelGGL(split_kernel<4>, dim3(grid), dim3(kSplitThreads), 0, st, a);
 	return hipGetLastError();
 }
 

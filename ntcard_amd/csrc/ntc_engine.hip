@@ -17,7 +17,6 @@
 #include <mutex>
 #include <new>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/ntcard_hip.h"
@@ -104,8 +103,6 @@ int ensure_kernel_attrs(int dev)
 	HIP_TRY(ntc::set_sketch_hf_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_hash_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_apply_smem_limit());
-	HIP_TRY(ntc::set_sketch_bs_smem_limit(kMaxDynLds));
-	HIP_TRY(ntc::set_sketch_ts_smem_limit(kMaxDynLds));
 	HIP_TRY(ntc::set_sketch_k1h_smem_limit());
 	done[dev] = 1;
 	return 0;
@@ -250,7 +247,6 @@ struct ntc_engine {
 	// (repeated keys -> the counters stay cached -> direct atomics are cheaper; ntc_apply.hip, log_probe_kernel)
 	uint32_t* d_logmode = nullptr;          // 0 = log, 1 = direct atomics
 	bool partition_always = false;          // NTC_FLAG_PARTITION_ALWAYS
-	uint64_t bs_min_tiles = 128;            // K1b takes batches of at least this many 2048-read tiles
 	unsigned long long* d_logstats = nullptr; // {keys sampled, repeats among them}
 	uint32_t* d_probe = nullptr;            // 2^20-slot hash table of the probe
 	bool adaptive = true, probed = false;
@@ -259,10 +255,8 @@ struct ntc_engine {
 		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
 	} ap;
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
-	void* d_t4 = nullptr;           // K1b / K1c: closed-form table, 4 bases per entry, of klist[0] (NULL: neither is used by this engine)
-	std::vector<void*> d_t4s;       // K1c: one table per k of the list (d_t4s[0] == d_t4)
-	std::vector<uint32_t*> d_k1h_tabs; // K1h: closed-form table per k of the list (nullptr: K1c takes that k)
-	bool k1h_wanted = true;         // !NTC_FLAG_TILED_TEAMS
+	std::vector<void*> d_t4s;       // K1f: closed-form table, 4 bases per entry, per k of the list (empty: the engine has no tiled kernel)
+	std::vector<uint32_t*> d_k1h_tabs; // K1h: closed-form table (3 bases per entry) per k of the list
 	// What K1h hands to K1f (two bit arrays, the suspect list, a little state): one set per K1h launch whose K1f is still to come.  K1f's kernels
 	// wait on memory (a few dependent loads per dirty piece / suspect, ~45 us per kernel whatever the batch), so for a caller that promised to leave
 	// its batches alone until ntc_sync (NTC_FLAG_DEFER_REDO) the engine collects up to kK1fBatch K1h launches and sends ONE K1f over all of them;
@@ -289,25 +283,15 @@ struct ntc_engine {
 	// profiling of the tiled path: ONE pair of events brackets a RUN of hash launches (a pair per launch costs 10 - 20 us of stream bubbles per
 	// launch, measured); the run ends when anything else is about to enter the stream (K1f, an apply, another kind of batch, a sync)
 	hipEvent_t run_ev0 = nullptr;
-	std::vector<uint64_t> pending_runs; // hash submits bracketed by pending[i] when that is more than one (index-aligned with `pending`; 0 = one)
+	std::vector<uint64_t> pending_runs; // index-aligned with `pending`: 0 = one launch; n + 1 = a bracket of tiled launches that counts as n submits
 	uint64_t run_submits = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: deferred K1f launches (outside the hash kernels' events)
 	double k1f_ms = 0.0;
-	bool ts_ok = false;             // K1c (tiled streaming kernel) is instantiated for this configuration
-	bool bs_ok = false;             // K1b (bit-sliced kernel over row slots) is
+	bool ts_ok = false;             // the tiled kernel pair K1h + K1f is built for every k of this configuration
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
 	bool defer_redo = false;        // NTC_FLAG_DEFER_REDO
-	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1c does not cover
+	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1h is not built for
 	size_t untile_cap = 0;
-	// K1b hands the reads with a non-ACGTU byte and the batch tails to K1 as a list of slot ADDRESSES.  For device-resident
-	// batches (valid until ntc_sync by contract) the list is kept across batches and K1 takes it in ONE gather pass when it
-	// could overflow, when the slot geometry changes, and before anything needs the counters: the pass has fixed costs
-	// (tables, first batch, last partial resolve) that one pass per batch pays ten times (0.13 vs 0.06 ms per 10 M reads)
-	uint64_t* d_redo = nullptr;     // [redo_cap] slot addresses
-	uint32_t* d_redo_count = nullptr;
-	uint64_t redo_cap = 0, redo_bound = 0; // capacity; upper bound of what the pending batches may have appended
-	bool redo_pending = false;
-	uint32_t redo_stride = 0, redo_len = 0;
 	double apply_ms = 0.0;
 	uint64_t applies = 0;
 	uint32_t hll_bits = 0;       // != 0: nthll engine (d_sketch holds uint32 M[1<<hll_bits])
@@ -356,7 +340,7 @@ int drain_events(ntc_engine* e)
 		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
 		e->ms_total += ms;
 		const size_t idx = (size_t)(&pr - e->pending.data());
-		e->launches += idx < e->pending_runs.size() && e->pending_runs[idx] ? e->pending_runs[idx] : 1;
+		e->launches += idx < e->pending_runs.size() && e->pending_runs[idx] ? e->pending_runs[idx] - 1 : 1; // (a bracket: submits + 1; 0: a single launch)
 		(void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
@@ -417,48 +401,6 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	return true;
 }
 
-// K1 in gather mode over the pending list of slot addresses (the reads K1b handed back and the batch tails), then the list is empty
-int flush_redo(ntc_engine* e)
-{
-	if (!e->redo_pending) return 0;
-	if (int rc = close_run(e)) return rc;
-	e->redo_pending = false;
-	HfPlan hp;
-	if (int rc = hf_plan(e->device, std::max<uint64_t>(e->redo_bound, 64), e->redo_stride, &e->klist[0], 1, 0, hp)) return rc;
-	e->redo_bound = 0;
-	ntc::HfArgs a;
-	std::memset(&a, 0, sizeof a);
-	a.stride = e->redo_stride;
-	a.read_len = e->redo_len;
-	a.r_bits = e->r_bits;
-	a.s_bits = e->s_bits;
-	a.n_k = 1;
-	a.gather = e->d_redo;
-	a.gather_count = e->d_redo_count;
-	a.ks[0] = e->hfk[0];
-	if (e->d_log) {
-		a.log = e->d_log;
-		a.log_fill = e->d_logfill;
-		a.log_regions = e->log_regions;
-		a.log_region_cap = e->log_region_cap;
-		a.log_mode = e->d_logmode;
-	}
-	a.sketch0 = e->d_sketch;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	if (e->profiling) {
-		HIP_TRY(hipEventCreate(&ev0));
-		HIP_TRY(hipEventCreate(&ev1));
-		HIP_TRY(hipEventRecord(ev0, e->stream));
-	}
-	HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
-	HIP_TRY(hipMemsetAsync(e->d_redo_count, 0, 4, e->stream));
-	if (e->profiling) {
-		HIP_TRY(hipEventRecord(ev1, e->stream));
-		e->pending.emplace_back(ev0, ev1);
-	}
-	return 0;
-}
-
 // K1f over the K1h launches that still wait for it (asynchronous on the engine's stream).  Before anything reads the counters or F1, touches the
 // sketch without atomics (the apply's sweep does), or hands the batches back to the caller.
 int close_run(ntc_engine* e) // the end of a bracketed run of tiled hash launches (see run_ev0)
@@ -469,7 +411,7 @@ int close_run(ntc_engine* e) // the end of a bracketed run of tiled hash launche
 	HIP_TRY(hipEventRecord(ev1, e->stream));
 	e->pending_runs.resize(e->pending.size(), 0);
 	e->pending.emplace_back(e->run_ev0, ev1);
-	e->pending_runs.push_back(e->run_submits);
+	e->pending_runs.push_back(e->run_submits + 1); // (+ 1: a bracket re-opened in the middle of a k list has counted its submit already and adds none)
 	e->run_ev0 = nullptr;
 	e->run_submits = 0;
 	return 0;
@@ -501,7 +443,6 @@ int join_k1f(ntc_engine* e)
 int apply_log(ntc_engine* e)
 {
 	if (int rc = join_k1f(e)) return rc;
-	if (int rc = flush_redo(e)) return rc; // K1 may log too: its pass comes first
 	if (!e->d_log || !e->log_pending) return 0;
 	const auto& ap = e->ap;
 	const uint32_t nb1 = 1u << ap.b1, nb2 = 1u << ap.b2;
@@ -600,7 +541,7 @@ int apply_log(ntc_engine* e)
 
 // launch the hash->sample->count kernel for every k of the list over one device-resident batch
 int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_meta, uint64_t n_slots,
-              uint32_t read_len, uint32_t stride, bool may_defer = false)
+              uint32_t read_len, uint32_t stride)
 {
 	if (n_slots == 0) return 0;
 	if (int rc = close_run(e)) return rc;
@@ -648,39 +589,11 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		// The head is sized to log the ~2^20 entries the probe wants (0.6 M slots at sBits = 7, k = 32); a batch that is
 		// not several heads long (large sBits, small batches) is not cut: the probe then runs once enough has been logged.
 		constexpr double kProbeEntries = 1.25 * (1 << 20);
-		const uint32_t k0 = e->klist[0];
-		// K1b pays when all four walkers have work: 4 x 32 windows cover 97 .. 128 windows per read (128 .. 159 bp at k = 32;
-		// measured on genome-like reads, hash kernels per 10 M reads: 97 windows 0.63 vs K1's 0.74 ms, 109: 0.65 vs 0.80, 119: 0.68
-		// vs 0.87, 128: 0.72 vs 1.10; 93 windows, where the fourth walker idles: about equal); NTC_FLAG_BITSLICE_KERNEL lifts that
-		const uint32_t n_win = read_len >= k0 ? read_len - k0 + 1 : 0;
-		const bool use_bs = e->bs_ok && e->d_t4 && e->d_log && d_meta == nullptr && n_win >= (e->bs_min_tiles > 1 ? 97u : 1u) && n_win <= 255 && stride >= 128 && stride <= 160 &&
-		                    ntc::sketch_bs_smem(k0, stride) <= kMaxDynLds && n_slots >= 2048 * e->bs_min_tiles;
-		if (e->d_log && e->adaptive && !e->probed && !use_bs && d_meta == nullptr && per_slot > 0.0) {
+		if (e->d_log && e->adaptive && !e->probed && d_meta == nullptr && per_slot > 0.0) {
 			const uint64_t head = (((uint64_t)(kProbeEntries / per_slot) + 2047) / 2048) * 2048;
 			if (e->log_est < (double)(1u << 20) && n_slots >= 4 * head) {
 				if (int rc = run_batch(e, d_slots, nullptr, head, read_len, stride)) return rc;
 				return run_batch(e, d_slots + head * stride, nullptr, n_slots - head, read_len, stride);
-			}
-		}
-		if (use_bs) {
-			// the redo list: room for a few batches of this size (every slot of a batch could end up on it); the deferred K1
-			// pass runs first when the list could overflow or the slot geometry changes
-			if (e->redo_pending && (e->redo_stride != stride || e->redo_len != read_len || e->redo_bound + n_slots > e->redo_cap))
-				if (int rc = flush_redo(e)) return rc;
-			if (n_slots > e->redo_cap) {
-				if (int rc = flush_redo(e)) return rc;
-				HIP_TRY(hipStreamSynchronize(e->stream));
-				if (e->d_redo) (void)hipFree(e->d_redo);
-				e->d_redo = nullptr;
-				e->redo_cap = 0;
-				const uint64_t cap = std::min<uint64_t>(8 * n_slots, std::max<uint64_t>(n_slots, 128ull << 20));
-				if (hipMalloc((void**)&e->d_redo, cap * 8) != hipSuccess)
-					return fail(NTC_ERR_MEMORY, "cannot allocate the %llu-entry redo list on device", (unsigned long long)cap);
-				if (!e->d_redo_count) {
-					if (hipMalloc((void**)&e->d_redo_count, 8) != hipSuccess) return fail(NTC_ERR_MEMORY, "cannot allocate the redo counter on device");
-					HIP_TRY(hipMemsetAsync(e->d_redo_count, 0, 8, e->stream));
-				}
-				e->redo_cap = cap;
 			}
 		}
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -699,8 +612,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		}
 		// K1: one launch per group of up to kMaxFusedK values of k (the batch is staged and decoded once per group);
 		// a group whose closed-form tables would push the CU below 12 waves (and below what its members reach alone) is split in two
-		std::function<int(size_t, size_t, const unsigned char*, uint64_t, const uint64_t*, const uint32_t*)> launch_group =
-		    [&](size_t b, size_t n, const unsigned char* slots, uint64_t ns, const uint64_t* gather, const uint32_t* gather_count) -> int {
+		std::function<int(size_t, size_t, const unsigned char*, uint64_t)> launch_group =
+		    [&](size_t b, size_t n, const unsigned char* slots, uint64_t ns) -> int {
 			HfPlan hp;
 			if (int rc = hf_plan(e->device, ns, stride, &e->klist[b], (uint32_t)n, e->gap, hp)) {
 				if (n == 1) return rc;
@@ -714,8 +627,8 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				worst_single = std::min(worst_single, one.waves_per_cu);
 			}
 			if (n > 1 && hp.waves_per_cu < 12 && hp.waves_per_cu < worst_single) {
-				if (int rc = launch_group(b, n / 2, slots, ns, gather, gather_count)) return rc;
-				return launch_group(b + n / 2, n - n / 2, slots, ns, gather, gather_count);
+				if (int rc = launch_group(b, n / 2, slots, ns)) return rc;
+				return launch_group(b + n / 2, n - n / 2, slots, ns);
 			}
 			ntc::HfArgs a;
 			std::memset(&a, 0, sizeof a);
@@ -730,8 +643,6 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.gap = e->gap;
 			a.gap_first = (e->klist[b] - e->gap) / 2;
 			a.gapt = e->d_gapt;
-			a.gather = gather;
-			a.gather_count = gather_count;
 			if (e->gap) ntc::build_gap_roll_table(e->klist[b], a.gap_first, e->gap, a.tabg);
 			for (size_t j = 0; j < n; ++j)
 				a.ks[j] = e->hfk[b + j];
@@ -746,76 +657,14 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
 			return 0;
 		};
-		// K1b (bit-sliced filter walk) takes the whole 2048-slot tiles of an equal-length batch when it is instantiated
-		// for this k; reads with a non-ACGTU byte come back on a device list and go through K1 in gather mode, and so
-		// does the tail of the batch.
-		uint64_t bs_slots = 0;
-		if (use_bs) {
-			const uint64_t n_tiles = n_slots / 2048;
-			bs_slots = n_tiles * 2048;
-			uint32_t* redo_count = e->d_redo_count;
-			DevInfo di;
-			if (int rc = device_info(e->device, di)) return rc;
-			ntc::BsArgs ba;
-			std::memset(&ba, 0, sizeof ba);
-			ba.slots = d_slots;
-			ba.n_tiles = n_tiles;
-			ba.stride = stride;
-			ba.read_len = read_len;
-			ba.k = k0;
-			ba.r_bits = e->r_bits;
-			ba.s_bits = e->s_bits;
-			ba.nq = (read_len - k0 + 1 + 63) / 64;
-			ba.key_base = 0;
-			if (e->d_log) {
-				ba.log = e->d_log;
-				ba.log_fill = e->d_logfill;
-				ba.log_regions = e->log_regions;
-				ba.log_region_cap = e->log_region_cap;
-				ba.log_mode = nullptr; // K1b always logs
-			}
-			ba.sketch0 = e->d_sketch;
-			ba.f1 = e->d_f1;
-			ba.t4 = e->d_t4;
-			ba.redo_list = e->d_redo;
-			ba.redo_count = redo_count;
-#ifdef NTC_BS_TIMERS
-			static uint64_t* dbg = nullptr;
-			if (!dbg) {
-				HIP_TRY(hipMalloc((void**)&dbg, 16 * 8));
-				HIP_TRY(hipMemset(dbg, 0, 16 * 8));
-				std::atexit([] {
-					uint64_t h[16];
-					if (hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-						fprintf(stderr, "K1b cycles (sum over waves): walker barrier %llu warm %llu (fetch %llu steps %llu) steady steps %llu drain %llu | stager barrier %llu dump+dirty %llu stage %llu\n",
-						        (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[4], (unsigned long long)h[5], (unsigned long long)h[2], (unsigned long long)h[3],
-						        (unsigned long long)h[8], (unsigned long long)h[9], (unsigned long long)h[10]);
-				});
-			}
-			ba.dbg = dbg;
-#endif
-			HIP_TRY(ntc::launch_sketch_bs(ba, (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)di.cus), e->stream));
-			// the tail of the batch behind the whole tiles joins the handed-back reads on the list; K1 takes the list in gather
-			// mode: now for a staged host batch (its buffer is recycled), later and together with other batches otherwise
-			if (bs_slots < n_slots)
-				HIP_TRY(ntc::launch_append_slots(e->d_redo, redo_count, d_slots, stride, bs_slots, (uint32_t)(n_slots - bs_slots), e->stream));
-			e->redo_pending = true;
-			e->redo_bound += n_slots;
-			e->redo_stride = stride;
-			e->redo_len = read_len;
-			if (!may_defer)
-				if (int rc = flush_redo(e)) return rc;
-			bs_slots = n_slots;
-		}
-		if (bs_slots < n_slots)
-			for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)
-				if (int rc = launch_group(b, std::min<size_t>(ntc::kMaxFusedK, e->klist.size() - b), d_slots + bs_slots * stride, n_slots - bs_slots, nullptr, nullptr))
-					return rc;
+		for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)
+			if (int rc = launch_group(b, std::min<size_t>(ntc::kMaxFusedK, e->klist.size() - b), d_slots, n_slots))
+				return rc;
 		if (e->profiling) {
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
 		}
-		if (e->d_log && e->adaptive && !e->probed && !use_bs && e->log_est >= (double)(1u << 20)) { // enough logged since the reset: sample the log, decide log vs atomics
+		if (e->d_log && e->adaptive && !e->probed && e->log_est >= (double)(1u << 20)) { // enough logged since the reset: sample the log, decide log vs atomics
 			e->probed = true;
 			HIP_TRY(ntc::launch_log_probe(e->d_log, e->d_logfill, e->log_region_cap, std::min<uint32_t>(e->log_regions, 1024), 256, e->d_probe, 1u << 20,
 			                              e->d_logstats, e->d_logmode, e->stream));
@@ -856,28 +705,40 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	return 0;
 }
 
-// K1c over one device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)
+// a tiled batch for K1: re-laid out as row-major slots on the device (exact; not a fast path)
+int run_tiled_as_rows(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len)
+{
+	const uint32_t stride = pick_stride(read_len, e->klist, e->gap);
+	const size_t need = (size_t)n_reads * stride + 16;
+	if (need > e->untile_cap) {
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		if (e->d_untile) (void)hipFree(e->d_untile);
+		e->d_untile = nullptr;
+		e->untile_cap = 0;
+		if (hipMalloc((void**)&e->d_untile, need) != hipSuccess) return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of row-major scratch on device", need);
+		e->untile_cap = need;
+	}
+	HIP_TRY(ntc::launch_untile(d_tiles, e->d_untile, n_reads, read_len, stride, e->stream));
+	return run_batch(e, e->d_untile, nullptr, n_reads, read_len, stride);
+}
+
+// K1h + K1f over one device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)
 int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len)
 {
 	if (n_reads == 0) return 0;
 	if (!e->ts_ok && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
-	if (!e->ts_ok) {
-		// this configuration is served by K1 only: re-lay the batch out as row-major slots (exact; not a fast path)
-		const uint32_t stride = pick_stride(read_len, e->klist, e->gap);
-		const size_t need = (size_t)n_reads * stride + 16;
-		if (need > e->untile_cap) {
-			HIP_TRY(hipStreamSynchronize(e->stream));
-			if (e->d_untile) (void)hipFree(e->d_untile);
-			e->d_untile = nullptr;
-			e->untile_cap = 0;
-			if (hipMalloc((void**)&e->d_untile, need) != hipSuccess) return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of row-major scratch on device", need);
-			e->untile_cap = need;
-		}
-		HIP_TRY(ntc::launch_untile(d_tiles, e->d_untile, n_reads, read_len, stride, e->stream));
-		return run_batch(e, e->d_untile, nullptr, n_reads, read_len, stride);
-	}
+	if (!e->ts_ok) return run_tiled_as_rows(e, d_tiles, n_reads, read_len); // this configuration is K1's
 	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
-	if (n_tiles > 0xffffffffull / 64) return fail(NTC_ERR_ARG, "tiled batch of %llu reads is too large for one submit", (unsigned long long)n_reads);
+	{
+		// K1h addresses its bit arrays (one word per tile, chunk / block and lane) with 32-bit byte offsets: a batch of several hundred GB is cut in
+		// two at a tile boundary, as often as it takes (any prefix of a tiled buffer is a batch)
+		const uint64_t rows = (uint64_t)(read_len + 15u) / 16u + 2u; // chunks, and at most chunks + 1 blocks, per tile
+		if (n_tiles * rows * 256u >= (1ull << 32)) {
+			const uint64_t head_tiles = n_tiles / 2, head_reads = head_tiles * ntc::kTileReads;
+			if (int rc = run_tiled(e, d_tiles, head_reads, read_len)) return rc;
+			return run_tiled(e, d_tiles + ntc_tiled_bytes(head_reads, read_len), n_reads - head_reads, read_len);
+		}
+	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
 	if (e->d_log) {
@@ -901,16 +762,20 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 		}
 		return 0;
 	};
-	if (e->profiling) ++e->run_submits;
+	bool counted = false; // this submit counts as one launch of ntc_kernel_time once its first kernel is queued (not at all when read_len < every k)
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
 		if (read_len < k) continue; // no window of this k (ntHashIterator.hpp:61-64)
 		if (int rc = open_run()) return rc;
-		if (e->d_k1h_tabs[ki] != nullptr) {
+		if (e->profiling && !counted) {
+			++e->run_submits;
+			counted = true;
+		}
+		{
 			// K1h + K1f: one wave per tile; the two bit arrays between them are scratch of this launch pair
 			const uint32_t n_chunks = (read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, read_len);
-			const size_t need_d = (size_t)n_tiles * n_chunks * 256, need_t = (size_t)n_tiles * nb * 256;
-			if (need_d < (1ull << 32) && need_t < (1ull << 32)) {
+			const size_t need_d = (size_t)n_tiles * n_chunks * 256, need_t = (size_t)n_tiles * nb * 256; // (< 2^32: larger batches were cut in two above)
+			{
 				// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
 				// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N against 2.4 ms for K1c).  The share: the
 				// blocks of a wave (launch_sketch_k1h: even shares of a workgroup's quota) + 1, all of
@@ -966,7 +831,13 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 					if (e->k1f_n != 0) // the sets ahead are in use by launches whose K1f is still to come
 						if (int rc = join_k1f(e)) return rc;
 					for (uint32_t si = 0; si < (e->defer_redo ? ntc::kK1fBatch : 1u); ++si)
-						if (int rc = ensure_set(e->k1h_set[si])) return rc;
+						if (int rc = ensure_set(e->k1h_set[si])) {
+							// no memory for K1h's hand-over arrays (8 sets with NTC_FLAG_DEFER_REDO: up to ~0.5 GB each per 10 M reads): the
+							// batch is K1's, unless the caller insists on the tiled kernels or part of the k list has been launched already
+							if (e->ts_required || ki != 0) return rc;
+							if (int rc2 = close_run(e)) return rc2;
+							return run_tiled_as_rows(e, d_tiles, n_reads, read_len);
+						}
 				}
 				auto& ks0 = e->k1h_set[e->k1f_n]; // (k1f_n may be 0 now)
 				ntc::K1hArgs h;
@@ -1009,29 +880,6 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				continue;
 			}
 		}
-		ntc::TsArgs a;
-		std::memset(&a, 0, sizeof a);
-		a.tiles = d_tiles;
-		a.n_reads = n_reads;
-		a.n_tiles = (uint32_t)n_tiles;
-		a.n_chunks = (read_len + 15u) / 16u;
-		a.read_len = read_len;
-		a.k = k;
-		a.r_bits = e->r_bits;
-		a.s_bits = e->s_bits;
-		a.key_base = (uint32_t)(ki * e->plane_elems()); // (an engine that gets here has at most 2^32 counters)
-		if (e->d_log) {
-			a.log = e->d_log;
-			a.log_fill = e->d_logfill;
-			a.log_regions = e->log_regions;
-			a.log_region_cap = e->log_region_cap;
-			a.log_mode = nullptr; // K1c logs whenever the engine has a log
-		}
-		a.sketch0 = e->d_sketch;
-		a.f1 = e->d_f1 + ki;
-		a.t4 = e->d_t4s[ki];
-		const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 1) / 2, (uint64_t)di.cus);
-		HIP_TRY(ntc::launch_sketch_ts(a, grid, e->stream));
 	}
 	if (!e->profiling)
 		if (int rc = close_run(e)) return rc; // (profiling was switched off inside a run)
@@ -1157,50 +1005,31 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			want = e->log_cap / 2;
 		}
 	}
-	// K1b (bit-sliced filter walk) is instantiated for k = 32: such an engine gives it every large equal-length batch.  K1b
-	// always logs (a single walker wave per SIMD cannot hide the latency of direct atomics: 1.07 vs 0.61 ms); the batches K1
-	// takes (ragged, short or long slots, small) keep the adaptive choice
-	const bool bs_wanted = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) || (!(cfg->flags & (NTC_FLAG_LANE_KERNEL | NTC_FLAG_DIRECT_ATOMICS)) && e->d_log != nullptr);
-	e->bs_min_tiles = (cfg->flags & NTC_FLAG_BITSLICE_KERNEL) ? 1 : 128;
-	// K1c (tiled streaming kernel): every k of the list must have an instantiation (k = 12 .. 32); a list is served by one launch
-	// per k over the same resident tiles.  Its hit-log keys and its direct-atomics fallback are 32-bit counter indices.
-	e->k1h_wanted = !(cfg->flags & NTC_FLAG_TILED_TEAMS);
+	// The tiled kernel pair K1h + K1f: every k of the list must be one K1h is generated for (k = 12 .. 32; ntcard's -g seed at k = 12 / gap 2); a list is
+	// served by one launch per k over the same resident tiles.  Its hit-log keys and K1f's atomics are 32-bit counter indices.  Everything else —
+	// row slots, other k, other seeds, nthll — is K1's (NTC_FLAG_LANE_KERNEL: tiled batches too, re-laid out as row slots).
 	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->hll_bits == 0 && e->klist.size() * e->plane_elems() <= (1ull << 32);
-	for (uint32_t k : e->klist) // every k of the list needs a tiled kernel: K1h (its (k, gap) variants) or K1c (k = 12 .. 32, no spaced seed)
-		e->ts_ok = e->ts_ok && ((e->k1h_wanted && ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits)) ||
-		                        (e->gap == 0 && ntc::sketch_ts_supports(k, e->s_bits) && ntc::sketch_ts_smem(k) <= 160 * 1024));
-	e->bs_ok = e->kernel_kind == KIND_HF && bs_wanted && e->klist.size() == 1 && e->gap == 0 && e->hll_bits == 0 && ntc::sketch_bs_supports(e->klist[0], e->s_bits);
-	if (e->bs_ok || e->ts_ok) {
-		for (size_t ki = 0; ki < (e->ts_ok ? e->klist.size() : 1); ++ki) {
-			std::vector<uint32_t> t4((size_t)ntc::t4_groups(e->klist[ki]) * 256 * 4);
-			ntc::build_t4(e->klist[ki], t4.data(), (e->klist[ki] - e->gap) / 2, e->gap);
-			void* d = nullptr;
-			if (hipMalloc(&d, t4.size() * 4) != hipSuccess || hipMemcpy(d, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-				if (d) (void)hipFree(d);
-				ntc_destroy(e);
-				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the bit-sliced kernels on device");
-			}
-			e->d_t4s.push_back(d);
-		}
-		e->d_t4 = e->d_t4s[0];
-	}
-	if (!e->d_t4) e->ts_ok = e->bs_ok = false;
-	// K1h (one wave per tile) takes the (k, gap) it is generated for; K1c keeps the others of a list
+	for (uint32_t k : e->klist)
+		e->ts_ok = e->ts_ok && ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits);
 	e->d_k1h_tabs.assign(e->klist.size(), nullptr);
-	if (e->ts_ok && e->k1h_wanted) {
+	if (e->ts_ok) {
 		for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 			const uint32_t k = e->klist[ki];
-			if (!ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits)) continue;
-			if ((uint64_t)(ki + 1) * e->plane_elems() > (1ull << 32)) continue; // K1h / K1f index the counters with 32 bits
-			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);
+			std::vector<uint32_t> t4((size_t)ntc::t4_groups(k) * 256 * 4); // K1f: both strands' 64-bit terms, 4 bases per entry
+			ntc::build_t4(k, t4.data(), (k - e->gap) / 2, e->gap);
+			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);     // K1h's resolve pass: the low r_bits + sample bits, 3 bases per entry
 			ntc::build_k1h_table(k, e->gap, e->r_bits, e->s_bits, tab.data());
-			uint32_t* d = nullptr;
-			if (hipMalloc((void**)&d, tab.size() * 4) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-				if (d) (void)hipFree(d);
+			void* d4 = nullptr;
+			uint32_t* d3 = nullptr;
+			if (hipMalloc(&d4, t4.size() * 4) != hipSuccess || hipMemcpy(d4, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+			    hipMalloc((void**)&d3, tab.size() * 4) != hipSuccess || hipMemcpy(d3, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+				if (d4) (void)hipFree(d4);
+				if (d3) (void)hipFree(d3);
 				ntc_destroy(e);
-				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form table of the tiled kernel on device");
+				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form tables of the tiled kernels on device");
 			}
-			e->d_k1h_tabs[ki] = d;
+			e->d_t4s.push_back(d4);
+			e->d_k1h_tabs[ki] = d3;
 		}
 	}
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
@@ -1232,7 +1061,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_untile) (void)hipFree(e->d_untile);
-	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, (void*)e->d_redo, (void*)e->d_redo_count, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
+	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
 		(void)hipEventDestroy(pr.first);
@@ -1279,11 +1108,6 @@ int ntc_reset(ntc_engine* e)
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
 	if (int rc = join_k1f(e)) return rc;
-	if (e->redo_pending) { // what was handed to the deferred K1 pass belongs to the counts that are being dropped
-		e->redo_pending = false;
-		e->redo_bound = 0;
-		HIP_TRY(hipMemsetAsync(e->d_redo_count, 0, 4, e->stream));
-	}
 	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->hll_bits ? (sizeof(uint32_t) << e->hll_bits) : e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
 	e->hll_reads_seen = 0;
 	if (e->d_logfill) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
@@ -1314,7 +1138,7 @@ int ntc_submit_device(ntc_engine* e, const void* d_slots, uint64_t n_reads, uint
 	if (read_len > 0xffffu) return fail(NTC_ERR_ARG, "ntc_submit_device: read_len %u > 65535", read_len);
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride, /*may_defer=*/e->defer_redo); // only when the caller promised to keep its buffers until ntc_sync
+	return run_batch(e, (const unsigned char*)d_slots, nullptr, n_reads, read_len, stride);
 }
 
 
@@ -1354,9 +1178,8 @@ namespace {
 // Equal-length reads of a host batch go to the device in the TILED layout (round 4): the packing loop writes each read's 16-byte pieces
 // where ntc_submit_tiled_device expects them, so the reads the reference's parsers hand to ntRead (ntcard.cpp:182,203,230) reach the
 // tiled kernels (K1h / K1c) like a device-resident producer's do.
-using LenFn = std::function<uint64_t(uint64_t)>;
-using PtrFn = std::function<const char*(uint64_t)>;
-int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const PtrFn& ptr_of)
+// (len_of / ptr_of are template callables: the packing loops call them once or twice per read, inlined)
+template <class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const PtrFn& ptr_of)
 {
 	HIP_TRY(hipSetDevice(e->device));
 	ntc_engine::StageSlot* sl = nullptr;
@@ -1427,7 +1250,7 @@ int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const PtrFn
 			(void)hipStreamSynchronize(e->stream);
 			return fail(NTC_ERR_DEVICE, "ntc_submit: host to device copy failed");
 		}
-		const bool keep = e->defer_redo; // the staging pair is recycled: its K1f may not run late on the side stream
+		const bool keep = e->defer_redo; // the staging pair is recycled: its K1f may not be deferred
 		e->defer_redo = false;
 		const int rc = run_tiled(e, sl->d_stage, n_reads, len);
 		e->defer_redo = keep;
@@ -1438,33 +1261,11 @@ int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const PtrFn
 	return 0;
 }
 
-int submit_impl(ntc_engine* e, uint64_t n_reads, const LenFn& len_of, const PtrFn& ptr_of, bool rows_only = false)
+// reads -> row slots (one slot per read, long sequences in overlapping chunks) -> K1
+template <class LenFn, class PtrFn> int submit_rows(ntc_engine* e, uint64_t n_reads, const LenFn& len_of, const PtrFn& ptr_of)
 {
 	const uint32_t kmax = *std::max_element(e->klist.begin(), e->klist.end());
 	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
-	if (!rows_only && e->ts_ok && n_reads >= 1024) {
-		// the reads of the most frequent length (a FASTQ file's untrimmed reads) take the tiled path when they are the bulk of the batch
-		std::unordered_map<uint64_t, uint64_t> cnt;
-		uint64_t best = 0, best_n = 0;
-		for (uint64_t i = 0; i < n_reads; ++i) {
-			const uint64_t l = len_of(i);
-			const uint64_t c = ++cnt[l];
-			if (c > best_n) {
-				best_n = c;
-				best = l;
-			}
-		}
-		if (best >= kmin && best <= 0xffffu && best_n >= 1024 && best_n * 10 >= n_reads * 9) {
-			if (best_n == n_reads) return submit_tiled_host(e, n_reads, (uint32_t)best, ptr_of);
-			std::vector<uint64_t> same, rest;
-			same.reserve(best_n);
-			rest.reserve(n_reads - best_n);
-			for (uint64_t i = 0; i < n_reads; ++i)
-				(len_of(i) == best ? same : rest).push_back(i);
-			if (int rc = submit_tiled_host(e, same.size(), (uint32_t)best, [&](uint64_t i) { return ptr_of(same[i]); })) return rc;
-			return submit_impl(e, rest.size(), [&](uint64_t i) { return len_of(rest[i]); }, [&](uint64_t i) { return ptr_of(rest[i]); }, true);
-		}
-	}
 	// ---- plan: one slot per read, or chunks with kmax-1 overlap for long sequences ----
 	uint64_t maxlen = 0;
 	bool uniform = true;
@@ -1622,6 +1423,42 @@ int submit_impl(ntc_engine* e, uint64_t n_reads, const LenFn& len_of, const PtrF
 	return 0;
 }
 
+template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_reads, const LenFn& len_of, const PtrFn& ptr_of)
+{
+	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
+	if (e->ts_ok && n_reads >= 1024) {
+		// the reads of the most frequent length (a FASTQ file's untrimmed reads) take the tiled path when they are the bulk of the batch.
+		// The common case — every read as long as the first — is a plain compare loop; only a mixed batch is counted by length.
+		uint64_t best = len_of(0), best_n = 0;
+		for (uint64_t i = 0; i < n_reads; ++i)
+			best_n += len_of(i) == best;
+		if (best_n != n_reads) {
+			std::vector<uint32_t> cnt(0x10000u, 0u); // (only lengths the tiled layout can take: < 64 Ki)
+			best_n = 0;
+			for (uint64_t i = 0; i < n_reads; ++i) {
+				const uint64_t l = len_of(i);
+				if (l > 0xffffu) continue;
+				const uint32_t c = ++cnt[l];
+				if (c > best_n) {
+					best_n = c;
+					best = l;
+				}
+			}
+		}
+		if (best >= kmin && best <= 0xffffu && best_n >= 1024 && best_n * 10 >= n_reads * 9) {
+			if (best_n == n_reads) return submit_tiled_host(e, n_reads, (uint32_t)best, ptr_of);
+			std::vector<uint64_t> same, rest;
+			same.reserve(best_n);
+			rest.reserve(n_reads - best_n);
+			for (uint64_t i = 0; i < n_reads; ++i)
+				(len_of(i) == best ? same : rest).push_back(i);
+			if (int rc = submit_tiled_host(e, same.size(), (uint32_t)best, [&](uint64_t i) { return ptr_of(same[i]); })) return rc;
+			return submit_rows(e, rest.size(), [&](uint64_t i) { return len_of(rest[i]); }, [&](uint64_t i) { return ptr_of(rest[i]); });
+		}
+	}
+	return submit_rows(e, n_reads, len_of, ptr_of);
+}
+
 } // namespace
 
 extern "C" {
@@ -1649,7 +1486,6 @@ int ntc_sync(ntc_engine* e)
 	if (!e) return fail(NTC_ERR_ARG, "ntc_sync: null engine");
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	if (int rc = flush_redo(e)) return rc; // after ntc_sync the caller may recycle its batches: the listed slots are read now
 	if (int rc = join_k1f(e)) return rc;   // (K1f reads the batches too)
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return drain_events(e);
@@ -1864,15 +1700,21 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 					hipStream_t st = nullptr;
 					hipEvent_t ev = nullptr;
 					HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+					if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { // lanes and arrived stay the same length
+						(void)hipStreamDestroy(st);
+						return fail(NTC_ERR_DEVICE, "ntc_merge_devices: cannot create an event on device %d", p.e->device);
+					}
 					mc.lanes.push_back(st);
-					HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 					mc.arrived.push_back(ev);
 					p.e->merge_allocs += 2;
 				}
 				if (!mc.narrowed) {
 					HIP_TRY(hipEventCreateWithFlags(&mc.narrowed, hipEventDisableTiming));
+					++p.e->merge_allocs;
+				}
+				if (!mc.summed) { // (tested on its own: a failure here must be retried by the next merge)
 					HIP_TRY(hipEventCreateWithFlags(&mc.summed, hipEventDisableTiming));
-					p.e->merge_allocs += 2;
+					++p.e->merge_allocs;
 				}
 				p.narrow = mc.narrow;
 				p.recv = mc.recv;

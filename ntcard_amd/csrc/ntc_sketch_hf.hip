@@ -112,9 +112,7 @@ __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_bal
 // kDump: validation build (ntc_hash_dump_k1_device): the filter lets EVERY window through, so the resolve stage
 // re-derives the full canonical hash of every window with the production code path, and writes it out instead of
 // sampling it (what ntHashIterator / stHashIterator enumerate, ntHashIterator.hpp:59-86, stHashIterator.hpp:60-87)
-// kGather: the batch is a device-side list of slot indices (the reads K1b hands back); its own instantiation, so that
-// the list handling costs the ordinary kernel no registers
-template <bool kMulti, int kMode, int kPref, bool kDump = false, bool kGather = false>
+template <bool kMulti, int kMode, int kPref, bool kDump = false>
 __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(const HfArgs a)
 {
 	const uint32_t n_k = kMulti ? a.n_k : 1u;
@@ -189,9 +187,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	const uint32_t rbuck = 1u << a.r_bits;
 
 	const uint32_t gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + wave);
-	// gather mode: the batch is a device-side list of slot indices (its length is only known on the device)
-	const uint32_t n_listed = kGather ? (uint32_t)__builtin_amdgcn_readfirstlane(*a.gather_count) : 0u;
-	const uint64_t n_slots = kGather ? (uint64_t)n_listed : a.n_slots;
+	const uint64_t n_slots = a.n_slots;
 	const uint64_t n_wb = (n_slots + 63) / 64;
 	// Hit log: ntComp's `++t_Counter[...]` (ntcard.cpp:142-143) is not executed here.  The wave appends the counter
 	// index of every sampled k-mer to its private log regions gwave, gwave + W, ... (W = waves of this launch) with one
@@ -224,7 +220,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	// ---- global -> LDS staging with register prefetch of the next batch (see ntc_sketch_fast.hip) ----
 	const uint32_t full_bytes = 64u * stride;
 	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
-	const bool can_prefetch = nchunk <= (uint32_t)kPref && !kGather;
+	const bool can_prefetch = nchunk <= (uint32_t)kPref;
 	const uint64_t wb_step = (uint64_t)gridDim.x * wpb;
 	uint4 pref[kPref];
 	auto load_round = [&](uint64_t wb_, uint32_t c0) {
@@ -263,28 +259,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		// Slots too long for the register prefetch keep the staging at the walk's level (it would starve otherwise).
 		if (can_prefetch) __builtin_amdgcn_s_setprio(0); // without the register prefetch the staging waits for its own loads: keep its rank
 		__builtin_amdgcn_wave_barrier();
-		if constexpr (kGather) {
-			// row i of the wave's LDS block <- slot gather[slot0 + i]: lane i fetches index i, every lane then copies
-			// dwords d = lane, lane + 64, ... of the 64 x stride/4 block (row = d / (stride/4) by multiply-high)
-			const uint32_t s4 = stride >> 2, magic = 0xffffffffu / s4 + 1u;
-			const uint64_t my_ptr = (uint32_t)lane < nvalid ? a.gather[slot0 + (uint32_t)lane] : 0ull; // the slot's address (any buffer)
-			const uint32_t total = nvalid * s4;
-			for (uint32_t d0 = 0; d0 < total; d0 += 64u * 8u) {
-				uint32_t v[8];
-#pragma unroll
-				for (int u = 0; u < 8; ++u) {
-					const uint32_t d = d0 + (uint32_t)u * 64u + (uint32_t)lane;
-					const uint32_t row = __umulhi(d, magic), col = d - row * s4;
-					const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)my_ptr, (int)(row & 63u)), phi = (uint32_t)__shfl((int)(uint32_t)(my_ptr >> 32), (int)(row & 63u));
-					v[u] = d < total ? reinterpret_cast<const uint32_t*>(((uint64_t)phi << 32) | plo)[col] : 0x41414141u;
-				}
-#pragma unroll
-				for (int u = 0; u < 8; ++u) {
-					const uint32_t d = d0 + (uint32_t)u * 64u + (uint32_t)lane;
-					if (d < total) reinterpret_cast<uint32_t*>(wdata)[d] = decode4(v[u], badacc);
-				}
-			}
-		} else if (nvalid == 64 && can_prefetch) {
+		if (nvalid == 64 && can_prefetch) {
 			store_round(0, badacc);
 			if (wb + wb_step < n_wb && is_full(wb + wb_step)) load_round(wb + wb_step, 0);
 		} else if (nvalid == 64) {
@@ -773,9 +748,7 @@ hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_b
 {
 	const dim3 g(grid), b(64u * waves_per_block);
 	const bool deep = sketch_hf_deep_prefetch(a.stride) && waves_per_block <= 12; // plain k-mer mode only
-	if (a.gather != nullptr)
-		hipLaunchKernelGGL((sketch_hf_kernel<false, 0, 10, false, true>), g, b, smem, st, a);
-	else if (a.dump != nullptr && a.gap != 0)
+	if (a.dump != nullptr && a.gap != 0)
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 1, 10, true>), g, b, smem, st, a);
 	else if (a.dump != nullptr)
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 0, 10, true>), g, b, smem, st, a);
@@ -824,8 +797,7 @@ hipError_t set_sketch_hf_smem_limit(size_t smem)
 	const void* fns[] = { reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 10>),
 		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 16>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 16>),
 		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 2, 10>),
-		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10, true>),
-		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, false, true>) };
+		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10, true>) };
 	for (const void* f : fns) {
 		const hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (rc != hipSuccess) return rc;

@@ -14,13 +14,11 @@ from . import _abi
 from ._abi import NtcConfig, NtcError, check
 
 FLAG_SIMPLE_KERNEL = 1  # NTC_FLAG_SIMPLE_KERNEL: run the simple validation kernel
-FLAG_BITSLICE_KERNEL = 4  # NTC_FLAG_BITSLICE_KERNEL: K1b for every equal-length k = 32 batch, however small (default: batches of >= 128 tiles)
-FLAG_LANE_KERNEL = 32  # NTC_FLAG_LANE_KERNEL: never use the bit-sliced kernel K1b
+FLAG_LANE_KERNEL = 32  # NTC_FLAG_LANE_KERNEL: the lane-per-read kernel K1 takes every batch (tiled ones are re-laid out as row slots)
 FLAG_ALWAYS_LOG = 8  # NTC_FLAG_ALWAYS_LOG: never switch from the hit log to direct atomics
 FLAG_PARTITION_ALWAYS = 16  # NTC_FLAG_PARTITION_ALWAYS: small logs go through the partition passes too (validation)
 FLAG_DEFER_REDO = 128  # NTC_FLAG_DEFER_REDO: submit_device buffers stay unchanged until sync(); the handed-back reads of several batches share one pass
 FLAG_REQUIRE_TILED = 64  # NTC_FLAG_REQUIRE_TILED: submit_tiled_device fails instead of falling back to the general kernel
-FLAG_TILED_TEAMS = 256  # NTC_FLAG_TILED_TEAMS: tiled batches through K1c (teams of four waves) instead of K1h (one wave per tile)
 FLAG_DIRECT_ATOMICS = 2  # NTC_FLAG_DIRECT_ATOMICS: no hit log, one device atomic per sampled k-mer
 SIZE_RULE_BYTES = 50_000_000_000  # ntcard.cpp:430: total input < 50 GB => sBits = 7
 
@@ -154,7 +152,7 @@ class Engine:
         return n.value
 
     def fixup_time(self):
-        """milliseconds of K1f launches on the engine's side stream (FLAG_DEFER_REDO engines; 0 otherwise)"""
+        """milliseconds of the deferred K1f launches (FLAG_DEFER_REDO engines: one per up to 8 K1h launches, on the engine's stream; 0 otherwise)"""
         ms = C.c_double()
         check(self._lib.ntc_fixup_time(self._h, C.byref(ms)))
         return ms.value

@@ -233,9 +233,9 @@ def test_hit_log_geometries_match_direct_atomics(nt, r_bits, klist, log_entries)
 
 
 def test_deferred_pass_over_several_buffers(nt):
-    """K1b hands reads with a non-ACGTU byte and batch tails to ONE deferred K1 pass as a list of slot ADDRESSES: several
-    device batches in different buffers, different tails, a change of slot geometry (flushes the list), a reset (drops
-    it), no ntc_sync in between -> counters and F1 equal the oracle's over everything submitted after the reset"""
+    """several device batches in different buffers, different tails, a change of slot geometry, a reset in between, no ntc_sync in
+    between -> counters and F1 equal the oracle's over everything submitted after the reset (written for round 2's K1b, whose
+    deferred pass kept slot ADDRESSES across batches; kept as a test of ntc_submit_device + ntc_reset)"""
     rng = random.Random(99)
 
     def batch(n, L, stride, pn):
@@ -246,7 +246,7 @@ def test_deferred_pass_over_several_buffers(nt):
     dropped = batch(2048 * 2 + 5, 150, 152, 0.01)
     batches = [batch(2048 * 2 + 300, 150, 152, 0.002), batch(2048 + 1, 150, 152, 0.02), batch(2048 * 3, 150, 152, 0.0),
                batch(2048 * 2 + 77, 148, 156, 0.004), batch(2048 + 900, 150, 152, 0.001)]
-    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_BITSLICE_KERNEL | nt.FLAG_DEFER_REDO) as e:
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_DEFER_REDO) as e:
         e.submit_device(dropped[1].data_ptr(), len(dropped[0]), 150, 152)
         e.reset()
         for reads, d in batches:
@@ -260,16 +260,16 @@ def test_deferred_pass_over_several_buffers(nt):
 
 
 def test_submit_device_buffer_may_be_reused_in_stream_order(nt):
-    """ntc_submit_device's contract: the buffer belongs to the caller again as soon as the stream has passed the call.  K1b hands
-    reads (non-ACGTU byte, batch tail) to a later pass by ADDRESS; by default that pass runs before the submit returns, so
-    overwriting the buffer right behind the submit (same stream) must not change a counter.  With NTC_FLAG_DEFER_REDO the
-    caller promises to keep the buffer, and the pass is shared by several batches."""
+    """ntc_submit_device's contract: the buffer belongs to the caller again as soon as the stream has passed the call, so
+    overwriting the buffer right behind the submit (same stream) must not change a counter.  (Rounds 2-4 had a kernel, K1b, that
+    handed reads to a later pass by address; the test stays as the contract's.)  With NTC_FLAG_DEFER_REDO the caller promises to
+    keep the buffer."""
     rng = random.Random(7)
     reads = [rseq(rng, 150, pn=0.01, plow=0.05) for _ in range(2048 * 2 + 333)]
     buf, _ = to_slots(reads, stride=152)
     buf[buf == 10] = ord("A")
     oc, of1 = orc.sketch_reads(reads, [32], 0, 20, 7)
-    for flags in (nt.FLAG_BITSLICE_KERNEL, 0):
+    for flags in (nt.FLAG_ALWAYS_LOG, 0):
         d = torch.from_numpy(buf).cuda()
         with nt.Engine([32], r_bits=20, s_bits=7, flags=flags) as e:  # engine and torch both use the null stream here
             e.submit_device(d.data_ptr(), len(reads), 150, 152)
@@ -277,7 +277,7 @@ def test_submit_device_buffer_may_be_reused_in_stream_order(nt):
             tc, ph, f1 = e.finish(counters=True)
         assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
     d = torch.from_numpy(buf).cuda()
-    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_BITSLICE_KERNEL | nt.FLAG_DEFER_REDO) as e:
+    with nt.Engine([32], r_bits=20, s_bits=7, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_DEFER_REDO) as e:
         e.submit_device(d.data_ptr(), len(reads), 150, 152)
         e.submit_device(d.data_ptr(), 2048, 150, 152)
         tc, ph, f1 = e.finish(counters=True)
@@ -322,7 +322,7 @@ def test_adaptive_mode_probes_once(nt, s_bits, dist, want_mode):
     """lane-per-read engines decide the update mode ONCE from a sample of the first ~2^20 logged entries: repeat-rich
     reads (dist g) -> direct atomics, uniform reads -> hit log; a batch is cut into head + rest at most once, whatever
     sBits is (regression: at sBits = 11 the head never logged enough for the probe and EVERY batch was cut into
-    0.65 M-slot pieces).  An engine that can use the bit-sliced kernel (k = 32) stays in hit-log mode."""
+    0.65 M-slot pieces)."""
     n, L, stride = 6_000_000, 150, 152
     d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
     nt.gen_reads_device(d.data_ptr(), 5, 0, n, L, stride, dist, genome_len=3_000_000)
@@ -334,24 +334,15 @@ def test_adaptive_mode_probes_once(nt, s_bits, dist, want_mode):
         _, launches = e.kernel_time()
         assert e.update_mode() == want_mode
         assert 4 <= launches <= 5, launches
-    for flags, want in ((nt.FLAG_DEFER_REDO, 3), (0, 4)):  # 2 x K1b + ONE deferred K1 pass over the handed-back reads / one pass per batch
-        with nt.Engine([32], r_bits=27, s_bits=s_bits, flags=flags) as e:
-            e.set_profiling(True)
-            for _ in range(2):
-                e.submit_device(d.data_ptr(), n, L, stride)
-            e.flush()
-            _, launches = e.kernel_time()
-            assert e.update_mode() == 0 and launches == want, (e.update_mode(), launches)
 
 
 @pytest.mark.parametrize("L,stride,s_bits,pn", [
     (150, 152, 7, 0.0005), (150, 152, 11, 0.0), (150, 160, 7, 0.01), (128, 128, 7, 0.0), (156, 156, 8, 0.002),
     (32, 128, 7, 0.0), (33, 132, 7, 0.001), (95, 140, 7, 0.0), (96, 144, 9, 0.0), (97, 148, 7, 0.0005), (159, 160, 7, 0.0),
 ])
-def test_bit_sliced_kernel_matches_oracle(nt, L, stride, s_bits, pn):
-    """K1b (ntc_sketch_bs.hip): whole 2048-slot tiles of equal-length k=32 batches take the bit-sliced filter walk,
-    reads with a non-ACGTU byte come back through K1's gather mode, the tail of the batch through K1.  Window counts
-    around the 16-window blocks and the 4-way segment split, slot strides 128..160, lower case / U, all-N reads."""
+def test_equal_length_row_slots_match_oracle(nt, L, stride, s_bits, pn):
+    """equal-length k = 32 batches in row slots (K1 with the log forced; the shapes are those of round 2's bit-sliced row-slot kernel K1b:
+    window counts around 16-window blocks, slot strides 128..160, lower case / U, all-N reads)"""
     rng = random.Random(L * 31 + stride)
     n = 2048 * 3 + 777
     reads = [rseq(rng, L, pn=pn, plow=0.05) for _ in range(n)]
@@ -361,7 +352,7 @@ def test_bit_sliced_kernel_matches_oracle(nt, L, stride, s_bits, pn):
     buf, _ = to_slots(reads, stride=stride)
     buf[buf == 10] = ord("A")  # padding bytes are base letters (ntc_submit_device's contract for the fast path)
     d = torch.from_numpy(buf).cuda()
-    with nt.Engine([32], r_bits=20, s_bits=s_bits, flags=nt.FLAG_BITSLICE_KERNEL) as e:
+    with nt.Engine([32], r_bits=20, s_bits=s_bits, flags=nt.FLAG_ALWAYS_LOG) as e:
         e.submit_device(d.data_ptr(), n, L, stride)
         tc, ph, f1 = e.finish(counters=True)
     oc, of1 = orc.sketch_reads(reads, [32], 0, 20, s_bits)
@@ -369,13 +360,13 @@ def test_bit_sliced_kernel_matches_oracle(nt, L, stride, s_bits, pn):
     assert np.array_equal(tc, oc)
 
 
-def test_bit_sliced_kernel_agrees_with_lane_kernel_at_size(nt):
-    """2 M genome-like reads (1 % substitutions, 0.05 % N): K1b + redo list vs K1 alone, counters compared on the device"""
+def test_log_and_adaptive_modes_agree_at_size(nt):
+    """2 M genome-like reads (1 % substitutions, 0.05 % N) in row slots: K1 with the hit log forced vs the adaptive engine, counters compared on the device"""
     n, L, stride = 2_000_000, 150, 152
     d = torch.empty(n * stride + 16, dtype=torch.uint8, device="cuda")
     nt.gen_reads_device(d.data_ptr(), 5, 0, n, L, stride, 1, genome_len=3_000_000)
     res = []
-    for flags in (nt.FLAG_BITSLICE_KERNEL, 0):
+    for flags in (nt.FLAG_ALWAYS_LOG, 0):
         with nt.Engine([32], r_bits=24, s_bits=7, flags=flags) as e:
             e.submit_device(d.data_ptr(), n, L, stride)
             _, ph, f1 = e.finish()

@@ -1,8 +1,8 @@
-"""GPU parity of the TILED path (ntc_submit_tiled_device -> K1c, ntc_sketch_ts.hip): the tiled streaming kernel against the
-CPU oracle on seeded and adversarial inputs (bit-exact), and against the real reference's full-size digests.
+"""GPU parity of the TILED path (ntc_submit_tiled_device -> K1h + K1f, ntc_sketch_k1h.hip / gen_k1h.py): the one-wave-per-tile kernel and its
+fix-up kernels against the CPU oracle on seeded and adversarial inputs (bit-exact), and against the real reference's full-size digests.
 
-K1c handles ntHashIterator's N semantics (ntHashIterator.hpp:59-86) inside the kernel, so the inputs lean on that: reads
-with many non-ACGTU bytes, all-N reads, lower case / U, partial tiles, read lengths around the 16-base chunks.
+ntHashIterator's N semantics (ntHashIterator.hpp:59-86) are K1f's job (K1h leaves every window near a non-ACGTU byte to it), so the inputs lean on
+that: reads with many non-ACGTU bytes, all-N reads, lower case / U, partial tiles, read lengths around the 16-base chunks.
 """
 import hashlib
 import json
@@ -34,21 +34,13 @@ def gen_host(n, L, dist, genome_len=200_000, seed=1):
     return [sl[i * stride: i * stride + L].tobytes() for i in range(n)]
 
 
-VARIANT_FLAGS = 0  # set per test by the `tiled_variant` fixture: 0 = the engine's choice (K1h where it is built, else K1c), or FLAG_TILED_TEAMS = K1c
-
-
-@pytest.fixture(autouse=True, params=["default", "teams"])
-def tiled_variant(request, nt):
-    """every test of this module runs twice: through the engine's default tiled kernel (K1h + K1f for k = 32, sBits = 7; K1c otherwise)
-    and with NTC_FLAG_TILED_TEAMS (K1c throughout)"""
-    global VARIANT_FLAGS
-    VARIANT_FLAGS = nt.FLAG_TILED_TEAMS if request.param == "teams" else 0
-    yield
-    VARIANT_FLAGS = 0
+VARIANT_FLAGS = 0  # (rounds 3-4 ran every test of this module a second time through K1c, NTC_FLAG_TILED_TEAMS; round 5 retired that kernel)
 
 
 def run_tiled(nt, reads, L, k=32, r_bits=18, s_bits=7, flags=0, pieces=1):
-    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | VARIANT_FLAGS | nt.FLAG_REQUIRE_TILED) as e:
+    # (K1h's table word holds r_bits + 1 + s_bits - 7 bits: a configuration beyond 32 is K1's, after a re-layout — the one case here that may fall back)
+    req = nt.FLAG_REQUIRE_TILED if r_bits + 1 + s_bits - 7 <= 32 else 0
+    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | VARIANT_FLAGS | req) as e:
         step = (len(reads) + pieces - 1) // pieces
         keep = []
         for i in range(0, len(reads), step):
@@ -119,7 +111,7 @@ def test_tiled_batches_and_modes(nt):
 
 @pytest.mark.parametrize("k", list(range(12, 32)))
 def test_tiled_kernel_every_k(nt, k):
-    """K1c is instantiated for k = 12 .. 32 (generated step bodies per k): reads of
+    """K1h is generated for k = 12 .. 32 (one assembly body per k): reads of
     exactly k and k + 1 bases, 97 and 150 bp, non-ACGTU bytes, sBits 7 / 8 / 11"""
     rng = np.random.default_rng(k)
     alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
@@ -133,7 +125,7 @@ def test_tiled_kernel_every_k(nt, k):
 @pytest.mark.parametrize("seed", range(8))
 def test_tiled_kernel_random_shapes(nt, seed):
     """random read length (32 .. 400), read count (partial last tile, one read, several tiles per team), sBits and rate of
-    non-ACGTU bytes: K1c's chunk / ring / window arithmetic has no special case for 150 bp"""
+    non-ACGTU bytes: K1h's chunk / ring / window arithmetic has no special case for 150 bp"""
     rng = np.random.default_rng(1000 + seed)
     k = int(rng.integers(12, 33))
     L = int(rng.integers(k, 401))
@@ -148,7 +140,7 @@ def test_tiled_kernel_random_shapes(nt, seed):
 
 
 def test_tiled_kernel_k_lists(nt):
-    """a list of k within 16 .. 32 is one K1c launch per k over the same tiles (ntRead's loop over kList, ntcard.cpp:147-158): planes and
+    """a list of k within 16 .. 32 is one K1h launch per k over the same tiles (ntRead's loop over kList, ntcard.cpp:147-158): planes and
     F1 per k as the oracle's; reads shorter than some of the k"""
     for klist, L, n in (([21, 25, 31], 150, 5000), ([32, 16, 24], 100, 2100), ([17, 29], 20, 3000), ([20, 32], 19, 100), ([12, 15, 13], 14, 2500)):
         reads = gen_host(n, L, 1)
@@ -215,8 +207,6 @@ def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     cfg = meta["configs"][name]
     n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
     buf = torch.empty(nt.tiled_bytes(R, L), dtype=torch.uint8, device="cuda")
-    if cfg["gap"] and VARIANT_FLAGS:
-        pytest.skip("K1c has no spaced-seed form")
     with nt.Engine(cfg["klist"], gap=cfg["gap"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
         for first in range(0, n, R):
             m = min(R, n - first)
@@ -243,7 +233,7 @@ def test_tiled_deferred_fixups(nt):
         n, L = 30_000 + 4000 * i, (150, 97, 64)[i % 3]
         arr = alpha[rng.integers(0, 4, size=(n, L))]
         arr = np.where(rng.random((n, L)) < 0.003, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
-        if i == 4 and VARIANT_FLAGS == 0:  # (K1c takes those bytes for non-bases: a documented deviation of that kernel only)
+        if i == 4:
             arr[rng.integers(0, n, size=50), rng.integers(0, L, size=50)] = np.array([1, 3, 4, 5, 7], dtype=np.uint8)[rng.integers(0, 5, size=50)]
         parts.append(arr)
         bufs.append(torch.from_numpy(tile_array(arr)).cuda())
@@ -272,7 +262,7 @@ def test_tiled_reference_table_slot_bytes_and_suspect_overflow(nt):
     arr = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L))]
     odd = np.array([1, 3, 4, 5, 7], dtype=np.uint8)
     arr = np.where(rng.random((n, L)) < 0.002, odd[rng.integers(0, 5, size=(n, L))], arr).astype(np.uint8)
-    if VARIANT_FLAGS == 0:  # (K1c takes those bytes for non-bases: a documented deviation of that kernel only)
+    if True:
         check(nt, [arr[i].tobytes() for i in range(n)], L)
     dense = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(400_000, 64))].astype(np.uint8)
     t = torch.from_numpy(tile_array(dense)).cuda()
@@ -295,8 +285,6 @@ def test_tiled_reference_table_slot_bytes_and_suspect_overflow(nt):
 def test_tiled_spaced_seed_k12_gap2(nt, n, L, p_bad, s_bits):
     """stRead with ntcard's -g seed (ntcard.cpp:160-171,407-413) through the tiled layout: K1h's (k = 12, gap = 2) variant, K1f with the
     spaced closed form (the last case overflows the suspect list: slow path)"""
-    if VARIANT_FLAGS:
-        pytest.skip("K1c has no spaced-seed form")
     rng = np.random.default_rng(n + L)
     alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
     arr = alpha[rng.integers(0, 4, size=(n, L))]

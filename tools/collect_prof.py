@@ -55,7 +55,7 @@ def main():
             if "sketch_" in k or "k1h_" in k:
                 hash_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
     open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
-    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) of the hash kernels per bench step (K1 / K1b + its redo pass)
+    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) of the hash kernels per bench step (K1h + K1f, or K1)
     if bench and hash_kernels:
         fetch = sum(v.get("FETCH_SIZE", 0.0) for v in hash_kernels.values())
         write = sum(v.get("WRITE_SIZE", 0.0) for v in hash_kernels.values())

@@ -53,9 +53,9 @@ for case in range(n_cases):
     oc, of1 = orc.sketch_reads(reads, klist, gap, r_bits, s_bits)
     ok = np.array_equal(f1, of1) and np.array_equal(tc, oc)
     if ok and mode == "equal" and L >= 1 and gap == 0:
-        # the same reads in the tiled layout: the streaming kernel K1c where it is built (every k of the list in 12 .. 32, sBits >= 7:
+        # the same reads in the tiled layout: the tiled kernel pair K1h + K1f where it is built (every k of the list in 12 .. 32, sBits >= 7:
         # then a fallback would be an error), the device-side re-layout + K1 otherwise; batches cut at the same places
-        k1c = all(12 <= k <= 32 for k in klist) and s_bits >= 7 and (len(klist) << (r_bits + 1)) <= (1 << 32)
+        k1c = all(12 <= k <= 32 for k in klist) and s_bits >= 7 and (len(klist) << (r_bits + 1)) <= (1 << 32) and r_bits + 1 + s_bits - 7 <= 32 and not (flags & nt.FLAG_LANE_KERNEL)
         with nt.Engine(klist, gap=gap, r_bits=r_bits, s_bits=s_bits, flags=flags | (nt.FLAG_REQUIRE_TILED if k1c else 0), log_entries=log_entries) as e:
             prev, keep = 0, []
             for c in cuts + [len(reads)]:
@@ -67,7 +67,7 @@ for case in range(n_cases):
             tc2, ph2, f12 = e.finish(counters=True)
         ok = np.array_equal(f12, of1) and np.array_equal(tc2, oc)
         if not ok: f1, tc = f12, tc2
-        mode = "equal+tiled(K1c)" if k1c else "equal+tiled(K1)"
+        mode = "equal+tiled(K1h)" if k1c else "equal+tiled(K1)"
     desc = "case %d: klist=%s gap=%d s=%d r=%d mode=%s L=%d n=%d pn=%g cuts=%s flags=%d log=%d" % (case, klist, gap, s_bits, r_bits, mode, L, len(reads), pn, cuts, flags, log_entries)
     if not ok:
         print("MISMATCH", desc, "f1", list(f1), list(of1), "diff counters", int(np.count_nonzero(tc != oc)))

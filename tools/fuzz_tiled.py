@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_tiled.py [n_cases] [seed] — randomised parity sweep of the TILED device path (K1h + K1f; K1c with NTC_FLAG_TILED_TEAMS) against
+"""tools/fuzz_tiled.py [n_cases] [seed] — randomised parity sweep of the TILED device path (K1h + K1f) against
 the oracle: k (every built variant, the spaced seed included), read length, batch sizes from one read to hundreds of tiles (many waves, block
 ranges that split tiles, the share-out by SIMD), sBits / rBits, rate and kind of non-base bytes (table-slot bytes 1, 3, 4, 5, 7 included),
 small hit logs (region switches, applies in mid-run), several submits per engine with deferred fix-ups.  Prints the first mismatch, exits 1."""
@@ -22,7 +22,7 @@ alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
 odd = np.array([1, 3, 4, 5, 7], dtype=np.uint8)
 
 for case in range(n_cases):
-    teams = rng.random() < 0.15
+    teams = False  # (round 3's kernel K1c, NTC_FLAG_TILED_TEAMS, was retired in round 5)
     gap = 0
     if not teams and rng.random() < 0.15:
         klist, gap = [12], 2
@@ -33,7 +33,7 @@ for case in range(n_cases):
     L = int(rng.choice([int(rng.integers(max(klist), 401)), 100, 150, 151, 250]))
     p_bad = float(rng.choice([0.0, 0.0005, 0.005, 0.05]))
     slot_bytes = (not teams) and rng.random() < 0.2
-    flags = nt.FLAG_REQUIRE_TILED | (nt.FLAG_TILED_TEAMS if teams else 0) | (nt.FLAG_DEFER_REDO if rng.random() < 0.6 else 0)
+    flags = nt.FLAG_REQUIRE_TILED | (nt.FLAG_DEFER_REDO if rng.random() < 0.6 else 0)
     log_entries = int(rng.choice([0, 1 << 18, 1 << 20]))
     n_sub = int(rng.choice([1, 1, 2, 5, 11]))
     sizes = [int(rng.choice([1, 70, 2048, 2049, 30_000, 200_000, 500_000])) for _ in range(n_sub)]

@@ -16,8 +16,8 @@ for p_bad in (0.0, 0.0005, 0.002, 0.005, 0.02, 0.1):
         arr = np.where(rng.random((n, L)) < p_bad, np.uint8(ord("N")), arr).astype(np.uint8)
     t = torch.from_numpy(np.ascontiguousarray(np.pad(arr, ((0, (-n) % 2048), (0, (-L) % 16)), constant_values=ord("A"))
                                               .reshape(-1, 2048, (L + 15) // 16, 16).transpose(0, 2, 1, 3)).reshape(-1)).cuda()
-    for teams in (0, nt.FLAG_TILED_TEAMS):
-        with nt.Engine([32], r_bits=27, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | nt.FLAG_DEFER_REDO | teams) as e:
+    for teams in (0,):
+        with nt.Engine([32], r_bits=27, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | nt.FLAG_DEFER_REDO) as e:
             for _ in range(3):
                 e.submit_tiled_device(t.data_ptr(), n, L)
             e.flush(); e.sync(); e.reset(); e.set_profiling(True)

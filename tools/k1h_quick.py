@@ -1,4 +1,4 @@
-"""quick GPU check of K1h + K1f against K1c and the oracle (development aid)"""
+"""quick GPU check of K1h + K1f against the oracle (development aid)"""
 import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
