@@ -339,16 +339,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def value_hist(counters, hist):
-        nt.value_hist_device(counters.data_ptr(), counters.numel(), hist.data_ptr(), device=local_rank, stream=stream)
-
     def warm(e):
         for _ in range(W):
             submit_to(e, wb)
         if W > 0:
             e.flush()  # warm the deferred sketch update too (allocates its partition scratch)
         if use_dist and W > 0:  # warm the RCCL path too (same collectives as the timed merge)
-            parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0)
+            parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, dst=0)
         e.sync()
 
     def timed_region(e):
@@ -363,8 +360,9 @@ def main():
         merged, merge_t = None, {}
         if use_dist:
             # the path's one exchange step: all-to-all of the 16-bit counter slices, wrapping local sums, per-rank value
-            # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms
-            merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, value_hist, dst=0, timings=merge_t)
+            # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms; narrowing,
+            # sums and histograms are the library's kernels (ntc_narrow_u16_device / ntc_sum_slices_u16_device / ntc_value_hist_u16_device)
+            merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, dst=0, timings=merge_t)
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -151,6 +151,17 @@ int ntc_finish(ntc_engine *e, uint16_t *t_counter_out, uint32_t *p_hist_out, uin
  * only the 256 KiB histograms travel to rank 0 (ntcard_amd/parallel.py).                                      */
 int ntc_value_hist_device(int32_t device, void *stream, const void *d_counters_u32, uint64_t n, void *d_hist_u32);
 
+/* The device steps of the multi-GPU merge for a caller that moves the counter slices itself — one process per GPU, the slices travel in one RCCL
+ * all-to-all (ntcard_amd/parallel.py) — the same kernels ntc_merge_devices runs between its peer copies.  t_Counter wraps at 16 bits
+ * (ntcard.cpp:142-143,439), so only the low halves travel:
+ *   ntc_narrow_u16_device      d_out_u16[i] = d_counters_u32[i] mod 2^16, i < n
+ *   ntc_sum_slices_u16_device  slice 0 += slices 1 .. n_slices - 1 (wrapping 16-bit adds); slice r = d_slices_u16[r * stride, r * stride + len)
+ *   ntc_value_hist_u16_device  ++d_hist_u32[d_counters_u16[i]], i < n (compEst's first loop, ntcard.cpp:240-247, over a summed slice)
+ * All asynchronous on `stream`; buffers 16-byte aligned, stride a multiple of 8 elements.                                              */
+int ntc_narrow_u16_device(int32_t device, void *stream, const void *d_counters_u32, uint64_t n, void *d_out_u16);
+int ntc_sum_slices_u16_device(int32_t device, void *stream, void *d_slices_u16, uint64_t stride, uint32_t n_slices, uint64_t len);
+int ntc_value_hist_u16_device(int32_t device, void *stream, const void *d_counters_u16, uint64_t n, void *d_hist_u32);
+
 /* Sketch load / merge: adds a t_Counter image dumped by ntc_finish (same k list, r_bits;
  * uint16 [n_k][2][1<<r_bits]) and its F1 values (may be NULL) into this engine.  Counting is a commutative sum
  * mod 2^16 (ntcard.cpp:142-143), so runs split across processes, nodes or days merge exactly.               */

@@ -16,6 +16,7 @@ ABI_SYMBOLS = [
     "ntc_hash_dump_device", "ntc_hash_dump_k1_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
     "ntc_kernel_time", "ntc_apply_time", "ntc_fixup_time", "ntc_merge_allocations", "ntc_update_mode", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
     "ntc_submit_tiled_device", "ntc_tiled_bytes", "ntc_gen_reads_tiled_device",
+    "ntc_narrow_u16_device", "ntc_sum_slices_u16_device", "ntc_value_hist_u16_device",
 ]
 
 
@@ -79,6 +80,9 @@ def lib():
     L.ntc_merge_counters.argtypes = [p, p, p]
     L.ntc_merge_devices.argtypes = [C.POINTER(p), i32]
     L.ntc_value_hist_device.argtypes = [i32, p, p, u64, p]
+    L.ntc_narrow_u16_device.argtypes = [i32, p, p, u64, p]
+    L.ntc_sum_slices_u16_device.argtypes = [i32, p, p, u64, u32, u64]
+    L.ntc_value_hist_u16_device.argtypes = [i32, p, p, u64, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_hash_dump_k1_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]

@@ -1531,6 +1531,38 @@ int ntc_value_hist_device(int32_t device, void* stream, const void* d_counters_u
 	return 0;
 }
 
+// The three device steps of the multi-GPU merge for a caller that moves the slices itself (one process per GPU: RCCL all-to-all under
+// torch.distributed, ntcard_amd/parallel.py) — the kernels ntc_merge_devices runs between its peer copies
+int ntc_narrow_u16_device(int32_t device, void* stream, const void* d_counters_u32, uint64_t n, void* d_out_u16)
+{
+	if (!d_counters_u32 || !d_out_u16) return fail(NTC_ERR_ARG, "ntc_narrow_u16_device: null buffer");
+	if (((uintptr_t)d_counters_u32 & 15u) || ((uintptr_t)d_out_u16 & 15u)) return fail(NTC_ERR_ARG, "ntc_narrow_u16_device: need 16-byte aligned buffers");
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(ntc::launch_narrow_u16((const uint32_t*)d_counters_u32, (uint16_t*)d_out_u16, n, (hipStream_t)stream));
+	return 0;
+}
+
+int ntc_sum_slices_u16_device(int32_t device, void* stream, void* d_slices_u16, uint64_t stride, uint32_t n_slices, uint64_t len)
+{
+	if (!d_slices_u16) return fail(NTC_ERR_ARG, "ntc_sum_slices_u16_device: null buffer");
+	if (((uintptr_t)d_slices_u16 & 15u) || (stride & 7u) || len > stride) return fail(NTC_ERR_ARG, "ntc_sum_slices_u16_device: need 16-byte aligned slices, stride %% 8 == 0, len <= stride");
+	if (n_slices <= 1 || len == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(ntc::launch_sum_slices_u16((uint16_t*)d_slices_u16, stride, n_slices, len, (hipStream_t)stream));
+	return 0;
+}
+
+int ntc_value_hist_u16_device(int32_t device, void* stream, const void* d_counters_u16, uint64_t n, void* d_hist_u32)
+{
+	if (!d_counters_u16 || !d_hist_u32) return fail(NTC_ERR_ARG, "ntc_value_hist_u16_device: null buffer");
+	if ((uintptr_t)d_counters_u16 & 15u) return fail(NTC_ERR_ARG, "ntc_value_hist_u16_device: need 16-byte aligned counters");
+	if (n == 0) return 0;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(ntc::launch_value_hist_u16((const uint16_t*)d_counters_u16, n, (uint32_t*)d_hist_u32, (hipStream_t)stream));
+	return 0;
+}
+
 int ntc_merge_counters(ntc_engine* e, const uint16_t* t_counter, const uint64_t* f1)
 {
 	if (!e || !t_counter) return fail(NTC_ERR_ARG, "ntc_merge_counters: null argument");

@@ -588,6 +588,49 @@ hipError_t launch_finalize(const uint32_t* sketch, uint64_t n_per_sample, uint32
 	return hipGetLastError();
 }
 
+// the same for counters that are already 16 bits wide (a summed slice of the multi-GPU merge): ADDED to p_hist[65536]
+__global__ __launch_bounds__(256) void value_hist_u16_kernel(const uint16_t* __restrict__ src, uint64_t n, uint32_t* __restrict__ p)
+{
+	constexpr uint32_t kLocal = 2048;
+	__shared__ uint32_t lh[kLocal];
+	for (uint32_t i = threadIdx.x; i < kLocal; i += blockDim.x)
+		lh[i] = 0;
+	__syncthreads();
+	uint32_t zeros = 0;
+	const uint64_t n8 = n / 8;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+			if (c == 0)
+				++zeros;
+			else if (c < kLocal)
+				atomicAdd(&lh[c], 1u);
+			else
+				atomicAdd(p + c, 1u);
+		}
+	}
+	if (blockIdx.x == 0)
+		for (uint64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) {
+			const uint32_t c = src[i];
+			if (c == 0) ++zeros;
+			else atomicAdd(p + c, 1u);
+		}
+	for (int o = 32; o > 0; o >>= 1)
+		zeros += __shfl_xor(zeros, o);
+	if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(p, zeros);
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < kLocal; i += blockDim.x)
+		if (lh[i]) atomicAdd(p + i, lh[i]);
+}
+hipError_t launch_value_hist_u16(const uint16_t* counters, uint64_t n, uint32_t* p_hist, hipStream_t st)
+{
+	hipLaunchKernelGGL(value_hist_u16_kernel, dim3(2048), dim3(256), 0, st, counters, n, p_hist);
+	return hipGetLastError();
+}
+
 // value histogram of an arbitrary run of counters (one "sample" of n counters), ADDED to p_hist[65536]
 hipError_t launch_value_hist(const uint32_t* counters, uint64_t n, uint32_t* p_hist, hipStream_t st)
 {

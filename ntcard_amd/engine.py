@@ -247,6 +247,21 @@ def value_hist_device(d_counters_ptr, n, d_hist_ptr, device=0, stream=None):
                                            C.c_void_p(d_hist_ptr)))
 
 
+def narrow_u16_device(d_counters_ptr, n, d_out_ptr, device=0, stream=None):
+    """d_out (uint16[n]) = the low halves of n device uint32 counters (t_Counter wraps at 16 bits: all the merge has to move)"""
+    check(_abi.lib().ntc_narrow_u16_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_counters_ptr), n, C.c_void_p(d_out_ptr)))
+
+
+def sum_slices_u16_device(d_slices_ptr, stride, n_slices, length, device=0, stream=None):
+    """slice 0 += slices 1 .. n_slices - 1 with wrapping 16-bit adds; slice r = uint16[r * stride : r * stride + length]"""
+    check(_abi.lib().ntc_sum_slices_u16_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_slices_ptr), stride, n_slices, length))
+
+
+def value_hist_u16_device(d_counters_ptr, n, d_hist_ptr, device=0, stream=None):
+    """accumulate the value histogram of n device uint16 counters into a device uint32[65536]"""
+    check(_abi.lib().ntc_value_hist_u16_device(device, C.c_void_p(stream) if stream else None, C.c_void_p(d_counters_ptr), n, C.c_void_p(d_hist_ptr)))
+
+
 def hash_dump_device(d_slots_ptr, n_reads, read_len, stride, k, gap, max_win, d_hash_ptr, d_count_ptr, device=0, stream=None, k1=False):
     """every canonical (spaced-seed when gap != 0) hash of every clean window; k1=True: out of the production kernel K1"""
     fn = _abi.lib().ntc_hash_dump_k1_device if k1 else _abi.lib().ntc_hash_dump_device

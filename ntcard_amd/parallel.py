@@ -67,18 +67,34 @@ class _Phases:
         return out
 
 
+def _dev_args(t):
+    """(device index, current stream handle) of a CUDA tensor, for the library's device entry points"""
+    return t.device.index or 0, torch.cuda.current_stream(t.device).cuda_stream
+
+
 def exchange_and_sum_u16(sketch, shard, phases=None):
-    """Slice `rank` of the SUM over ranks of the counters modulo 2^16, as an int32 tensor of values 0..65535.
+    """Slice `rank` of the SUM over ranks of the counters modulo 2^16, as an int16 tensor (the uint16 bit patterns).
 
     t_Counter is uint16 with wrap-around (ntcard.cpp:142-143,439), so only the low 16 bits of every per-rank counter
     matter for the merged sketch: (sum_r c_r) mod 2^16 == (sum_r (c_r mod 2^16)) mod 2^16.  Every rank therefore narrows
     its counters to 16 bits, sends slice j to rank j (ONE all-to-all: 512 MiB·(N-1)/N per rank and k instead of the 1 GiB
     a uint32 reduce-scatter moves, and every one of a rank's point-to-point xGMI links carries exactly one slice at the
     same time, where a ring reduce-scatter makes N-1 dependent hops) and adds up the N slices it received with a
-    wrapping 16-bit add.  RCCL has no 16-bit integer SUM; none is needed.  gloo has no all-to-all for this either: the CPU
-    tests run the same exchange as batched isend/irecv."""
+    wrapping 16-bit add.  RCCL has no 16-bit integer SUM; none is needed.
+
+    Device tensors: the narrowing and the sums are the LIBRARY's kernels (ntc_narrow_u16_device / ntc_sum_slices_u16_device, the ones
+    ntc_merge_devices runs between its peer copies — one merge implementation, round 5); only the all-to-all is torch.distributed's.
+    CPU tensors (the gloo tests of this module's slicing and wrap arithmetic): the same steps as torch expressions, the exchange as
+    batched isend/irecv (gloo has no all-to-all for this)."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    low = sketch.to(torch.int16)  # int32 -> int16 keeps the low 16 bits (two's complement)
+    on_gpu = sketch.is_cuda
+    if on_gpu:
+        from . import engine as _eng
+        dev, st = _dev_args(sketch)
+        low = torch.empty(sketch.numel(), dtype=torch.int16, device=sketch.device)
+        _eng.narrow_u16_device(sketch.data_ptr(), sketch.numel(), low.data_ptr(), device=dev, stream=st)
+    else:
+        low = sketch.to(torch.int16)  # int32 -> int16 keeps the low 16 bits (two's complement)
     recv = torch.empty(world * shard, dtype=torch.int16, device=sketch.device)
     if phases:
         phases.mark("narrow")
@@ -96,23 +112,27 @@ def exchange_and_sum_u16(sketch, shard, phases=None):
         dist.all_to_all_single(recv.view(torch.uint8), low.view(torch.uint8))  # bytes: RCCL has no 16-bit integer type, and none is needed to move them
     if phases:
         phases.mark("exchange")
-    parts = recv.view(world, shard)
-    acc = parts[0].clone()
-    for r in range(1, world):
-        acc += parts[r]  # int16 addition wraps: exactly the uint16 counter arithmetic
-    out = acc.to(torch.int32) & 0xFFFF
+    if on_gpu:
+        _eng.sum_slices_u16_device(recv.data_ptr(), shard, world, shard, device=dev, stream=st)  # slice 0 += the others (wrapping)
+        out = recv[:shard]
+    else:
+        parts = recv.view(world, shard)
+        out = parts[0].clone()
+        for r in range(1, world):
+            out += parts[r]  # int16 addition wraps: exactly the uint16 counter arithmetic
     if phases:
         phases.mark("sum")
     return out
 
 
-def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0, timings=None):
+def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist=None, dst=0, timings=None):
     """Multi-GPU merge for the estimator (compEst only needs the value histogram p[2][65536] of the SUMMED counters,
     ntcard.cpp:240-247): every rank ends up with one slice of the summed uint16 counters (exchange_and_sum_u16),
     histograms that slice locally, and only the histograms (256 KiB per plane) and F1 go to rank `dst`.
 
     sketch: int32 tensor [n_k * 2 * 2^r_bits] (uint32 counters), f1: int64 [n_k]; f1 is reduced in place.
-    value_hist(counters_slice, hist_slice): accumulates the histogram of (counter & 0xffff) into an int32[65536] view.
+    value_hist(counters_u16_slice, hist_slice): accumulates the histogram of the uint16 counters (an int16 tensor of their bit patterns)
+    into an int32[65536] view; None: the library's ntc_value_hist_u16_device for device tensors, torch.bincount for CPU tensors.
     Returns (p_hist int32 [n_k, 2, 65536], f1) — meaningful on rank dst.  timings: a dict that receives narrow_ms / exchange_ms / sum_ms /
     histogram_ms / reduce_ms / total_ms of this rank (bench.py reports them so that a scaling run separates hashing from the merge)."""
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -120,8 +140,18 @@ def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist, dst=0, timing
     ph.mark("start")
     plane = 1 << r_bits
     n = sketch.numel()
-    assert n == n_k * 2 * plane and n % world == 0 and (n // world) % 4 == 0
+    assert n == n_k * 2 * plane and n % world == 0 and (n // world) % 8 == 0
     shard = n // world
+    if value_hist is None:
+        if sketch.is_cuda:
+            from . import engine as _eng
+            dev, st = _dev_args(sketch)
+
+            def value_hist(c, h):
+                _eng.value_hist_u16_device(c.data_ptr(), c.numel(), h.data_ptr(), device=dev, stream=st)
+        else:
+            def value_hist(c, h):
+                h += torch.bincount(c.to(torch.int32) & 0xFFFF, minlength=65536).to(torch.int32)
     mine = exchange_and_sum_u16(sketch, shard, ph)
     hist = torch.zeros(n_k * 2 * 65536, dtype=torch.int32, device=sketch.device)
     pos, end = rank * shard, (rank + 1) * shard

@@ -96,10 +96,7 @@ def _hist_worker(rank, world, port, out_dir):
     sk[5] += 50000  # the merged counter wraps past 65535
     sk[9] += 70000 + rank  # a per-rank uint32 counter that is itself past 65535 (only its low 16 bits may count)
 
-    def value_hist(c, h):
-        h += torch.bincount((c & 0xFFFF).to(torch.int64), minlength=65536).to(torch.int32)
-
-    ph, f1t = parallel.merge_to_value_histograms(sk, torch.from_numpy(f1.astype(np.int64)), len(klist), RB, value_hist, dst=0)
+    ph, f1t = parallel.merge_to_value_histograms(sk, torch.from_numpy(f1.astype(np.int64)), len(klist), RB, dst=0)  # (CPU tensors: torch arithmetic)
     if rank == 0:
         np.save(os.path.join(out_dir, "ph.npy"), ph.numpy())
         np.save(os.path.join(out_dir, "f1.npy"), f1t.numpy())

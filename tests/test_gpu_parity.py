@@ -702,6 +702,33 @@ def test_value_hist_device_matches_numpy(nt):
     assert np.array_equal(h.cpu().numpy().astype(np.int64), want)
 
 
+def test_merge_step_kernels_match_numpy(nt):
+    """the device steps of the one-process-per-GPU merge (ntc_narrow_u16_device, ntc_sum_slices_u16_device, ntc_value_hist_u16_device: what
+    parallel.exchange_and_sum_u16 runs around the RCCL all-to-all): low halves, wrapping 16-bit sums of slices, histogram of uint16 counters"""
+    rng = np.random.default_rng(11)
+    n, world = (1 << 18) + 8, 5
+    c = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    d = torch.from_numpy(c.view(np.int32)).cuda()
+    low = torch.empty(n, dtype=torch.int16, device="cuda")
+    nt.narrow_u16_device(d.data_ptr(), n, low.data_ptr())
+    assert np.array_equal(low.cpu().numpy().view(np.uint16), (c & 0xFFFF).astype(np.uint16))
+    sl = rng.integers(0, 1 << 16, size=(world, n), dtype=np.uint32).astype(np.uint16)
+    sl[:, :16] = 0xFFFF  # sums that wrap several times
+    ds = torch.from_numpy(sl.view(np.int16).reshape(-1)).cuda()
+    nt.sum_slices_u16_device(ds.data_ptr(), n, world, n - 3)  # (a length that is no multiple of 8: the scalar tail)
+    got = ds.cpu().numpy().view(np.uint16).reshape(world, n)
+    want = sl.astype(np.uint32).sum(axis=0).astype(np.uint16)
+    assert np.array_equal(got[0, : n - 3], want[: n - 3]) and np.array_equal(got[0, n - 3:], sl[0, n - 3:]) and np.array_equal(got[1:], sl[1:])
+    h = torch.zeros(65536, dtype=torch.int32, device="cuda")
+    u = rng.integers(0, 70000, size=n - 5, dtype=np.uint32).astype(np.uint16)
+    u[::5] = 0
+    du = torch.from_numpy(np.concatenate([u, np.zeros(5, np.uint16)]).view(np.int16)).cuda()
+    nt.value_hist_u16_device(du.data_ptr(), n - 5, h.data_ptr())
+    nt.value_hist_u16_device(du.data_ptr(), 4096, h.data_ptr())  # accumulates
+    torch.cuda.synchronize()
+    assert np.array_equal(h.cpu().numpy().astype(np.int64), np.bincount(u, minlength=65536) + np.bincount(u[:4096], minlength=65536))
+
+
 def test_bench_under_torchrun_single_rank(tmp_path):
     """the multi-GPU code path of bench.py (RCCL init, all-to-all slice exchange, histogram reduce) with one rank"""
     import json
