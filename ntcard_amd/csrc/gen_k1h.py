@@ -435,9 +435,19 @@ class Gen:
         p = self.p
         r = V_RAW + 4 * i
         t = [V_T0 + 12 + 6 * (i % 3) + x for x in range(6)]  # three sets of scratch registers: the scheduler interleaves neighbouring groups
+        # 2 x code of every byte: (ascii >> 1) & 3 = A 0, C 1, T / U 2, G 3 — the multiply-gather's input AND the index of the validity look-up:
+        # the letter that code stands for (A, C, T, G), XORed with the byte, is zero or the case bit for exactly the bytes ACGTacgt.  (Round 4 looked
+        # the letter up by byte & 7, which told U from T at the price of four more v_and per 16 bases; now a U is "dirty": its windows are K1f's,
+        # which knows that U is a base — exact, slower for reads that are RNA.)
+        x, e = t[4], t[5]
         for q in range(4):
             p.i("v_and_b32", v(t[q]), "0x06060606", v(r + q))
         for q in range(4):
+            p.i("v_perm_b32", v(e), s(S_EXP0), v(V_EXP1), v(t[q]))
+            if q == 0:
+                p.i("v_xor_b32", v(x), v(e), v(r + q))
+            else:
+                self.bitop3(v(x), v(e), v(r + q), v(x), lambda a, b, c: (a ^ b) | c)
             if "nomul" in self.exp:
                 p.i("v_lshlrev_b32", v(t[q]), 3, v(t[q]))
             else:
@@ -445,18 +455,6 @@ class Gen:
         p.i("v_perm_b32", v(t[0]), v(t[1]), v(t[0]), v(V_CPERMLO))
         p.i("v_perm_b32", v(t[2]), v(t[3]), v(t[2]), v(V_CPERMHI))
         p.i("v_or_b32", v(dst), v(t[0]), v(t[2]))
-        # validity: the letter (byte & 7) may stand for, XORed with the byte (zero or the case bit for a base letter)
-        x = t[4]
-        for q in range(4):
-            p.i("v_and_b32", v(t[q]), "0x07070707", v(r + q))
-            if "noperm" in self.exp:
-                p.i("v_xor_b32", v(t[q]), v(V_EXP1), v(t[q]))
-            else:
-                p.i("v_perm_b32", v(t[q]), s(S_EXP0), v(V_EXP1), v(t[q]))
-            if q == 0:
-                p.i("v_xor_b32", v(x), v(t[q]), v(r + q))
-            else:
-                self.bitop3(v(x), v(t[q]), v(r + q), v(x), lambda a, b, c: (a ^ b) | c)
         p.i("v_and_b32", v(x), "0xdfdfdfdf", v(x))
         if "nocarry" in self.exp:
             p.i("v_or_b32", v(V_DN), v(V_DN), v(x))
@@ -919,7 +917,7 @@ class Gen:
         p.i("s_add_u32", s(S_SUS), s(S_SUS), s(S_A))
         p.i("s_addc_u32", s(S_SUS + 1), s(S_SUS + 1), s(S_B))
         p.i("s_mov_b32", s(S_SUSOFF), 0)
-        p.i("s_mov_b32", s(S_EXP0), "0x47ff5554")
+        p.i("s_mov_b32", s(S_EXP0), "0xff47ff54")         # validity look-up, codes 2 and 3: T, G
         if self.sb != 7:
             p.i("s_load_dword", s(S_SPARE), sr(S_KARG, 2), hex(KARG["s_bits"]))
             p.i("s_waitcnt", "lgkmcnt(0)")
@@ -936,7 +934,7 @@ class Gen:
         p.i("v_lshlrev_b32", v(V_LANE16), 4, v(V_LANE4))
         p.i("v_lshlrev_b32", v(V_LANE4), 2, v(V_LANE4))
         p.i("v_mov_b32", v(V_ONE), 1)
-        p.i("v_mov_b32", v(V_EXP1), "0x43ff41ff")
+        p.i("v_mov_b32", v(V_EXP1), "0xff43ff41")         # codes 0 and 1: A, C
         p.i("s_add_u32", s(S_A), s(S_RQ[0]), RING_BYTES)
         p.i("v_mov_b32", v(V_QBASE), s(S_A))
         p.i("v_mov_b32", v(V_QDUMMY), QCAP * 4)

@@ -1,4 +1,5 @@
-"""Full-size parity (BASELINE.json configs 2, 4, 5 and config 3's sBits=11 sampling: 100 M synthetic 150 bp reads) inside
+"""Full-size parity (BASELINE.json configs 2, 4, 5 — both spaced seeds of SURVEY 8(d): -k 12 -g 2 and -k 32 -g 8 —, config 3's sBits=11 sampling: 100 M
+synthetic 150 bp reads; rBits = 24 on 20 M) inside
 the driver-run GPU suite.
 
 The goldens under tests/golden/fullsize/ were produced in the build container by the REAL reference
@@ -27,13 +28,13 @@ def _meta():
 
 
 @pytest.mark.parametrize("name,flags", [("cfg2", 0), ("cfg2u", 0), ("cfg4", 0), ("cfg5", 0), ("cfg2", 8), ("cfg2u", 2),
-                                        ("cfg3s", 0), ("cfg3s", 8), ("cfg4", 8)])  # row slots: K1, adaptive / 8 = log forced / 2 = direct atomics
+                                        ("cfg3s", 0), ("cfg3s", 8), ("cfg4", 8), ("cfg5b", 0), ("cfg2r24", 0)])  # row slots: K1, adaptive / 8 = log forced / 2 = direct atomics
 def test_fullsize_matches_reference_goldens(name, flags, tmp_path):
     assert torch.cuda.is_available(), "GPU tests need a HIP device (run on the MI355X box)"
     import ntcard_amd as nt
     meta = _meta()
     cfg = meta["configs"][name]
-    n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
+    n, L, rb, sb, cov = cfg.get("n_reads", meta["n_reads"]), meta["read_len"], cfg.get("r_bits", meta["r_bits"]), cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
     stride, R = 152, 10_000_000
     buf = torch.empty(R * stride + 16, dtype=torch.uint8, device="cuda")
     with nt.Engine(cfg["klist"], gap=cfg["gap"], r_bits=rb, s_bits=sb, flags=flags) as e:

@@ -198,14 +198,15 @@ def test_tiled_layout_falls_back_for_other_configurations(nt):
                 e.submit_tiled_device(t.data_ptr(), len(reads), 150)
 
 
-@pytest.mark.parametrize("name,R", [("cfg2", 10_000_000), ("cfg2u", 10_000_000), ("cfg3s", 10_000_000), ("cfg2", 50_000_000), ("cfg5", 10_000_000)])
+@pytest.mark.parametrize("name,R", [("cfg2", 10_000_000), ("cfg2u", 10_000_000), ("cfg3s", 10_000_000), ("cfg2", 50_000_000), ("cfg5", 10_000_000),
+                                    ("cfg2r24", 10_000_000)])  # (cfg2r24: rBits = 24, 20 M reads — a sketch of another size through NTC_FLAG_REQUIRE_TILED)
 def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     """100 M synthetic reads through the tiled kernel against the digests of the REAL reference (see test_fullsize_gpu.py); the
     50 M-read batches make every team of waves walk ~48 tiles in one launch (tile tags of deferred work wrap many times)"""
     with open(os.path.join(GOLD, "digests.json")) as f:
         meta = json.load(f)
     cfg = meta["configs"][name]
-    n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
+    n, L, rb, sb, cov = cfg.get("n_reads", meta["n_reads"]), meta["read_len"], cfg.get("r_bits", meta["r_bits"]), cfg.get("s_bits", meta["s_bits"]), meta["cov_max"]
     buf = torch.empty(nt.tiled_bytes(R, L), dtype=torch.uint8, device="cuda")
     with nt.Engine(cfg["klist"], gap=cfg["gap"], r_bits=rb, s_bits=sb, flags=nt.FLAG_REQUIRE_TILED | VARIANT_FLAGS) as e:
         for first in range(0, n, R):

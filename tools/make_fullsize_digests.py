@@ -21,12 +21,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "oracle", "_ref", "ref_tool")
 OUT = os.path.join(ROOT, "tests", "golden", "fullsize")
 
-CONFIGS = [  # (name, dist, klist, gap, s_bits)
+CONFIGS = [  # (name, dist, klist, gap, s_bits[, r_bits, n_reads])
     ("cfg2", 1, [32], 0, 7),
     ("cfg2u", 0, [32], 0, 7),
     ("cfg4", 1, [32, 64, 96, 128], 0, 7),
     ("cfg5", 1, [12], 2, 7),
     ("cfg3s", 1, [32], 0, 11),  # config 3's sampling (the >= 50 GB branch of ntcard.cpp:427-431: sBits = 11), one GPU's share of reads
+    ("cfg5b", 1, [32], 8, 7),   # SURVEY 8(d)'s other spaced seed: -k 32 -g 8 (round 5)
+    ("cfg2r24", 1, [32], 0, 7, 24, 20_000_000),  # a sketch of another size (-b: rBits = 24), 20 M reads (round 5)
 ]
 
 
@@ -51,14 +53,17 @@ def main():
         assert old["n_reads"] == n, "partial regeneration must keep n_reads"
         meta["configs"] = old["configs"]
     with tempfile.TemporaryDirectory() as tmp:
-        for name, dist, klist, gap, s_bits in CONFIGS:
+        for name, dist, klist, gap, s_bits, *rest in CONFIGS:
             if only and name not in only:
                 continue
+            r_bits, n_cfg = (rest + [27, n])[:2] if rest else (27, n)
             prefix = os.path.join(tmp, name)
-            cmd = [TOOL, "fullsize", "1", str(n), "150", str(dist), ",".join(map(str, klist)), str(gap), "27", str(s_bits), str(threads), prefix]
+            cmd = [TOOL, "fullsize", "1", str(n_cfg), "150", str(dist), ",".join(map(str, klist)), str(gap), str(r_bits), str(s_bits), str(threads), prefix]
             out = subprocess.run(cmd, stdout=subprocess.PIPE, check=True).stdout.decode()
             f1 = {int(l.split()[0][2:]): int(l.split()[1][3:]) for l in out.strip().splitlines()}
             ent = {"dist": dist, "klist": klist, "gap": gap, "s_bits": s_bits, "planes": []}
+            if rest:
+                ent["r_bits"], ent["n_reads"] = r_bits, n_cfg
             for k in klist:
                 hist = open(f"{prefix}_k{k}.hist", "rb").read()
                 gold = f"{name}_k{k}.hist"
