@@ -253,7 +253,7 @@ def main():
         args.k, args.gap = 12, 2
     if args.layout == "auto":
         kl = klist_of(args)
-        k1h_gap = len(kl) == 1 and kl[0] == 12 and args.gap == 2  # K1h's spaced-seed variant (config 5)
+        k1h_gap = len(kl) == 1 and (kl[0], args.gap) in ((12, 2), (32, 8))  # K1h's spaced-seed variants (config 5 in both forms of SURVEY 8(d))
         args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and (args.gap == 0 or k1h_gap) and args.s_bits >= 7 and not args.lane_kernel) else "rows"
     import torch
     import torch.distributed as dist
@@ -412,7 +412,7 @@ def main():
         step_ms = (ker_ms + apply_ms + fix_ms) / max(K, 1)  # (fix_ms: the deferred K1f launches, one per up to 8 batches, on the engine's stream like everything else)
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
-        if (tiled and ((all(12 <= k <= 32 for k in klist) and not args.gap) or (klist == [12] and args.gap == 2)) and args.s_bits >= 7
+        if (tiled and ((all(12 <= k <= 32 for k in klist) and not args.gap) or (nk == 1 and (klist[0], args.gap) in ((12, 2), (32, 8)))) and args.s_bits >= 7
                 and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel):
             kern = "sketch_k1h_kernel (K1h: one wave per tile, eight waves per CU) + k1h_fix_kernel / k1h_slow_kernel (K1f: one launch per up to 8 batches)"
         else:

@@ -125,7 +125,7 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
  * prefix of a tiled buffer is a valid batch.  All reads of a batch have the same length.  Asynchronous on the engine's
  * stream; the buffer may be reused as soon as the stream has passed the call — unless the engine was created with
  * NTC_FLAG_DEFER_REDO, see there.  A list of k is served by one launch per k.  Configurations the tiled kernels are not
- * built for (a k outside 12 .. 32, spaced seeds other than ntcard's -g seed at k = 12 / gap 2, nthll, sBits < 7) are re-laid
+ * built for (a k outside 12 .. 32, spaced seeds other than ntcard's -g seed at k = 12 / gap 2 or k = 32 / gap 8, nthll, sBits < 7) are re-laid
  * out on the device and take the general kernel: same results, not the fast path.  Host batches of (mostly) equal-length
  * reads reach the same kernels: ntc_submit / ntc_submit_spans pack them into tiles in pinned staging.                   */
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);

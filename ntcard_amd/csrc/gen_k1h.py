@@ -1209,8 +1209,9 @@ def render_inc(k, sb, gap=0):
         "\n".join(ln + " \\" for ln in body.split("\n")) + "\n\n"
 
 
-# (k, gap) the library is built with: every plain k of 12 .. 32, and ntcard's -g seed of BASELINE config 5 (k = 12, gap 2)
-VARIANTS = tuple((k, 0) for k in range(12, 33)) + ((12, 2),)
+# (k, gap) the library is built with: every plain k of 12 .. 32, and ntcard's -g seed in the two forms SURVEY 8(d) names for BASELINE config 5
+# (k = 12 / gap 2: round 4; k = 32 / gap 8: round 5)
+VARIANTS = tuple((k, 0) for k in range(12, 33)) + ((12, 2), (32, 8))
 PARTS = 4                      # the kernels are spread over this many objects (k % PARTS) so that `make -j` compiles them side by side
 
 

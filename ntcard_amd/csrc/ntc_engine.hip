@@ -1005,7 +1005,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			want = e->log_cap / 2;
 		}
 	}
-	// The tiled kernel pair K1h + K1f: every k of the list must be one K1h is generated for (k = 12 .. 32; ntcard's -g seed at k = 12 / gap 2); a list is
+	// The tiled kernel pair K1h + K1f: every k of the list must be one K1h is generated for (k = 12 .. 32; ntcard's -g seed at k = 12 / gap 2 and k = 32 / gap 8); a list is
 	// served by one launch per k over the same resident tiles.  Its hit-log keys and K1f's atomics are 32-bit counter indices.  Everything else —
 	// row slots, other k, other seeds, nthll — is K1's (NTC_FLAG_LANE_KERNEL: tiled batches too, re-laid out as row slots).
 	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->hll_bits == 0 && e->klist.size() * e->plane_elems() <= (1ull << 32);

@@ -199,7 +199,7 @@ def test_tiled_layout_falls_back_for_other_configurations(nt):
 
 
 @pytest.mark.parametrize("name,R", [("cfg2", 10_000_000), ("cfg2u", 10_000_000), ("cfg3s", 10_000_000), ("cfg2", 50_000_000), ("cfg5", 10_000_000),
-                                    ("cfg2r24", 10_000_000)])  # (cfg2r24: rBits = 24, 20 M reads — a sketch of another size through NTC_FLAG_REQUIRE_TILED)
+                                    ("cfg2r24", 10_000_000), ("cfg5b", 10_000_000)])  # (cfg2r24: rBits = 24, 20 M reads — a sketch of another size through NTC_FLAG_REQUIRE_TILED)
 def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     """100 M synthetic reads through the tiled kernel against the digests of the REAL reference (see test_fullsize_gpu.py); the
     50 M-read batches make every team of waves walk ~48 tiles in one launch (tile tags of deferred work wrap many times)"""
