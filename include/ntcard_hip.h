@@ -131,6 +131,17 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
 
+/* The same for reads of UNEQUAL length (ntRead takes any sequence, ntcard.cpp:173-189; adapter-trimmed FASTQ) — ABI 5.  A ragged tiled batch holds
+ * reads of 16 * n_chunks - 15 .. 16 * n_chunks bases (one bin of ceil(len / 16)) in the tiled layout of ntc_submit_tiled_device with
+ * read_len = 16 * n_chunks; bytes behind a read's end hold a base letter ('A').  EVERY TILE IS SORTED LONGEST READ FIRST (counting is
+ * order-independent, so a producer may reorder), and d_tails[tile * 16 + d], d = 0 .. 15, is the number of reads of that tile with more than d
+ * bases in their last 16-base piece (d_tails[tile * 16] = the reads of the tile; non-increasing in d).  The kernel masks every window that ends
+ * behind a read's end with the prefix of the tile that is long enough: no per-read length array, 64 bytes per tile.  d_tails follows the rules of
+ * d_tiles (device memory, valid until the stream has passed the call — until ntc_sync with NTC_FLAG_DEFER_REDO).  Fails with NTC_ERR_ARG on an
+ * engine whose configuration the tiled kernels are not built for.  ntc_submit / ntc_submit_spans build such batches themselves: a host batch of
+ * mixed lengths is binned by ceil(len / 16), bins of >= 1024 reads go this way, the rest takes row slots.                                      */
+int ntc_submit_tiled_ragged_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t n_chunks, const uint32_t *d_tails);
+
 int ntc_sync(ntc_engine *e); /* wait for all submitted work */
 
 /* Apply the pending hit log to the device sketch (asynchronous on the engine's stream).  After it the

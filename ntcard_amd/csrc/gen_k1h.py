@@ -127,6 +127,7 @@ S_N, S_A, S_B, S_CC = _salloc(), _salloc(), _salloc(), _salloc()  # scalar scrat
 S_SPARE = _salloc()
 S_END = _sn[0]
 assert S_END <= 100, S_END
+S_TAILMASK, S_RAGGED = 100, 101   # ragged batches (K1hArgs.tails != NULL): the steps of this block that end in a read's last 16-base piece; the flag
 
 S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCAP = the last time stamp): no F1, no suspects
 
@@ -134,7 +135,7 @@ S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCA
 INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase", "first_block", "end_block"]
 # byte offsets in struct K1hArgs (ntc_kernels.hpp); the kernel reads them with scalar loads
 KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_tiles=56, n_chunks=60, read_len=64, nv_last=68, key_base=72,
-            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128, s_bits=96)
+            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128, s_bits=96, tails=144)
 
 
 class Gen:
@@ -267,6 +268,39 @@ class Gen:
                 self.p.i("v_xor_b32", v(dst), v(prev), v(z))
         else:
             self.bitop3(v(dst), v(prev), v(x), v(y), (lambda a, b, c: 1 ^ a ^ b ^ c) if inv else (lambda a, b, c: a ^ b ^ c))
+
+    def emit_tail_step(self):
+        """subroutine (S_B = 4 d).  Ragged batch: the step ends at base 16 (C - 1) + d of the reads.  n = tails[tile][d] reads of the tile are that long — a
+        prefix of it (longest first): the candidate masks shrink to it (they only ever shrink until the tile ends: the steps in the last piece come in the
+        order of d) and F1 takes n windows."""
+        p = self.p
+        T = V_T0
+        p.label("tailsub")
+        p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["tails"]))
+        p.i("s_lshl_b32", s(S_A), s(S_WT), 6)
+        p.i("s_add_u32", s(S_A), s(S_A), s(S_B))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_load_dword", s(S_A), sr(S_TMP, 2), s(S_A))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        if "timers" not in self.exp:
+            p.i("s_add_u32", s(S_F1ACC), s(S_F1ACC), s(S_A))
+            p.i("s_addc_u32", s(S_F1ACC + 1), s(S_F1ACC + 1), 0)
+        # bit m of the prefix mask = (64 m + lane < n): cnt = clamp((n - lane + 63) >> 6, 0, 32) low bits (n <= 2048; n = 0: none)
+        p.i("v_lshrrev_b32", v(T), 2, v(V_LANE4))
+        p.i("v_sub_u32", v(T), s(S_A), v(T))                    # n - lane (may be negative: lane >= n)
+        p.i("v_add_u32", v(T), 63, v(T))
+        p.i("v_ashrrev_i32", v(T), 6, v(T))
+        p.i("v_max_i32", v(T), 0, v(T))
+        p.i("v_min_u32", v(T), 32, v(T))
+        p.i("v_cmp_gt_u32_e32", "vcc", 32, v(T))
+        p.i("v_lshlrev_b32", v(T + 1), v(T), v(V_ONE))
+        p.i("v_add_u32", v(T + 1), -1, v(T + 1))
+        p.i("v_cndmask_b32_e64", v(T + 1), -1, v(T + 1), "vcc")
+        p.i("v_and_b32", v(V_VMASK), v(V_VMASK), v(T + 1))
+        p.i("v_or3_b32", v(T), v(V_D0), v(V_D1), v(V_D2))
+        self.bitop3(v(V_CMASK), v(T), v(V_VMASK), v(V_VMASK), lambda x, y, z: (1 ^ x) & y)
+        p.i("v_and_b32", v(V_DMASK), v(T), v(V_VMASK))
+        self.ret()
 
     def walk_step(self, a):
         i0, i1, o0, o1 = self.planes_of_step(a)
@@ -910,6 +944,11 @@ class Gen:
                           (S_LOGREG, "log_regions"), (S_LOGCAP4, "log_region_cap"), (S_SUSCAP, "sus_cap")):
             p.i("s_load_dword", s(reg), sr(S_KARG, 2), hex(KARG[name]))
         p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["tails"]))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_cmp_lg_u64", sr(S_TMP, 2), 0)
+        p.i("s_cselect_b32", s(S_RAGGED), 1, 0)
+        p.i("s_mov_b32", s(S_TAILMASK), 0)
         p.i("s_lshl_b32", s(S_LOGCAP4), s(S_LOGCAP4), 2)
         p.i("s_lshl_b32", s(S_SUSCAP), s(S_SUSCAP), 4)         # bytes
         p.i("s_mul_i32", s(S_A), s(S_WT), s(S_SUSCAP))
@@ -1017,13 +1056,24 @@ class Gen:
             if a % 4 == 0:
                 self.quarter_enter(a // 4)
             self.walk_step(a)
-            skip = self.lbl("nostep")
+            skip, notstep, dostep, tailp = self.lbl("nostep"), self.lbl("notstep"), self.lbl("dostep"), self.lbl("tailstep")
             p.i("s_bitcmp1_b32", s(S_STEPMASK), a)
-            p.i("s_cbranch_scc0", "@" + skip)
+            p.i("s_cbranch_scc0", "@" + notstep)
             if "noflags" in self.exp:
                 p.i("s_branch", "@" + skip)
+            p.label(dostep)
             self.flags_and_push(a)
             p.label(skip)
+
+            def cold_tail(a=a, skip=skip, notstep=notstep, dostep=dostep, tailp=tailp):
+                # a step the mask leaves out (a filling block, the steps behind the read) — or, in a ragged batch, one that ends in the reads' last piece
+                p.label(notstep)
+                p.i("s_bitcmp1_b32", s(S_TAILMASK), a)
+                p.i("s_cbranch_scc0", "@" + skip)
+                p.i("s_mov_b32", s(S_B), 4 * ((self.phi + a) & 15))   # the step ends at base 16 (C - 1) + d of the reads: d x 4
+                self.call("tailsub")
+                p.i("s_branch", "@" + dostep)
+            self.cold.append(cold_tail)
             if a in (4, 8, 12):
                 self.pack_batch(a // 4 - 1)
             if a == 15:
@@ -1144,6 +1194,23 @@ class Gen:
         p.i("s_cmp_ge_u32", s(S_WF), s(S_F0))                    # a block walked only to fill the window completes nothing
         p.i("s_cselect_b32", s(S_STEPMASK), s(S_STEPMASK), 0)
         p.i("s_cselect_b32", s(S_CC), s(S_CC), 0)
+        # Ragged batch (round 5; ntRead takes any std::string, ntcard.cpp:173-189): the reads of a batch are 16 C - 15 .. 16 C bases long (read_len = 16 C) and
+        # every tile's reads are sorted by length, longest first, so "the reads with a window ending at base 16 (C - 1) + d" are a PREFIX of the tile —
+        # tails[tile][d] of them.  The steps that end in the last piece (e >= 16 (C - 1)) leave the step mask for the tail mask: their code (tail_step,
+        # out of line) narrows the candidate masks to that prefix and counts tails[tile][d] windows into F1 instead of one per read.
+        noragged = self.lbl("noragged")
+        p.i("s_cmp_eq_u32", s(S_RAGGED), 1)
+        p.i("s_cbranch_scc0", "@" + noragged)
+        p.i("s_sub_u32", s(S_B), s(S_C), 1)
+        p.i("s_lshl_b32", s(S_B), s(S_B), 4)
+        p.i("s_sub_i32", s(S_B), s(S_B), s(S_A))                 # first step that ends in the last piece (e0 + a >= 16 (C - 1))
+        p.i("s_max_i32", s(S_B), s(S_B), 0)
+        p.i("s_min_i32", s(S_B), s(S_B), 16)
+        p.i("s_bfm_b32", s(S_B), s(S_B), 0)                      # the steps before it
+        p.i("s_andn2_b32", s(S_TAILMASK), s(S_STEPMASK), s(S_B))
+        p.i("s_and_b32", s(S_STEPMASK), s(S_STEPMASK), s(S_B))
+        p.i("s_bcnt1_i32_b32", s(S_CC), s(S_STEPMASK))
+        p.label(noragged)
         # F1 (ntcard.cpp:154): every window of every valid read counts here (K1f takes the invalid ones back)
         p.i("s_add_u32", s(S_A), s(S_WT), 1)
         p.i("s_cmp_eq_u32", s(S_A), s(S_NTILES))
@@ -1194,6 +1261,7 @@ class Gen:
         p.i("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
         p.i("s_branch", "@end")
         self.emit_pass()
+        self.emit_tail_step()
         p.label("end")
         if "nosched" not in self.exp:
             schedule(p)

@@ -486,6 +486,12 @@ class Emu:
     def op_v_lshrrev_b32(self, pc, o, m):
         self._vbin(o, lambda a, b: b >> (a & np.uint32(31)))
 
+    def op_v_ashrrev_i32(self, pc, o, m):
+        self._vbin(o, lambda a, b: (b.astype(np.int32) >> (a & np.uint32(31)).astype(np.int32)).astype(np.uint32))
+
+    def op_v_max_i32(self, pc, o, m):
+        self._vbin(o, lambda a, b: np.maximum(a.astype(np.int32), b.astype(np.int32)).astype(np.uint32))
+
     def op_v_mul_lo_u32(self, pc, o, m):
         self._vbin(o, lambda a, b: (a.astype(np.uint64) * b.astype(np.uint64)).astype(np.uint32))
 

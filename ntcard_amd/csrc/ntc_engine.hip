@@ -723,10 +723,11 @@ int run_tiled_as_rows(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_re
 }
 
 // K1h + K1f over one device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)
-int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len)
+int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len, const uint32_t* d_tails = nullptr)
 {
 	if (n_reads == 0) return 0;
 	if (!e->ts_ok && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
+	if (!e->ts_ok && d_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for this configuration");
 	if (!e->ts_ok) return run_tiled_as_rows(e, d_tiles, n_reads, read_len); // this configuration is K1's
 	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
 	{
@@ -735,8 +736,8 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 		const uint64_t rows = (uint64_t)(read_len + 15u) / 16u + 2u; // chunks, and at most chunks + 1 blocks, per tile
 		if (n_tiles * rows * 256u >= (1ull << 32)) {
 			const uint64_t head_tiles = n_tiles / 2, head_reads = head_tiles * ntc::kTileReads;
-			if (int rc = run_tiled(e, d_tiles, head_reads, read_len)) return rc;
-			return run_tiled(e, d_tiles + ntc_tiled_bytes(head_reads, read_len), n_reads - head_reads, read_len);
+			if (int rc = run_tiled(e, d_tiles, head_reads, read_len, d_tails)) return rc;
+			return run_tiled(e, d_tiles + ntc_tiled_bytes(head_reads, read_len), n_reads - head_reads, read_len, d_tails ? d_tails + head_tiles * 16 : nullptr);
 		}
 	}
 	DevInfo di;
@@ -834,7 +835,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 						if (int rc = ensure_set(e->k1h_set[si])) {
 							// no memory for K1h's hand-over arrays (8 sets with NTC_FLAG_DEFER_REDO: up to ~0.5 GB each per 10 M reads): the
 							// batch is K1's, unless the caller insists on the tiled kernels or part of the k list has been launched already
-							if (e->ts_required || ki != 0) return rc;
+							if (e->ts_required || ki != 0 || d_tails) return rc;
 							if (int rc2 = close_run(e)) return rc2;
 							return run_tiled_as_rows(e, d_tiles, n_reads, read_len);
 						}
@@ -866,6 +867,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 				h.table = e->d_k1h_tabs[ki];
 				h.s_bits = e->s_bits;
 				h.r_bits = e->r_bits;
+				h.tails = d_tails;
 				ntc::K1hArgs launched;
 				uint32_t n_waves = 0;
 				if (int rc = open_run()) return rc; // (a K1f above may have closed the bracket)
@@ -1153,6 +1155,17 @@ int ntc_submit_tiled_device(ntc_engine* e, const void* d_tiles, uint64_t n_reads
 	return run_tiled(e, (const unsigned char*)d_tiles, n_reads, read_len);
 }
 
+int ntc_submit_tiled_ragged_device(ntc_engine* e, const void* d_tiles, uint64_t n_reads, uint32_t n_chunks, const uint32_t* d_tails)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: null engine");
+	if (n_reads == 0) return 0;
+	if (!d_tiles || ((uintptr_t)d_tiles & 15u) || !d_tails || ((uintptr_t)d_tails & 3u)) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: need a 16-byte aligned tile buffer and a tails array");
+	if (n_chunks == 0 || n_chunks > 0xffffu / 16u) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: n_chunks %u outside 1..4095", n_chunks);
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	return run_tiled(e, (const unsigned char*)d_tiles, n_reads, 16u * n_chunks, d_tails);
+}
+
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len)
 {
 	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
@@ -1179,7 +1192,10 @@ namespace {
 // where ntc_submit_tiled_device expects them, so the reads the reference's parsers hand to ntRead (ntcard.cpp:182,203,230) reach the
 // tiled kernels (K1h / K1c) like a device-resident producer's do.
 // (len_of / ptr_of are template callables: the packing loops call them once or twice per read, inlined)
-template <class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const PtrFn& ptr_of)
+// ragged == false: every read is `len` bases long.  ragged == true (round 5): the reads are 16 C - 15 .. 16 C bases long, C = len / 16, and come
+// LONGEST FIRST (so every tile is sorted): the tiles are followed, in the same staging buffer, by tails[tile][16] — the reads of the tile with more than d
+// bases in their last piece — and the batch goes to ntc_submit_tiled_ragged_device's path.
+template <class LenFn, class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const LenFn& len_of, const PtrFn& ptr_of, bool ragged)
 {
 	HIP_TRY(hipSetDevice(e->device));
 	ntc_engine::StageSlot* sl = nullptr;
@@ -1211,7 +1227,9 @@ template <class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, ui
 	} release{e, sl};
 	if (sl->done == nullptr) HIP_TRY(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
 	if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));
-	const size_t need = (size_t)ntc_tiled_bytes(n_reads, len);
+	const size_t tile_bytes = (size_t)ntc_tiled_bytes(n_reads, len);
+	const size_t n_tiles_h = (size_t)((n_reads + ntc::kTileReads - 1) / ntc::kTileReads);
+	const size_t need = tile_bytes + (ragged ? n_tiles_h * 64 : 0);
 	if (need > sl->h_stage_cap) {
 		if (sl->h_stage) (void)hipHostFree(sl->h_stage);
 		sl->h_stage = nullptr;
@@ -1234,15 +1252,21 @@ template <class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, ui
 	}
 	// ---- pack: piece c of read i -> ((tile * C + c) * 2048 + i % 2048) * 16 ----
 	unsigned char* hs = sl->h_stage;
-	const uint32_t C = (len + 15u) / 16u, tail = len - (C - 1u) * 16u;
+	const uint32_t C = (len + 15u) / 16u;
+	uint32_t* tails = reinterpret_cast<uint32_t*>(hs + tile_bytes);
+	if (ragged) std::memset(tails, 0, n_tiles_h * 64);
 	for (uint64_t i = 0; i < n_reads; ++i) {
 		const char* src = ptr_of(i);
+		const uint32_t tail = (uint32_t)(ragged ? len_of(i) : len) - (C - 1u) * 16u; // 1 .. 16 bases in the last piece
 		unsigned char* dst = hs + ((i / ntc::kTileReads) * C * ntc::kTileReads + i % ntc::kTileReads) * 16u;
 		for (uint32_t c = 0; c + 1u < C; ++c)
 			std::memcpy(dst + (size_t)c * ntc::kTileReads * 16u, src + 16u * c, 16);
 		unsigned char* last = dst + (size_t)(C - 1u) * ntc::kTileReads * 16u;
 		std::memcpy(last, src + 16u * (C - 1u), tail);
 		std::memset(last + tail, 'A', 16u - tail);
+		if (ragged)
+			for (uint32_t d = 0; d < tail; ++d)
+				++tails[(i / ntc::kTileReads) * 16u + d];
 	}
 	{
 		std::lock_guard<std::mutex> lk(e->mu);
@@ -1252,7 +1276,7 @@ template <class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, ui
 		}
 		const bool keep = e->defer_redo; // the staging pair is recycled: its K1f may not be deferred
 		e->defer_redo = false;
-		const int rc = run_tiled(e, sl->d_stage, n_reads, len);
+		const int rc = run_tiled(e, sl->d_stage, n_reads, ragged ? 16u * C : len, ragged ? reinterpret_cast<const uint32_t*>(sl->d_stage + tile_bytes) : nullptr);
 		e->defer_redo = keep;
 		sl->used = true;
 		if (hipEventRecord(sl->done, e->stream) != hipSuccess) (void)hipStreamSynchronize(e->stream);
@@ -1427,33 +1451,64 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 {
 	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
 	if (e->ts_ok && n_reads >= 1024) {
-		// the reads of the most frequent length (a FASTQ file's untrimmed reads) take the tiled path when they are the bulk of the batch.
-		// The common case — every read as long as the first — is a plain compare loop; only a mixed batch is counted by length.
-		uint64_t best = len_of(0), best_n = 0;
+		// Reads of ONE length (an untrimmed FASTQ file) are one tiled batch.  Otherwise (round 5) the reads are binned by their number of 16-base pieces,
+		// C = ceil(len / 16): a bin of at least 512 Ki reads goes to the tiled kernels as a RAGGED batch — sorted longest first, K1h masks the windows
+		// behind every read's end — and what is left (thin bins, reads shorter than every k, sequences beyond 64 Ki bases) takes row slots and K1.
+		// (A K1h launch over fewer reads than that loses to K1: 0.5 M reads 0.065 ms against 0.042 — profiles/r05_batch_size_sweep.txt,
+		// profiles/r05_ragged_host.txt: 8 M reads of which 5 % are trimmed to 50 .. 149 bp took 0.91 ms with every bin of >= 1024 reads tiled, six of them
+		// thin, against 0.73 ms through K1 alone.  NTC_FLAG_REQUIRE_TILED, the validation flag, lowers the bar to 1024 reads.)
+		const uint32_t bin_min = e->ts_required ? 1024u : 512u * 1024u;
+		const uint64_t len0 = len_of(0);
+		uint64_t same = 0;
 		for (uint64_t i = 0; i < n_reads; ++i)
-			best_n += len_of(i) == best;
-		if (best_n != n_reads) {
-			std::vector<uint32_t> cnt(0x10000u, 0u); // (only lengths the tiled layout can take: < 64 Ki)
-			best_n = 0;
+			same += len_of(i) == len0;
+		if (same == n_reads) {
+			if (len0 >= kmin && len0 <= 0xffffu) return submit_tiled_host(e, n_reads, (uint32_t)len0, len_of, ptr_of, false);
+		} else {
+			constexpr uint32_t kMaxC = 0x10000u / 16u;
+			std::vector<uint32_t> per_c(kMaxC + 1, 0u);
 			for (uint64_t i = 0; i < n_reads; ++i) {
 				const uint64_t l = len_of(i);
-				if (l > 0xffffu) continue;
-				const uint32_t c = ++cnt[l];
-				if (c > best_n) {
-					best_n = c;
-					best = l;
-				}
+				if (l >= kmin && l <= 0xffffu) ++per_c[(l + 15u) / 16u];
 			}
-		}
-		if (best >= kmin && best <= 0xffffu && best_n >= 1024 && best_n * 10 >= n_reads * 9) {
-			if (best_n == n_reads) return submit_tiled_host(e, n_reads, (uint32_t)best, ptr_of);
-			std::vector<uint64_t> same, rest;
-			same.reserve(best_n);
-			rest.reserve(n_reads - best_n);
-			for (uint64_t i = 0; i < n_reads; ++i)
-				(len_of(i) == best ? same : rest).push_back(i);
-			if (int rc = submit_tiled_host(e, same.size(), (uint32_t)best, [&](uint64_t i) { return ptr_of(same[i]); })) return rc;
-			return submit_rows(e, rest.size(), [&](uint64_t i) { return len_of(rest[i]); }, [&](uint64_t i) { return ptr_of(rest[i]); });
+			std::vector<uint64_t> rest;
+			std::vector<std::vector<uint64_t>> bins; // (only the bins that are taken)
+			std::vector<int32_t> bin_of(kMaxC + 1, -1);
+			for (uint32_t c = 1; c <= kMaxC; ++c)
+				if (per_c[c] >= bin_min) {
+					bin_of[c] = (int32_t)bins.size();
+					bins.emplace_back();
+					bins.back().reserve(per_c[c]);
+				}
+			if (!bins.empty()) {
+				for (uint64_t i = 0; i < n_reads; ++i) {
+					const uint64_t l = len_of(i);
+					const int32_t b = (l >= kmin && l <= 0xffffu) ? bin_of[(l + 15u) / 16u] : -1;
+					if (b >= 0) bins[(size_t)b].push_back(i);
+					else rest.push_back(i);
+				}
+				for (uint32_t c = 1; c <= kMaxC; ++c) {
+					if (bin_of[c] < 0) continue;
+					std::vector<uint64_t>& idx = bins[(size_t)bin_of[c]];
+					// longest first: a counting sort by the 16 possible tails (stable)
+					std::vector<uint64_t> sorted(idx.size());
+					size_t start[17] = { 0 };
+					for (uint64_t i : idx)
+						++start[16u - (uint32_t)(len_of(i) - 16u * (c - 1u))]; // tail 16 -> bucket 0
+					size_t acc = 0;
+					for (int t = 0; t < 17; ++t) {
+						const size_t n = start[t];
+						start[t] = acc;
+						acc += n;
+					}
+					for (uint64_t i : idx)
+						sorted[start[16u - (uint32_t)(len_of(i) - 16u * (c - 1u))]++] = i;
+					if (int rc = submit_tiled_host(e, sorted.size(), 16u * c, [&](uint64_t j) { return len_of(sorted[j]); }, [&](uint64_t j) { return ptr_of(sorted[j]); }, true))
+						return rc;
+				}
+				if (rest.empty()) return 0;
+				return submit_rows(e, rest.size(), [&](uint64_t i) { return len_of(rest[i]); }, [&](uint64_t i) { return ptr_of(rest[i]); });
+			}
 		}
 	}
 	return submit_rows(e, n_reads, len_of, ptr_of);

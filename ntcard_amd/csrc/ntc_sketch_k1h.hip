@@ -74,6 +74,18 @@ __device__ __forceinline__ uint32_t ballot_rank(uint64_t m)
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// length of read r of tile t: read_len for a batch of equal-length reads; in a ragged batch (round 5: K1hArgs.tails) the reads are
+// 16 (C - 1) + 1 .. 16 C bases long, every tile is sorted longest first, and tails[t][d] = its reads with more than d bases in their last piece
+__device__ __forceinline__ uint32_t read_length(const K1hArgs& a, uint32_t t, uint32_t r)
+{
+	if (a.tails == nullptr) return a.read_len;
+	uint32_t tail = 0;
+#pragma unroll
+	for (uint32_t d = 0; d < 16u; ++d)
+		tail += a.tails[(size_t)t * 16u + d] > r;
+	return 16u * (a.n_chunks - 1u) + tail;
+}
+
 __device__ __forceinline__ tilebits::v4u32 raw_piece(const K1hArgs& a, uint32_t t, uint32_t c, uint32_t r)
 {
 	return *reinterpret_cast<const tilebits::v4u32*>(a.tiles + (((size_t)t * a.n_chunks + c) * kTileReads + r) * 16u);
@@ -104,7 +116,7 @@ __device__ __forceinline__ void k1f_f1_role(const K1fItem& item, const uint32_t 
 	__shared__ uint2 s_q[4][128];
 	__shared__ uint32_t s_sum[4], s_slow[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-	const uint32_t C = a.n_chunks, L = a.read_len, W = L - k + 1u;
+	const uint32_t C = a.n_chunks;
 	const uint64_t n_rows = (uint64_t)a.n_tiles * C;
 	uint32_t f1_sub = 0;
 	bool slow = false;
@@ -133,7 +145,7 @@ __device__ __forceinline__ void k1f_f1_role(const K1fItem& item, const uint32_t 
 			if (cov < k) E |= E << (k - cov);
 			const int tzb = B ? __builtin_ctz(B) : 32;
 			const int jmin = max(0, (int)k - 1 - 16 * (int)c);
-			const int jmax = min(min(46, 15 + tzb), (int)W + (int)k - 2 - 16 * (int)c);
+			const int jmax = min(min(46, 15 + tzb), (int)read_length(a, t, r) - 1 - 16 * (int)c); // (the last window ends at the read's last base)
 			if (A != 0u && jmax >= jmin) f1_sub += (uint32_t)__popcll((E >> jmin) & ((2ull << (jmax - jmin)) - 1ull));
 		}
 		qhead += n_items;
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256) void k1h_slow_kernel(const K1fBatch batch)
 		const bool ties = (it.y >> 26) & 1u;
 		int e_lo = 16 * (int)c - 16 + (int)phi, e_hi = 16 * (int)(c + nblk - 1u) + (int)phi - 1;
 		e_lo = max(e_lo, (int)k - 1);
-		e_hi = min(e_hi, (int)L - 1);
+		e_hi = min(e_hi, (int)(act ? read_length(a, t, r) : L) - 1);
 		const int p0 = e_lo - (int)k + 1;
 		const int len = act && e_hi >= e_lo ? e_hi - p0 + 1 : 0; // positions to walk
 		// stage the pieces [p0 >> 4, e_hi >> 4] of the read

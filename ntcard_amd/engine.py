@@ -103,6 +103,11 @@ class Engine:
         """a device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)"""
         check(self._lib.ntc_submit_tiled_device(self._h, C.c_void_p(d_tiles_ptr), n_reads, read_len))
 
+    def submit_tiled_ragged_device(self, d_tiles_ptr, n_reads, n_chunks, d_tails_ptr):
+        """a device-resident RAGGED batch: reads of 16 n_chunks - 15 .. 16 n_chunks bases in the tiled layout, every tile sorted longest first,
+        d_tails = uint32[n_tiles][16] (include/ntcard_hip.h: ntc_submit_tiled_ragged_device; tile_reads_ragged builds both)"""
+        check(self._lib.ntc_submit_tiled_ragged_device(self._h, C.c_void_p(d_tiles_ptr), n_reads, n_chunks, C.c_void_p(d_tails_ptr)))
+
     def sync(self):
         check(self._lib.ntc_sync(self._h))
 
@@ -239,6 +244,28 @@ def tile_reads(reads, read_len=None):
         a[:n, :L] = np.frombuffer(b"".join(reads), dtype=np.uint8).reshape(n, L)
         out[:] = a.reshape(nt, 2048, C16, 16).transpose(0, 2, 1, 3)
     return out.reshape(-1)
+
+
+def tile_reads_ragged(reads, n_chunks):
+    """host-side packing of a RAGGED batch (reads of 16 n_chunks - 15 .. 16 n_chunks bases, list of bytes) -> (tiles uint8 array, tails uint32
+    [n_tiles, 16], order): the reads are sorted longest first (order[j] = index of the read in slot j), tails[t, d] = reads of tile t with more than d
+    bases in their last piece (tests, small inputs)"""
+    n, C16 = len(reads), int(n_chunks)
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    assert n == 0 or (lens.min() > 16 * (C16 - 1) and lens.max() <= 16 * C16)
+    order = np.argsort(-lens, kind="stable")
+    nt = (n + 2047) // 2048
+    a = np.full((nt * 2048, C16 * 16), ord("A"), dtype=np.uint8)
+    for j, i in enumerate(order):
+        a[j, :lens[i]] = np.frombuffer(reads[i], dtype=np.uint8)
+    tails = np.zeros((nt, 16), dtype=np.uint32)
+    tl = lens[order] - 16 * (C16 - 1)
+    for t in range(nt):
+        part = tl[t * 2048:(t + 1) * 2048]
+        for d in range(16):
+            tails[t, d] = int(np.count_nonzero(part > d))
+    tiles = np.ascontiguousarray(a.reshape(nt, 2048, C16, 16).transpose(0, 2, 1, 3)).reshape(-1)
+    return tiles, tails, order
 
 
 def value_hist_device(d_counters_ptr, n, d_hist_ptr, device=0, stream=None):

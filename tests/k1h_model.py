@@ -64,7 +64,7 @@ class Layout:
         return a
 
 
-def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096, gap=0):
+def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096, gap=0, tails=None):
     """-> dict(keys=uint32[], f1=int, dirty=[n_tiles][C][64], tie=[n_tiles][NB][64], insts=executed per wave)"""
     Cn = (read_len + 15) // 16
     n_tiles = (n_reads + 2047) // 2048
@@ -83,6 +83,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     a_tie = lay.alloc(n_tiles * NB * 256)
     a_sus = lay.alloc(n_waves * sus_cap * 16)
     a_susn = lay.alloc(n_waves * 4)
+    a_tails = lay.alloc(n_tiles * 64) if tails is not None else 0  # ragged batch: uint32 [n_tiles][16], reads of the tile with more than d bases in their last piece
     mem = lay.mem
     mem[a_tiles:a_tiles + tiles.size] = tiles
     m32, m64 = mem.view(np.uint32), mem.view(np.uint64)
@@ -100,6 +101,9 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     m32[(a_karg + K["blocks_per_wave"]) // 4] = bpw
     m32[(a_karg + K["nb_magic"]) // 4] = (1 << 32) // NB
     m32[(a_karg + K["sus_cap"]) // 4] = sus_cap
+    m64[(a_karg + K["tails"]) // 8] = a_tails
+    if tails is not None:
+        m32[a_tails // 4: a_tails // 4 + n_tiles * 16] = np.asarray(tails, dtype=np.uint32).reshape(-1)
     lds = np.zeros(gen_k1h.LDS_BYTES, dtype=np.uint8)
     tab = build_table(k, r_bits, s_bits, gap)
     lds.view(np.uint32)[gen_k1h.TABLE_OFF // 4: gen_k1h.TABLE_OFF // 4 + tab.size] = tab.reshape(-1)
@@ -177,7 +181,7 @@ def k1f_model(reads, read_len, k, r_bits, s_bits, dirty, tie, sus=None, sus_over
         for b in range(NB):
             aff = any(0 <= c < Cn and (int(dirty[t, c, lane]) >> m) & 1 for c in (b - 2, b - 1, b))
             tb = (int(tie[t, b, lane]) >> m) & 1
-            for e in range(max(16 * b - 16 + phi, k - 1), min(16 * b + phi - 1, read_len - 1) + 1):
+            for e in range(max(16 * b - 16 + phi, k - 1), min(16 * b + phi - 1, len(seq) - 1) + 1):  # (a ragged batch: the read's own length)
                 win = seq[e - k + 1: e + 1]
                 ok, fv, rv = window_hashes(win, k, gap)
                 if not ok:

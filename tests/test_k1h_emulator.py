@@ -34,6 +34,42 @@ def run(n, L, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, s_bits=7, gap=0, **kw)
     return res
 
 
+def run_ragged(n, C, k, p_bad=0.0, r_bits=14, n_waves=2, seed=1, s_bits=7, gap=0, lo=None, **kw):
+    """a ragged batch: reads of 16 C - 15 .. 16 C bases (or lo .. 16 C), every tile sorted longest first, tails[tile][d] = its reads with more than d
+    bases in their last 16-base piece"""
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    lens = rng.integers(max(lo or 16 * C - 15, 16 * C - 15), 16 * C + 1, size=n)
+    ntl = (n + 2047) // 2048
+    reads, tails = [], np.zeros((ntl, 16), dtype=np.uint32)
+    arr = np.full((n, 16 * C), ord("A"), dtype=np.uint8)
+    for t in range(ntl):
+        ls = np.sort(lens[t * 2048:(t + 1) * 2048])[::-1]
+        for d in range(16):
+            tails[t, d] = int(np.count_nonzero(ls - 16 * (C - 1) > d))
+        for j, ln in enumerate(ls):
+            row = alpha[rng.integers(0, 4, size=ln)]
+            if p_bad:
+                row = np.where(rng.random(ln) < p_bad, alpha[rng.integers(4, len(alpha), size=ln)], row).astype(np.uint8)
+            arr[t * 2048 + j, :ln] = row
+            reads.append(row.tobytes())
+    res = km.run_k1h(tile_array(arr), n, 16 * C, k, r_bits=r_bits, n_waves=n_waves, s_bits=s_bits, gap=gap, tails=tails, **kw)
+    fk, f1_sub = km.k1f_model(reads, 16 * C, k, r_bits, s_bits, res["dirty"], res["tie"], res["sus"], res["sus_overflow"], gap=gap)
+    got = np.bincount(np.concatenate([res["keys"], np.array(fk, dtype=np.uint32)]).astype(np.int64), minlength=2 << r_bits).astype(np.uint32) + res["sketch"]
+    oc, of1 = orc.sketch_reads(reads, [k], gap, r_bits, s_bits)
+    assert res["f1"] - f1_sub == int(of1[0])
+    assert np.array_equal(got, oc[0].reshape(-1).astype(np.uint32))
+    return res
+
+
+@pytest.mark.parametrize("n,C,k,p_bad,n_waves", [(2048, 10, 32, 0.0, 2), (5000, 10, 32, 0.003, 3), (3000, 3, 32, 0.01, 2), (2100, 4, 25, 0.01, 2),
+                                                 (2500, 2, 12, 0.02, 2), (4100, 5, 17, 0.0, 4), (2048, 3, 31, 0.02, 1), (2048, 2, 20, 0.01, 2), (2300, 1, 12, 0.0, 2)])
+def test_k1h_emulated_ragged_batches(n, C, k, p_bad, n_waves):
+    """reads of unequal length (ntRead takes any string, ntcard.cpp:173-189): a batch of reads 16 C - 15 .. 16 C bases long, tiles sorted longest first,
+    the steps that end in the last piece masked to the prefix of the tile that is long enough (gen_k1h.Gen.tail_step)"""
+    run_ragged(n, C, k, p_bad, n_waves=n_waves, seed=n + C)
+
+
 @pytest.mark.parametrize("n,L,k,p_bad,n_waves", [
     (2048, 40, 32, 0.0, 2),       # one tile shared by two waves (the second one fills its window with two masked blocks)
     (4097, 47, 32, 0.02, 3),      # a partial last tile of one read

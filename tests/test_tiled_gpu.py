@@ -300,3 +300,50 @@ def test_tiled_spaced_seed_k12_gap2(nt, n, L, p_bad, s_bits):
     of1 = orc.sketch_update(counters, np.ascontiguousarray(arr).reshape(-1), offs, [12], 2, 18, s_bits)
     assert np.array_equal(f1, of1), (f1, of1)
     assert np.array_equal(tc, counters)
+
+
+def _ragged_reads(rng, n, lo, hi, p_bad=0.0):
+    alpha = np.frombuffer(b"ACGTacgtUuNnRYKM.-*", dtype=np.uint8)
+    lens = rng.integers(lo, hi + 1, size=n)
+    out = []
+    for ln in lens:
+        row = alpha[rng.integers(0, 4, size=ln)]
+        if p_bad:
+            row = np.where(rng.random(ln) < p_bad, alpha[rng.integers(4, len(alpha), size=ln)], row).astype(np.uint8)
+        out.append(row.tobytes())
+    return out
+
+
+@pytest.mark.parametrize("n,C,k,p_bad,s_bits", [(5000, 10, 32, 0.002, 7), (2048, 10, 32, 0.0, 7), (70000, 10, 32, 0.001, 7), (3000, 3, 32, 0.01, 7), (4100, 5, 17, 0.0, 7),
+                                               (2500, 2, 12, 0.02, 7), (2048, 2, 20, 0.01, 8), (9000, 7, 25, 0.003, 11), (300000, 10, 32, 0.0005, 7)])
+def test_tiled_ragged_batches(nt, n, C, k, p_bad, s_bits):
+    """ntc_submit_tiled_ragged_device: reads of 16 C - 15 .. 16 C bases, tiles sorted longest first, tails[tile][16] — K1h masks the windows behind
+    every read's end, K1f knows every read's own length (ntRead takes any string, ntcard.cpp:173-189)"""
+    rng = np.random.default_rng(n + C + k)
+    reads = _ragged_reads(rng, n, 16 * C - 15, 16 * C, p_bad)
+    tiles, tails, order = nt.tile_reads_ragged(reads, C)
+    dt, dl = torch.from_numpy(tiles).cuda(), torch.from_numpy(tails.reshape(-1).astype(np.int32)).cuda()
+    for flags in (0, nt.FLAG_DEFER_REDO):
+        with nt.Engine([k], r_bits=18, s_bits=s_bits, flags=flags | nt.FLAG_REQUIRE_TILED) as e:
+            e.submit_tiled_ragged_device(dt.data_ptr(), n, C, dl.data_ptr())
+            e.submit_tiled_ragged_device(dt.data_ptr(), min(n, 2048), C, dl.data_ptr())  # a prefix of a ragged batch is a ragged batch
+            tc, ph, f1 = e.finish(counters=True)
+        sub = [reads[i] for i in order[:min(n, 2048)]]
+        oc, of1 = orc.sketch_reads(reads + sub, [k], 0, 18, s_bits)
+        assert np.array_equal(f1, of1), (f1, of1)
+        assert np.array_equal(tc, oc)
+
+
+def test_host_submit_of_mixed_lengths_takes_ragged_tiles(nt):
+    """ntc_submit over adapter-trimmed-like reads (100 .. 150 bp, a few shorter than k, one long sequence): binned by ceil(len / 16), bins of >= 1024 reads
+    as ragged tiles, the rest in row slots — counters and F1 equal the oracle's"""
+    rng = np.random.default_rng(5)
+    reads = _ragged_reads(rng, 60000, 100, 150, 0.002) + _ragged_reads(rng, 300, 20, 40, 0.0) + _ragged_reads(rng, 50, 200, 230, 0.01) + _ragged_reads(rng, 2, 5000, 9000, 0.001)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    oc, of1 = orc.sketch_reads(reads, [32], 0, 18, 7)
+    for flags in (nt.FLAG_REQUIRE_TILED, 0):  # (the validation flag lowers the size a bin needs for the tiled kernels from 512 Ki reads to 1024)
+        with nt.Engine([32], r_bits=18, s_bits=7, flags=flags) as e:
+            e.submit_reads(reads)
+            tc, ph, f1 = e.finish(counters=True)
+        assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
