@@ -69,9 +69,9 @@ void process_file(const std::string& path, ntc_engine* eng)
 	if (type == 0)
 		parse_fastq_blocks(in, eng);
 	else if (type == 1)
-		parse_fasta(in, batch);
+		parse_fasta_blocks(in, eng, batch);
 	else if (type == 2)
-		parse_sam(in, batch, first, sam_has_header);
+		parse_sam_blocks(in, eng, batch, first, sam_has_header);
 	else {
 		std::cerr << "Error in reading file: " << path << std::endl; // ntcard.cpp:459-462
 		std::exit(EXIT_FAILURE);

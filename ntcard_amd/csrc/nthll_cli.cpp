@@ -31,11 +31,11 @@ void process_file(const std::string& path, ntc_engine* eng)
 	}
 	Batcher batch(eng);
 	if (type == 0)
-		parse_fastq(in, batch);
+		parse_fastq_blocks(in, eng);
 	else if (type == 1)
-		parse_fasta(in, batch);
+		parse_fasta_blocks(in, eng, batch);
 	else
-		parse_sam(in, batch, first, sam_has_header);
+		parse_sam_blocks(in, eng, batch, first, sam_has_header);
 	batch.flush();
 }
 

@@ -168,3 +168,68 @@ def test_live_differential_against_reference_binary(tmp_path):
             a = (tmp_path / ("gpu%d_k%s.hist" % (n, k))).read_bytes()
             b = (tmp_path / ("ref%d_k%s.hist" % (n, k))).read_bytes()
             assert a == b, (args, files, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_NTCARD), reason="the real reference binary (oracle/_ref) was not built")
+@pytest.mark.parametrize("block", [None, "64", "4096"])
+def test_block_splitters_against_reference_binary(tmp_path, block):
+    """the block-based FASTA and SAM splitters (cli_common.hpp) against the reference's line-based ones (ntcard.cpp:191-235), quirks included:
+    one-line and wrapped FASTA records mixed, blank lines, CR line ends, no final newline; SAM lines with fewer than ten fields and blank lines
+    (the reference counts the PREVIOUS sequence again), spaces as separators, header-only files with and without a final newline.  With
+    NTC_CLI_BLOCK_BYTES at 64 and 4096 every record straddles a block boundary and the grow path (a record longer than the block) runs."""
+    import random
+    rng = random.Random(7)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTACGTACGTacgtN") for _ in range(n))
+
+    fa = []
+    for i in range(3000):
+        s = seq(rng.choice([0, 10, 40, 100, 150, 151]))
+        kind = rng.random()
+        if kind < 0.8:
+            fa.append(">r%d\n%s\n" % (i, s))
+        elif kind < 0.9:
+            fa.append(">r%d\n%s\n\n%s\n" % (i, s[:50], s[50:]))
+        elif kind < 0.95:
+            fa.append(">r%d\r\n%s\r\n" % (i, s))
+        else:
+            fa.append(">r%d\n" % i)
+    fa.append(">last\n" + seq(100))  # no final newline
+    (tmp_path / "reads1.fa").write_text("".join(fa), newline="")
+    (tmp_path / "long1.fa").write_text(">c\n" + seq(20000) + "\n>d\n" + seq(300) + "\n", newline="")
+
+    def samrec(i, s, sep="\t"):
+        return sep.join(["q%d" % i, "0", "chr1", str(1 + i), "60", "%dM" % max(1, len(s)), "*", "0", "0", s, "I" * len(s), "NM:i:0"]) + "\n"
+
+    sam = ["@HD\tVN:1.6\tSO:unsorted\n", "@SQ\tSN:chr1\tLN:100000\n", "@CO\ta b c d e f g h ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT k\n"]
+    for i in range(3000):
+        r = rng.random()
+        if r < 0.9:
+            sam.append(samrec(i, seq(rng.choice([36, 100, 150])), "\t" if rng.random() < 0.9 else " "))
+        elif r < 0.95:
+            sam.append("q%d\t4\t*\n" % i)        # short line: the previous sequence counts again
+        else:
+            sam.append("\n")
+    sam.append("\n")
+    (tmp_path / "quirky.sam").write_text("".join(sam), newline="")
+    (tmp_path / "nohdr2.sam").write_text("".join(s for s in sam[3:] if s != "\n")[:-1], newline="")  # starts with a record, no final newline
+    hdr = "@HD\tVN:1.6\n@CO\ta b c d e f g h ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTTTGACCA k"
+    (tmp_path / "hdr_nl.sam").write_text(hdr + "\n", newline="")
+    (tmp_path / "hdr_nonl.sam").write_text(hdr, newline="")
+    env = dict(os.environ)
+    if block:
+        env["NTC_CLI_BLOCK_BYTES"] = block
+    cases = [(["-k", "21"], ["reads1.fa"]), (["-k", "32"], ["long1.fa"]), (["-k", "25"], ["quirky.sam"]), (["-k", "25", "-g", "3"], ["nohdr2.sam"]),
+             (["-k", "12"], ["hdr_nl.sam", "reads1.fa"]), (["-k", "12"], ["hdr_nonl.sam", "reads1.fa"]), (["-k", "17"], ["hdr_nonl.sam"])]
+    for n, (args, files) in enumerate(cases):
+        ours = subprocess.run([BIN] + args + ["-p", "gpu%d" % n] + files, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        ref = subprocess.run([REF_NTCARD] + args + ["-p", "ref%d" % n] + files, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert ours.returncode == ref.returncode, (args, files, ours.stderr, ref.stderr)
+        if ref.returncode != 0:
+            continue
+        k = args[1]
+        a = (tmp_path / ("gpu%d_k%s.hist" % (n, k))).read_bytes()
+        b = (tmp_path / ("ref%d_k%s.hist" % (n, k))).read_bytes()
+        assert a == b, (args, files)

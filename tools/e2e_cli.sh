@@ -15,6 +15,16 @@ echo "== multi-k 16,24,32,48 -t 8"
 time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 16,24,32,48 -p refm $W/s_*.fq
 time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 16,24,32,48 -p gpum $W/s_*.fq
 for k in 16 24 32 48; do cmp refm_k$k.hist gpum_k$k.hist && echo IDENTICAL k$k; done
+echo "== FASTA (one-line records) and SAM renderings of the same reads, -t 8 (block splitters since round 5)"
+for f in $W/s_*.fq; do
+  awk 'NR%4==1{print ">" substr($0,2)} NR%4==2{print}' $f > ${f%.fq}.fa
+  awk 'BEGIN{OFS="\t"; print "@HD","VN:1.6"} NR%4==1{n=substr($0,2)} NR%4==2{s=$0} NR%4==0{print n,4,"*",0,0,"*","*",0,0,s,$0}' $f > ${f%.fq}.sam
+done
+for ext in fa sam; do
+  echo "-- reference, .$ext"; time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 32 -p ref_$ext $W/s_*.$ext
+  echo "-- MI355X, .$ext"; time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p gpu_$ext $W/s_*.$ext
+  cmp ref_${ext}_k32.hist gpu_${ext}_k32.hist && echo IDENTICAL
+done
 echo "== kernels of one CLI run (rocprofv3 --kernel-trace --stats: which hash kernel the parsed reads reach)"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/e2e_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof -o t -- $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p $W/prof $W/s_*.fq > /tmp/e2e_prof.log 2>&1
