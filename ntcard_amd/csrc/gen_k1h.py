@@ -631,6 +631,12 @@ class Gen:
         fld = [T + 15 + g for g in range(11)]
         p.label("pass")
         self.probe(0)
+        # A resolving wave goes first on its SIMD: the pass is chains of LDS round trips and slow-class VALU instructions (v_bfe, v_lshl_add, v_perm
+        # class: no overlap with the other wave's instructions, profiles/r05_ubench_op_classes.txt), the other wave of the SIMD is most likely walking
+        # (full-rate v_bitop3 that fills any gap).  -4 % hash time (profiles/r05_k1h_priority_ab.txt); s_setprio around every run of slow-class
+        # instructions gives the same, raising the WALK's priority nothing.
+        if "noprio" not in self.exp:
+            p.i("s_setprio", 3)
         if "nopass" in self.exp:
             p.i("s_mov_b32", s(S_QHEAD4), s(S_QTAIL4))
             self.ret()
@@ -856,6 +862,8 @@ class Gen:
         p.i("s_mov_b64", "exec", -1)
         p.i("s_waitcnt", "lgkmcnt(0)")
         self.probe(2)
+        if "noprio" not in self.exp:
+            p.i("s_setprio", 0)
         self.ret()
         # ---- rare: the log region is full ----
         p.label("logswitch")
@@ -1265,7 +1273,83 @@ class Gen:
         p.label("end")
         if "nosched" not in self.exp:
             schedule(p)
+        self.phase_fix(p)
         return p
+
+    # VALU instructions that a second wave on the SIMD overlaps with completely (profiles/r05_ubench_op_classes.txt): every other VALU
+    # instruction — and any of these with an SGPR source — occupies the pipe for a whole issue interval
+    FAST_VALU = {"v_bitop3_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32",
+                 "v_mov_b32"}
+
+    @classmethod
+    def is_slow_valu(cls, mnem, ops):
+        if not mnem.startswith("v_"):
+            return False
+        if mnem not in cls.FAST_VALU:
+            return True
+        return any(o.startswith("s") or o.startswith("vcc") or o.startswith("exec") for o in ops[1:])
+
+    def phase_fix(self, p):
+        """K1H_EXP=nopslow | noprun | priorun | priowalk (results stay RIGHT; with priorun / priowalk add noprio, which takes the pass's own s_setprio out): scalar no-ops / priority changes next to the slow-class VALU
+        instructions.  profiles/r05_ubench_sparse_slow.txt, r05_ubench_phase_fix.txt: one slow-class instruction drops a pair of waves into a
+        persistent phase in which they do not overlap any more, and a scalar instruction next to it brings the overlap back."""
+        if "priowalk" in self.exp:
+            out, code = [], p.code
+            i, n = 0, len(code)
+            while i < n:
+                c = code[i]
+                if c[0] == "i" and c[1].startswith("v_") and not self.is_slow_valu(c[1], c[2]):
+                    j = i
+                    while j < n and code[j][0] == "i" and code[j][1].startswith("v_") and not self.is_slow_valu(code[j][1], code[j][2]):
+                        j += 1
+                    if j - i >= 12:
+                        out.append(("i", "s_setprio", ["3"], ""))
+                        out.extend(code[i:j])
+                        out.append(("i", "s_setprio", ["0"], ""))
+                    else:
+                        out.extend(code[i:j])
+                    i = j
+                    continue
+                out.append(c)
+                i += 1
+            p.code = out
+            return
+        mode = [m for m in ("nopslow", "noprun", "priorun") if m in self.exp]
+        if not mode:
+            return
+        mode = mode[0]
+        out = []
+        pending = False   # a slow-class VALU instruction has been issued and neither a scalar instruction nor a fix since
+        for c in p.code:
+            if c[0] != "i":
+                out.append(c)
+                if c[0] == "l":
+                    pending = False if mode != "priorun" else pending
+                continue
+            mnem, ops = c[1], c[2]
+            if mnem.startswith("v_"):
+                slow = self.is_slow_valu(mnem, ops)
+                if slow:
+                    if mode == "priorun" and not pending:
+                        out.append(("i", "s_setprio", ["3"], ""))
+                    out.append(c)
+                    if mode == "nopslow":
+                        out.append(("i", "s_nop", ["0"], ""))
+                    else:
+                        pending = True
+                    continue
+                if pending:
+                    out.append(("i", "s_nop", ["0"], "") if mode == "noprun" else ("i", "s_setprio", ["0"], ""))
+                    pending = False
+                out.append(c)
+                continue
+            if mnem.startswith("s_") and mode != "priorun":
+                pending = False   # a scalar instruction does what the no-op would
+            if mode == "priorun" and pending and (mnem.startswith("s_cbranch") or mnem in ("s_branch", "s_setpc_b64", "s_endpgm")):
+                out.append(("i", "s_setprio", ["0"], ""))
+                pending = False
+            out.append(c)
+        p.code = out
 
 
 def render_inc(k, sb, gap=0):

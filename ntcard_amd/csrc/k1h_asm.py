@@ -431,6 +431,9 @@ class Emu:
     def op_s_nop(self, pc, o, m):
         return None
 
+    def op_s_setprio(self, pc, o, m):
+        return None
+
     def op_s_sleep(self, pc, o, m):
         return None
 

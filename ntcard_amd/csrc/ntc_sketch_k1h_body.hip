@@ -89,6 +89,9 @@ __global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hArgs a
 	const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + wave * a.blocks_per_wave));
 	const uint32_t end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + (wave + 1u) * a.blocks_per_wave));
 	const uint32_t wave_gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kK1hWaves + wave));
+#ifdef K1H_STATIC_PRIO // timing experiment (tools/k1h_variant.sh): the second wave of every SIMD runs at a fixed higher priority
+	if (wave >= 4) __builtin_amdgcn_s_setprio(K1H_STATIC_PRIO);
+#endif
 	const uint32_t n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * kK1hWaves));
 	const uint32_t lds_wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kK1hWArea));
 	const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();

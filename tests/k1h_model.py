@@ -78,7 +78,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     a_log = lay.alloc(log_regions * log_region_cap * 4)
     a_fill = lay.alloc(log_regions * 4)
     a_sk = lay.alloc(4 << (r_bits + 1))
-    a_f1 = lay.alloc(8)
+    a_f1 = lay.alloc(64)   # (a timing build, K1H_EXP=timers, leaves its section clocks in f1[1 .. 4])
     a_dirty = lay.alloc(n_tiles * Cn * 256)
     a_tie = lay.alloc(n_tiles * NB * 256)
     a_sus = lay.alloc(n_waves * sus_cap * 16)
@@ -126,7 +126,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     sk = m32[a_sk // 4: a_sk // 4 + (2 << r_bits)].copy()
     susn = m32[a_susn // 4: a_susn // 4 + n_waves].copy()
     sus = [m32[a_sus // 4 + w * sus_cap * 4: a_sus // 4 + (w * sus_cap + min(int(susn[w]), sus_cap)) * 4].reshape(-1, 4).copy() for w in range(n_waves)]
-    return dict(sus=np.concatenate(sus) if sus else np.zeros((0, 4), dtype=np.uint32), sus_overflow=bool(np.any(susn == 0xFFFFFFFF)), keys=keys.copy(), sketch=sk, f1=int(m64[a_f1 // 8]), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
+    return dict(sus=np.concatenate(sus) if sus else np.zeros((0, 4), dtype=np.uint32), sus_overflow=bool(np.any(susn == 0xFFFFFFFF)), keys=keys.copy(), sketch=sk, f1=int(m64[a_f1 // 8]), f1_raw=m64[a_f1 // 8: a_f1 // 8 + 8].copy(), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
                 tie=m32[a_tie // 4: a_tie // 4 + n_tiles * NB * 64].reshape(n_tiles, NB, 64).copy(), insts=insts, NB=NB, C=Cn)
 
 
