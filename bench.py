@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 (default) 100 M reads k=32 sBits=7; 3: 1 B reads in total, sBits=11, read-index ranges split "
                          "over the ranks (strong scaling); 4: k=32,64,96,128 in one run; 5: spaced seed k=12 g=2")
-    ap.add_argument("--repeats", type=int, default=5, help="the timed region (K steps + flush + merge) is run this many times in-process; ms_per_step / value "
+    ap.add_argument("--repeats", type=int, default=9, help="the timed region (K steps + flush + merge) is run this many times in-process; ms_per_step / value "
                                                             "are the MEDIAN repeat's, ms_per_step_min / _max give the spread (the clocks differ from lease to lease and ramp)")
     ap.add_argument("--no-nodefer", action="store_true", help="skip the extra run without NTC_FLAG_DEFER_REDO (\"roofline_nodefer\": the default buffer contract of ntc_submit*_device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -431,6 +431,7 @@ def main():
             "ms_per_step_min": runs[order[0]]["dt"] * 1e3 / K,
             "ms_per_step_max": runs[order[-1]]["dt"] * 1e3 / K,
             "ms_per_step_all": [r["dt"] * 1e3 / K for r in runs],
+            "kernel_ms_per_step_all": [{"hash": r["ker_ms"] / K, "fixup": r["fix_ms"] / K, "apply": r["apply_ms"] / K} for r in runs],
             "sclk_mhz": {"before": sclk_before, "after": sclk_after, "source": "rocm-smi --showclocks (current sclk level), read before the warm-up and right behind the last repeat"},
             "higher_is_better": True,
             "scaling": "strong" if strong_total is not None else "weak",

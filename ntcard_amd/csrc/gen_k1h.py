@@ -127,7 +127,10 @@ S_N, S_A, S_B, S_CC = _salloc(), _salloc(), _salloc(), _salloc()  # scalar scrat
 S_SPARE = _salloc()
 S_END = _sn[0]
 assert S_END <= 100, S_END
-S_TAILMASK, S_RAGGED = 100, 101   # ragged batches (K1hArgs.tails != NULL): the steps of this block that end in a read's last 16-base piece; the flag
+# S_STEPMASK: bits 0 .. 15 the steps of this block that complete a window of every read; bits 16 .. 31 (ragged batches, K1hArgs.tails != NULL) the steps that
+# end in the reads' last 16-base piece.  S_USELOG: bit 0 the hit log is in use, bit 8 the batch is ragged, bit 9 the queue is being emptied (read by the pass).
+# (The compiler reserves s100 / s101 next to VCC, FLAT_SCRATCH and XNACK_MASK: nothing of the kernel may live there.)
+F_USELOG, F_RAGGED, F_DRAIN = 0, 8, 9
 
 S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCAP = the last time stamp): no F1, no suspects
 
@@ -593,14 +596,14 @@ class Gen:
         """resolve passes until the queue is empty"""
         p = self.p
         drain, drained = self.lbl("drain"), self.lbl("drained")
-        p.i("s_bitset1_b32", s(S_STEPMASK), 16)                # (bit 16 of the step mask: "the queue is being emptied", read by the pass)
+        p.i("s_bitset1_b32", s(S_USELOG), F_DRAIN)             # "the queue is being emptied", read by the pass
         p.label(drain)
         p.i("s_cmp_eq_u32", s(S_QTAIL4), s(S_QHEAD4))
         p.i("s_cbranch_scc1", "@" + drained)
         self.call("pass")
         p.i("s_branch", "@" + drain)
         p.label(drained)
-        p.i("s_bitset0_b32", s(S_STEPMASK), 16)
+        p.i("s_bitset0_b32", s(S_USELOG), F_DRAIN)
 
     def quarter_enter(self, q):
         """before step 4 q of block n.  The 4 windows of the coming quarter start in quarter q of chunk n - 1 - j and end, at the latest, in quarter q of
@@ -683,7 +686,7 @@ class Gen:
         p.i("ds_write2_b32", v(t1), v(rest), v(y), mods=f"offset0:0 offset1:{QSTRIDE}")
         p.i("ds_write_b32", v(t1), v(zr), mods=f"offset:{QSTRIDE * 8}")
         p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
-        p.i("s_bitcmp1_b32", s(S_STEPMASK), 16)               # another round?  only when the queue is being emptied (drain: a pass run for want of room
+        p.i("s_bitcmp1_b32", s(S_USELOG), F_DRAIN)            # another round?  only when the queue is being emptied (drain: a pass run for want of room
         p.i("s_cbranch_scc0", "@passloaded")                  # leaves the words it puts back to the next one, which costs nothing) ...
         p.i("s_cmp_lt_u32", s(S_CC), 64)                      # ... with idle lanes ...
         p.i("s_cbranch_scc0", "@passloaded")
@@ -792,7 +795,7 @@ class Gen:
             p.i("v_cmp_ne_u32_e32", "vcc", 0, v(t1))
         p.i("v_cmp_eq_u32_e64", sr(S_TMP, 2), 0, v(sflag))    # S_TMP = hits to log
         p.i("s_bcnt1_i32_b64", s(S_B), sr(S_TMP, 2))
-        p.i("s_cmp_eq_u32", s(S_USELOG), 1)
+        p.i("s_bitcmp1_b32", s(S_USELOG), F_USELOG)
         p.i("s_cbranch_scc0", "@" + nolog)
         p.i("s_lshl2_add_u32", s(S_A), s(S_B), s(S_LFILL4))
         p.i("s_cmp_le_u32", s(S_A), s(S_LOGCAP4))
@@ -873,7 +876,7 @@ class Gen:
         p.i("s_cmp_lt_u32", s(S_LREG), s(S_LOGREG))
         ok = self.lbl("lsw_ok")
         p.i("s_cbranch_scc1", "@" + ok)
-        p.i("s_mov_b32", s(S_USELOG), 0)                      # out of regions: ntComp's increment as device atomics from here on
+        p.i("s_bitset0_b32", s(S_USELOG), F_USELOG)           # out of regions: ntComp's increment as device atomics from here on
         p.i("s_mov_b64", "exec", "vcc")
         p.i("s_branch", "@logswitch_back")
         p.label(ok)
@@ -955,8 +958,7 @@ class Gen:
         p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["tails"]))
         p.i("s_waitcnt", "lgkmcnt(0)")
         p.i("s_cmp_lg_u64", sr(S_TMP, 2), 0)
-        p.i("s_cselect_b32", s(S_RAGGED), 1, 0)
-        p.i("s_mov_b32", s(S_TAILMASK), 0)
+        p.i("s_cselect_b32", s(S_USELOG), 1 << F_RAGGED, 0)   # (bit F_USELOG joins it below)
         p.i("s_lshl_b32", s(S_LOGCAP4), s(S_LOGCAP4), 2)
         p.i("s_lshl_b32", s(S_SUSCAP), s(S_SUSCAP), 4)         # bytes
         p.i("s_mul_i32", s(S_A), s(S_WT), s(S_SUSCAP))
@@ -998,13 +1000,14 @@ class Gen:
         p.i("s_add_u32", s(S_NB), s(S_NB), 1)
         # hit log: this wave's first region
         p.i("s_cmp_lg_u32", s(S_LOGREG), 0)
-        p.i("s_cselect_b32", s(S_USELOG), 1, 0)
+        p.i("s_cselect_b32", s(S_A), 1, 0)
         p.i("s_mov_b32", s(S_LREG), s(S_WT))
         p.i("s_mov_b32", s(S_LFILL4), 0)
         p.i("s_cmp_lt_u32", s(S_LREG), s(S_LOGREG))
-        p.i("s_cselect_b32", s(S_USELOG), s(S_USELOG), 0)
+        p.i("s_cselect_b32", s(S_A), s(S_A), 0)
+        p.i("s_or_b32", s(S_USELOG), s(S_USELOG), s(S_A))
         nolog0 = self.lbl("nolog0")
-        p.i("s_cmp_eq_u32", s(S_USELOG), 1)
+        p.i("s_bitcmp1_b32", s(S_USELOG), F_USELOG)
         p.i("s_cbranch_scc0", "@" + nolog0)
         self.load_log_region()
         p.label(nolog0)
@@ -1076,7 +1079,7 @@ class Gen:
             def cold_tail(a=a, skip=skip, notstep=notstep, dostep=dostep, tailp=tailp):
                 # a step the mask leaves out (a filling block, the steps behind the read) — or, in a ragged batch, one that ends in the reads' last piece
                 p.label(notstep)
-                p.i("s_bitcmp1_b32", s(S_TAILMASK), a)
+                p.i("s_bitcmp1_b32", s(S_STEPMASK), 16 + a)
                 p.i("s_cbranch_scc0", "@" + skip)
                 p.i("s_mov_b32", s(S_B), 4 * ((self.phi + a) & 15))   # the step ends at base 16 (C - 1) + d of the reads: d x 4
                 self.call("tailsub")
@@ -1207,7 +1210,7 @@ class Gen:
         # tails[tile][d] of them.  The steps that end in the last piece (e >= 16 (C - 1)) leave the step mask for the tail mask: their code (tail_step,
         # out of line) narrows the candidate masks to that prefix and counts tails[tile][d] windows into F1 instead of one per read.
         noragged = self.lbl("noragged")
-        p.i("s_cmp_eq_u32", s(S_RAGGED), 1)
+        p.i("s_bitcmp1_b32", s(S_USELOG), F_RAGGED)
         p.i("s_cbranch_scc0", "@" + noragged)
         p.i("s_sub_u32", s(S_B), s(S_C), 1)
         p.i("s_lshl_b32", s(S_B), s(S_B), 4)
@@ -1215,9 +1218,11 @@ class Gen:
         p.i("s_max_i32", s(S_B), s(S_B), 0)
         p.i("s_min_i32", s(S_B), s(S_B), 16)
         p.i("s_bfm_b32", s(S_B), s(S_B), 0)                      # the steps before it
-        p.i("s_andn2_b32", s(S_TAILMASK), s(S_STEPMASK), s(S_B))
+        p.i("s_andn2_b32", s(S_A), s(S_STEPMASK), s(S_B))        # (e0 is spent)
         p.i("s_and_b32", s(S_STEPMASK), s(S_STEPMASK), s(S_B))
         p.i("s_bcnt1_i32_b32", s(S_CC), s(S_STEPMASK))
+        p.i("s_lshl_b32", s(S_A), s(S_A), 16)
+        p.i("s_or_b32", s(S_STEPMASK), s(S_STEPMASK), s(S_A))
         p.label(noragged)
         # F1 (ntcard.cpp:154): every window of every valid read counts here (K1f takes the invalid ones back)
         p.i("s_add_u32", s(S_A), s(S_WT), 1)
@@ -1261,7 +1266,7 @@ class Gen:
             p.i("global_store_dword", v(V_WAVE4), v(T), sr(S_TMP, 2))
         p.i("s_mov_b64", "exec", -1)
         nofill = self.lbl("nofill")
-        p.i("s_cmp_eq_u32", s(S_USELOG), 1)
+        p.i("s_bitcmp1_b32", s(S_USELOG), F_USELOG)
         p.i("s_cbranch_scc0", "@" + nofill)
         self.store_log_fill()
         p.label(nofill)

@@ -16,6 +16,8 @@
 //                         be written once, so parallelism comes from the workgroup size, not from their number.
 //                         Round 2 history per 183 M keys: two LDS atomics per key, 256 threads x 1024 workgroups
 //                         0.85 + 0.65 ms; one returning atomic + prefetch, 256 x 512: 0.51 + 0.36 ms; this form ~0.6 ms.
+//                         The last pass writes its runs as uint16 (round 5): the run says which slice, A3 needs the low
+//                         slice_bits <= 15 bits only — 2 B per key less written and 2 B less read, half the scratch of that pass.
 //   A3     count_kernel   one workgroup per slice of 2^15 counters: histogram of the slice's keys in LDS
 //                         (ds_add on 16-bit fields, single writer per slice), then one coalesced `sketch[i] += n` sweep.
 //
@@ -74,6 +76,8 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 		step = a.parts * a.nb_in;
 	}
 	uint32_t* const outw = a.out + (uint64_t)w * nb * a.out_cap;
+	uint16_t* const outw16 = reinterpret_cast<uint16_t*>(a.out) + (uint64_t)w * nb * a.out_cap;
+	const bool narrow = a.narrow != 0;
 	__syncthreads();
 	for (; seg < a.n_in; seg += step) {
 		uint32_t n = a.in_cnt[seg];
@@ -127,9 +131,11 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 			for (uint32_t i = tid; i < m; i += kSplitThreads) {
 				const uint32_t kk = sorted[i];
 				const uint32_t off = rel[(kk >> a.shift) & dmask] + i;
-				if (off < a.out_cap)
-					outw[(uint64_t)((kk >> a.shift) & dmask) * a.out_cap + off] = kk;
-				else
+				if (off < a.out_cap) {
+					const uint64_t at = (uint64_t)((kk >> a.shift) & dmask) * a.out_cap + off;
+					if (narrow) outw16[at] = (uint16_t)kk;
+					else outw[at] = kk;
+				} else
 					atomicAdd(a.sketch + kk, 1u); // run is full: apply directly (exact, slower)
 			}
 			__syncthreads(); // sorted / rel are rewritten by the next round
@@ -179,8 +185,9 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 				n = n < a.in_cap ? n : a.in_cap;
 				const uint32_t take = n - off < 65535u - taken ? n - off : 65535u - taken;
 				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap + off;
+				const uint16_t* src16 = reinterpret_cast<const uint16_t*>(a.in) + (uint64_t)seg * a.in_cap + off;
 				for (uint32_t i = tid; i < take; i += nt) {
-					const uint32_t kk = src[i] & cmask;
+					const uint32_t kk = (a.in16 ? (uint32_t)src16[i] : src[i]) & cmask;
 					// hot counters (a few thousand distinct k-mers sampled at huge coverage: every key of a run is the same) would put all 64
 					// lanes on one LDS word, 64 serialised atomics per instruction: a wave whose keys are all equal adds their number once
 					const uint64_t act = __ballot(true);

@@ -253,6 +253,8 @@ struct ntc_engine {
 	struct ApplyPlan {
 		uint32_t key_bits = 0, slice_bits = 0, b1 = 0, b2 = 0; // key = [b1 | b2 | slice_bits]
 		uint32_t g1 = 0, parts2 = 0, cap1 = 0, cap2 = 0, n_slices = 0;
+		// bytes per key in the runs of partition pass 1 / 2: the LAST pass writes uint16 (the run implies the slice; A3 reads the low slice_bits <= 15 bits)
+		size_t key_bytes(int pass) const { return (pass == 2 || b2 == 0) ? 2 : 4; }
 	} ap;
 	uint32_t *d_s1 = nullptr, *d_c1 = nullptr, *d_s2 = nullptr, *d_c2 = nullptr; // partition scratch (allocated at the first apply)
 	std::vector<void*> d_t4s;       // K1f: closed-form table, 4 bases per entry, per k of the list (empty: the engine has no tiled kernel)
@@ -448,13 +450,13 @@ int apply_log(ntc_engine* e)
 	const uint32_t nb1 = 1u << ap.b1, nb2 = 1u << ap.b2;
 	if (ap.b1 && !e->d_s1) {
 		const size_t runs1 = (size_t)ap.g1 * nb1;
-		if (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * 4) != hipSuccess || hipMalloc((void**)&e->d_c1, runs1 * 4) != hipSuccess)
-			return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of partition scratch on device", runs1 * ap.cap1 * 4);
+		if (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * ap.key_bytes(1)) != hipSuccess || hipMalloc((void**)&e->d_c1, runs1 * 4) != hipSuccess)
+			return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of partition scratch on device", runs1 * ap.cap1 * ap.key_bytes(1));
 	}
 	if (ap.b2 && !e->d_s2) {
 		const size_t runs2 = (size_t)nb1 * ap.parts2 * nb2;
-		if (hipMalloc((void**)&e->d_s2, runs2 * ap.cap2 * 4) != hipSuccess || hipMalloc((void**)&e->d_c2, runs2 * 4) != hipSuccess)
-			return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of partition scratch on device", runs2 * ap.cap2 * 4);
+		if (hipMalloc((void**)&e->d_s2, runs2 * ap.cap2 * ap.key_bytes(2)) != hipSuccess || hipMalloc((void**)&e->d_c2, runs2 * 4) != hipSuccess)
+			return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of partition scratch on device", runs2 * ap.cap2 * ap.key_bytes(2));
 	}
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (e->profiling) {
@@ -490,6 +492,7 @@ int apply_log(ntc_engine* e)
 		s1.out_cnt = e->d_c1;
 		s1.out_cap = ap.cap1;
 		s1.sketch = e->d_sketch;
+		s1.narrow = ap.b2 == 0;
 		HIP_TRY(ntc::launch_split(s1, ap.g1, e->stream));
 		if (ap.b2 == 0) {
 			c.in = e->d_s1;
@@ -499,6 +502,7 @@ int apply_log(ntc_engine* e)
 			c.mode = 1;
 			c.nb1 = nb1;
 			c.nwg1 = ap.g1;
+			c.in16 = 1;
 		} else {
 			ntc::SplitArgs s2;
 			std::memset(&s2, 0, sizeof s2);
@@ -515,6 +519,7 @@ int apply_log(ntc_engine* e)
 			s2.out_cnt = e->d_c2;
 			s2.out_cap = ap.cap2;
 			s2.sketch = e->d_sketch;
+			s2.narrow = 1;
 			HIP_TRY(ntc::launch_split(s2, nb1 * ap.parts2, e->stream));
 			c.in = e->d_s2;
 			c.in_cnt = e->d_c2;
@@ -523,6 +528,7 @@ int apply_log(ntc_engine* e)
 			c.mode = 2;
 			c.parts = ap.parts2;
 			c.nb2 = nb2;
+			c.in16 = 1;
 		}
 	}
 	DevInfo di;
@@ -985,8 +991,8 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 			bool ok = hipMalloc((void**)&e->d_log, e->log_cap * 4) == hipSuccess && hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) == hipSuccess;
 			ok = ok && (e->d_logmode || hipMalloc((void**)&e->d_logmode, 4) == hipSuccess) && (e->d_logstats || hipMalloc((void**)&e->d_logstats, 24) == hipSuccess) &&
 			     (e->d_probe || hipMalloc((void**)&e->d_probe, 4u << 20) == hipSuccess);
-			ok = ok && (!runs1 || (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * 4) == hipSuccess && hipMalloc((void**)&e->d_c1, runs1 * 4) == hipSuccess));
-			ok = ok && (!runs2 || (hipMalloc((void**)&e->d_s2, runs2 * ap.cap2 * 4) == hipSuccess && hipMalloc((void**)&e->d_c2, runs2 * 4) == hipSuccess));
+			ok = ok && (!runs1 || (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * ap.key_bytes(1)) == hipSuccess && hipMalloc((void**)&e->d_c1, runs1 * 4) == hipSuccess));
+			ok = ok && (!runs2 || (hipMalloc((void**)&e->d_s2, runs2 * ap.cap2 * ap.key_bytes(2)) == hipSuccess && hipMalloc((void**)&e->d_c2, runs2 * 4) == hipSuccess));
 			if (ok) break;
 			(void)hipGetLastError();
 			for (void** d : {(void**)&e->d_log, (void**)&e->d_logfill, (void**)&e->d_s1, (void**)&e->d_c1, (void**)&e->d_s2, (void**)&e->d_c2})
