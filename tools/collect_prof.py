@@ -40,11 +40,13 @@ def main():
     # of an engine is split into a small head, whose hit log is sampled to choose the update mode, and the rest), so the
     # per-step figure is the SUM over all dispatches divided by the number of steps the command ran (warm-up + timed).
     n_steps = (bench["steps"] + bench["warmup"]) if bench else None
-    if ks and n_steps:
+    # (the kernel trace runs every repeat of the timed region: warmup + repeats x steps; the PMC passes run one)
+    n_trace = (bench["warmup"] + bench.get("repeats", 1) * bench["steps"]) if bench else None
+    if ks and n_trace:
         for r in csv.DictReader(open(ks[0])):
             if "sketch_" in r["Name"] or "k1h_" in r["Name"]:
-                lines.append("   -> %s: %d dispatches over %d bench steps = %.4f ms per step" %
-                             (r["Name"][:48], int(r["Calls"]), n_steps, float(r["TotalDurationNs"]) / n_steps / 1e6))
+                lines.append("   -> %s: %d dispatches over %d bench steps (%d warm-up + %d x %d timed) = %.4f ms per step" %
+                             (r["Name"][:48], int(r["Calls"]), n_trace, bench["warmup"], bench.get("repeats", 1), bench["steps"], float(r["TotalDurationNs"]) / n_trace / 1e6))
     hash_kernels = {}
     for k, v in agg.items():
         if any(t in k for t in ("sketch_", "k1h_", "split_kernel", "count_kernel", "finalize")):

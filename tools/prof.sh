@@ -15,9 +15,11 @@ if [ "${PROF_PHASE:-all}" != counters ]; then
   python $ROOT/bench.py $ARGS 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 fi
 if [ "${PROF_PHASE:-all}" = bench ]; then exit 0; fi
-# under the profiler: ONE timed region and no second engine, so that dispatches / (steps + warmup) is the per-step figure
+# the kernel trace runs the SAME command as the bench line (all repeats of the timed region: warmup + repeats x steps launches, so that the
+# average duration of the hash kernel is the one the bench line's HIP events see), without the second engine of roofline_nodefer
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS --no-nodefer > $OUT/trace.log 2>&1
+# the PMC passes: ONE timed region, so that dispatches / (steps + warmup) is the per-step figure
 ARGS="$ARGS --repeats 1 --no-nodefer"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS"; do
