@@ -908,6 +908,10 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	*out = nullptr;
 	if (cfg->n_k == 0 || cfg->n_k > NTC_MAX_K_LIST || !cfg->k)
 		return fail(NTC_ERR_ARG, "ntc_create: need 1..%d k values", NTC_MAX_K_LIST);
+	constexpr uint32_t kKnownFlags = NTC_FLAG_SIMPLE_KERNEL | NTC_FLAG_DIRECT_ATOMICS | NTC_FLAG_ALWAYS_LOG | NTC_FLAG_PARTITION_ALWAYS | NTC_FLAG_LANE_KERNEL |
+	                                 NTC_FLAG_REQUIRE_TILED | NTC_FLAG_DEFER_REDO;
+	if (cfg->flags & ~kKnownFlags) // (ABI 4's NTC_FLAG_BITSLICE_KERNEL = 4 and NTC_FLAG_TILED_TEAMS = 256 selected kernels that no longer exist)
+		return fail(NTC_ERR_ARG, "ntc_create: unknown flag bits 0x%x", cfg->flags & ~kKnownFlags);
 	for (uint32_t i = 0; i < cfg->n_k; ++i)
 		if (cfg->k[i] < 1 || cfg->k[i] > kMaxK)
 			return fail(NTC_ERR_ARG, "ntc_create: k=%u outside 1..%u", cfg->k[i], kMaxK);

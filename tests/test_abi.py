@@ -97,3 +97,6 @@ def test_bad_arguments_are_rejected_before_touching_the_device():
     cfg = _abi.NtcConfig(n_k=1, k=C.cast(k1, C.POINTER(C.c_uint32)), gap=3, r_bits=27, s_bits=7, device=0)
     assert L.ntc_create(C.byref(cfg), C.byref(h)) == -1  # g%2 != k%2 (ntcard.cpp:382-385)
     assert L.ntc_create(None, C.byref(h)) == -1
+    for gone in (4, 256, 1 << 20):  # ABI 4's NTC_FLAG_BITSLICE_KERNEL / NTC_FLAG_TILED_TEAMS selected kernels that were retired; unknown bits are an error, not ignored
+        cfg = _abi.NtcConfig(n_k=1, k=C.cast(k1, C.POINTER(C.c_uint32)), gap=0, r_bits=20, s_bits=7, device=0, flags=gone)
+        assert L.ntc_create(C.byref(cfg), C.byref(h)) == -1 and b"flag" in L.ntc_last_error()
