@@ -15,7 +15,7 @@ ABI_SYMBOLS = [
     "ntc_submit", "ntc_submit_spans", "ntc_submit_device", "ntc_sync", "ntc_finish", "ntc_device_state",
     "ntc_hash_dump_device", "ntc_hash_dump_k1_device", "ntc_gen_reads_device", "ntc_estimate", "ntc_write_hist",
     "ntc_kernel_time", "ntc_apply_time", "ntc_fixup_time", "ntc_merge_allocations", "ntc_update_mode", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
-    "ntc_submit_tiled_device", "ntc_submit_tiled_ragged_device", "ntc_tiled_bytes", "ntc_gen_reads_tiled_device",
+    "ntc_submit_tiled_device", "ntc_submit_tiled_ragged_device", "ntc_submit_tiled_bins_device", "ntc_tiled_bytes", "ntc_gen_reads_tiled_device",
     "ntc_narrow_u16_device", "ntc_sum_slices_u16_device", "ntc_value_hist_u16_device",
 ]
 
@@ -73,6 +73,7 @@ def lib():
     L.ntc_submit_device.argtypes = [p, p, u64, u32, u32]
     L.ntc_submit_tiled_device.argtypes = [p, p, u64, u32]
     L.ntc_submit_tiled_ragged_device.argtypes = [p, p, u64, u32, p]
+    L.ntc_submit_tiled_bins_device.argtypes = [p, u32, p, p, p, p]
     L.ntc_tiled_bytes.argtypes = [u64, u32]
     L.ntc_tiled_bytes.restype = u64
     L.ntc_gen_reads_tiled_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u64]

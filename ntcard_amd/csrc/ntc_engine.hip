@@ -729,39 +729,86 @@ int run_tiled_as_rows(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_re
 }
 
 // K1h + K1f over one device-resident batch in the tiled layout (include/ntcard_hip.h: ntc_submit_tiled_device)
+// One device-resident tiled batch: equal-length reads (d_tails == nullptr) or one length bin of a ragged read set (read_len = 16 C)
+struct TiledSeg {
+	const unsigned char* d_tiles;
+	uint64_t n_reads;
+	uint32_t read_len;
+	const uint32_t* d_tails;
+};
+int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in);
+
 int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len, const uint32_t* d_tails = nullptr)
 {
-	if (n_reads == 0) return 0;
+	const TiledSeg one{d_tiles, n_reads, read_len, d_tails};
+	return run_tiled_segs(e, &one, 1);
+}
+
+// K1h + K1f over up to kK1hSegs tiled batches of different geometry in ONE launch per k (launch_sketch_k1h_multi): the length bins of a ragged read set
+// share the launch's workgroups in proportion to their blocks instead of queueing as small launches, each of which would pay the waves' start-up again
+int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
+{
+	std::vector<TiledSeg> segs;
+	for (uint32_t i = 0; i < n_in; ++i)
+		if (segs_in[i].n_reads) segs.push_back(segs_in[i]);
+	if (segs.empty()) return 0;
+	bool any_tails = false;
+	for (const auto& sg : segs)
+		any_tails |= sg.d_tails != nullptr;
 	if (!e->ts_ok && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
-	if (!e->ts_ok && d_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for this configuration");
-	if (!e->ts_ok) return run_tiled_as_rows(e, d_tiles, n_reads, read_len); // this configuration is K1's
-	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
-	{
+	if (!e->ts_ok && any_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for this configuration");
+	if (!e->ts_ok) { // this configuration is K1's
+		for (const auto& sg : segs)
+			if (int rc = run_tiled_as_rows(e, sg.d_tiles, sg.n_reads, sg.read_len)) return rc;
+		return 0;
+	}
+	const uint32_t max_segs = std::min<uint32_t>(ntc::kK1hSegs, ntc::kK1fBatch);
+	if (segs.size() > max_segs) { // more bins than one launch takes: groups
+		for (size_t i = 0; i < segs.size(); i += max_segs)
+			if (int rc = run_tiled_segs(e, segs.data() + i, (uint32_t)std::min<size_t>(max_segs, segs.size() - i))) return rc;
+		return 0;
+	}
+	for (const auto& sg : segs) {
 		// K1h addresses its bit arrays (one word per tile, chunk / block and lane) with 32-bit byte offsets: a batch of several hundred GB is cut in
 		// two at a tile boundary, as often as it takes (any prefix of a tiled buffer is a batch)
-		const uint64_t rows = (uint64_t)(read_len + 15u) / 16u + 2u; // chunks, and at most chunks + 1 blocks, per tile
+		const uint64_t n_tiles = (sg.n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
+		const uint64_t rows = (uint64_t)(sg.read_len + 15u) / 16u + 2u; // chunks, and at most chunks + 1 blocks, per tile
 		if (n_tiles * rows * 256u >= (1ull << 32)) {
-			const uint64_t head_tiles = n_tiles / 2, head_reads = head_tiles * ntc::kTileReads;
-			if (int rc = run_tiled(e, d_tiles, head_reads, read_len, d_tails)) return rc;
-			return run_tiled(e, d_tiles + ntc_tiled_bytes(head_reads, read_len), n_reads - head_reads, read_len, d_tails ? d_tails + head_tiles * 16 : nullptr);
+			for (const auto& s2 : segs) { // (such a set of batches goes one by one, halves first)
+				if (&s2 != &sg) {
+					if (int rc = run_tiled_segs(e, &s2, 1)) return rc;
+					continue;
+				}
+				const uint64_t head_tiles = n_tiles / 2, head_reads = head_tiles * ntc::kTileReads;
+				const TiledSeg head{sg.d_tiles, head_reads, sg.read_len, sg.d_tails};
+				const TiledSeg rest{sg.d_tiles + ntc_tiled_bytes(head_reads, sg.read_len), sg.n_reads - head_reads, sg.read_len, sg.d_tails ? sg.d_tails + head_tiles * 16 : nullptr};
+				if (int rc = run_tiled_segs(e, &head, 1)) return rc;
+				if (int rc = run_tiled_segs(e, &rest, 1)) return rc;
+			}
+			return 0;
 		}
 	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
 	if (e->d_log) {
-		// candidates of this batch (both samples ~2^-sBits of the windows each, every k) + what every logging wave may leave unused at the
+		// candidates of these batches (both samples ~2^-sBits of the windows each, every k) + what every logging wave may leave unused at the
 		// end of a region; a log that could overflow is applied first (outside the hash kernels' timing events)
 		double est = 0;
-		for (uint32_t k : e->klist)
-			if (read_len >= k) est += 64.0 * 4096 + (double)n_reads * (double)(read_len - k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+		for (uint32_t k : e->klist) {
+			bool any = false;
+			for (const auto& sg : segs)
+				if (sg.read_len >= k) {
+					est += (double)sg.n_reads * (double)(sg.read_len - k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+					any = true;
+				}
+			if (any) est += 64.0 * 4096;
+		}
 		if (e->log_pending && e->log_est + est > 0.85 * (double)e->log_cap)
 			if (int rc = apply_log(e)) return rc;
 		e->log_est += est;
 		e->log_pending = true;
 	}
-	if (e->k1f_n + e->klist.size() > ntc::kK1fBatch) // no set left for this batch's K1h launches: K1f over the waiting ones first
-		if (int rc = join_k1f(e)) return rc;
-	// ntRead's loop over kList (ntcard.cpp:147-158): one launch per k over the same resident batch
+	// ntRead's loop over kList (ntcard.cpp:147-158): one launch per k over the same resident batches
 	auto open_run = [&]() -> int { // (again behind a K1f that had to come in the middle of the list)
 		if (e->profiling && !e->run_ev0) {
 			HIP_TRY(hipEventCreate(&e->run_ev0));
@@ -770,124 +817,140 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 		return 0;
 	};
 	bool counted = false; // this submit counts as one launch of ntc_kernel_time once its first kernel is queued (not at all when read_len < every k)
+	const uint32_t wpg = ntc::sketch_k1h_waves();                                              // waves per workgroup (one workgroup per CU)
+	const uint32_t max_waves = (uint32_t)di.cus * wpg;
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
-		if (read_len < k) continue; // no window of this k (ntHashIterator.hpp:61-64)
+		std::vector<const TiledSeg*> act; // no window of this k in a shorter read (ntHashIterator.hpp:61-64)
+		for (const auto& sg : segs)
+			if (sg.read_len >= k) act.push_back(&sg);
+		if (act.empty()) continue;
+		const uint32_t na = (uint32_t)act.size();
+		if (e->k1f_n + na > ntc::kK1fBatch) // no sets left for these launches: K1f over the waiting ones first
+			if (int rc = join_k1f(e)) return rc;
 		if (int rc = open_run()) return rc;
 		if (e->profiling && !counted) {
 			++e->run_submits;
 			counted = true;
 		}
-		{
-			// K1h + K1f: one wave per tile; the two bit arrays between them are scratch of this launch pair
-			const uint32_t n_chunks = (read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, read_len);
-			const size_t need_d = (size_t)n_tiles * n_chunks * 256, need_t = (size_t)n_tiles * nb * 256; // (< 2^32: larger batches were cut in two above)
-			{
-				// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
-				// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N against 2.4 ms for K1c).  The share: the
-				// blocks of a wave (launch_sketch_k1h: even shares of a workgroup's quota) + 1, all of
-				// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
-				// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
-				// 2 GiB per set (beyond that a launch may still overflow: slow path, exact).
-				const uint32_t wpg = ntc::sketch_k1h_waves();                                              // waves per workgroup (one workgroup per CU)
-				const uint32_t max_waves = (uint32_t)di.cus * wpg;
-				const uint64_t total_blocks = (uint64_t)n_tiles * nb;
-				const uint64_t per_wg = (uint64_t)wpg * ntc::sketch_k1h_min_blocks();
-				const uint64_t launch_wgs = std::min<uint64_t>((total_blocks + per_wg - 1) / per_wg, (uint64_t)di.cus); // (launch_sketch_k1h's grid)
-				const double lone_blocks = (double)((total_blocks + launch_wgs * wpg - 1) / (launch_wgs * wpg)) + 1.0; // blocks per wave (even shares)
-				const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
-				uint32_t sus_cap = (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 31) / 16u / max_waves));
-				if (const char* ev = std::getenv("NTC_K1H_SUS_CAP")) { // tests: a short list forces the overflow path
-					const long v = std::strtol(ev, nullptr, 10);
-					if (v >= 1 && v <= (long)sus_cap) sus_cap = (uint32_t)v;
-				}
-				if (e->k1f_n == ntc::kK1fBatch) // (a k list longer than the sets)
-					if (int rc = join_k1f(e)) return rc;
-				// the hand-over arrays of one set; an engine that defers K1f sizes ALL its sets at the first launch of a batch geometry (a set that grows
-				// later would stall the stream in the middle of a run)
-				auto ensure_set = [&](ntc_engine::K1hSet& s2) -> int {
-					if (need_d > s2.dirty_cap || need_t > s2.tie_cap || sus_cap > s2.sus_cap) HIP_TRY(hipStreamSynchronize(e->stream));
-					if (need_d > s2.dirty_cap || need_t > s2.tie_cap) {
-						if (s2.d_dirty) (void)hipFree(s2.d_dirty);
-						if (s2.d_tie) (void)hipFree(s2.d_tie);
-						s2.d_dirty = s2.d_tie = nullptr;
-						s2.dirty_cap = s2.tie_cap = 0;
-						if (hipMalloc((void**)&s2.d_dirty, need_d) != hipSuccess || hipMalloc((void**)&s2.d_tie, need_t) != hipSuccess)
-							return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
-						s2.dirty_cap = need_d;
-						s2.tie_cap = need_t;
-					}
-					if (sus_cap > s2.sus_cap) {
-						if (s2.d_sus) (void)hipFree(s2.d_sus);
-						s2.d_sus = nullptr;
-						s2.sus_cap = 0;
-						if (hipMalloc((void**)&s2.d_sus, (size_t)max_waves * sus_cap * 16) != hipSuccess)
-							return fail(NTC_ERR_MEMORY, "cannot allocate the %zu-byte suspect list of the tiled kernel on device", (size_t)max_waves * sus_cap * 16);
-						s2.sus_cap = sus_cap;
-					}
-					if (!s2.d_sus_count) {
-						if (hipMalloc((void**)&s2.d_sus_count, (size_t)max_waves * 4) != hipSuccess || hipMalloc((void**)&s2.d_fix_state, 16) != hipSuccess)
-							return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
-						HIP_TRY(hipMemsetAsync(s2.d_fix_state, 0, 16, e->stream));
-						HIP_TRY(hipMemsetAsync(s2.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
-					}
-					return 0;
-				};
-				auto& ks = e->k1h_set[e->k1f_n];
-				if (need_d > ks.dirty_cap || need_t > ks.tie_cap || sus_cap > ks.sus_cap || !ks.d_sus_count) {
-					if (e->k1f_n != 0) // the sets ahead are in use by launches whose K1f is still to come
-						if (int rc = join_k1f(e)) return rc;
-					for (uint32_t si = 0; si < (e->defer_redo ? ntc::kK1fBatch : 1u); ++si)
-						if (int rc = ensure_set(e->k1h_set[si])) {
-							// no memory for K1h's hand-over arrays (8 sets with NTC_FLAG_DEFER_REDO: up to ~0.5 GB each per 10 M reads): the
-							// batch is K1's, unless the caller insists on the tiled kernels or part of the k list has been launched already
-							if (e->ts_required || ki != 0 || d_tails) return rc;
-							if (int rc2 = close_run(e)) return rc2;
-							return run_tiled_as_rows(e, d_tiles, n_reads, read_len);
-						}
-				}
-				auto& ks0 = e->k1h_set[e->k1f_n]; // (k1f_n may be 0 now)
-				ntc::K1hArgs h;
-				std::memset(&h, 0, sizeof h);
-				h.sus = ks0.d_sus;
-				h.sus_count = ks0.d_sus_count;
-				h.sus_cap = sus_cap; // (<= the allocation's)
-				h.launch_id = ++e->k1h_launch_id;
-				if (h.launch_id == 0) h.launch_id = ++e->k1h_launch_id;
-				h.fix_state = ks0.d_fix_state;
-				h.tiles = d_tiles;
-				h.log = e->d_log;
-				h.log_fill = e->d_logfill;
-				h.sketch0 = e->d_sketch;
-				h.f1 = e->d_f1 + ki;
-				h.dirty = ks0.d_dirty;
-				h.tie = ks0.d_tie;
-				h.n_tiles = (uint32_t)n_tiles;
-				h.n_chunks = n_chunks;
-				h.read_len = read_len;
-				h.nv_last = (uint32_t)(n_reads - (n_tiles - 1) * ntc::kTileReads);
-				h.key_base = (uint32_t)(ki * e->plane_elems());
-				h.rmask2 = (uint32_t)((2ull << e->r_bits) - 1ull);
-				h.log_regions = e->d_log ? e->log_regions : 0u;
-				h.log_region_cap = e->log_region_cap;
-				h.table = e->d_k1h_tabs[ki];
-				h.s_bits = e->s_bits;
-				h.r_bits = e->r_bits;
-				h.tails = d_tails;
-				ntc::K1hArgs launched;
-				uint32_t n_waves = 0;
-				if (int rc = open_run()) return rc; // (a K1f above may have closed the bracket)
-				HIP_TRY(ntc::launch_sketch_k1h(h, k, e->gap, (unsigned)di.cus, e->stream, &launched, &n_waves));
-				auto& it = e->k1f_batch.item[e->k1f_n++];
-				it.a = launched;
-				it.t4 = e->d_t4s[ki];
-				it.k = k;
-				it.n_waves = n_waves;
-				if (!e->defer_redo) // the caller may change the batch once the stream has passed this call: K1f now
-					if (int rc = join_k1f(e)) return rc;
-				continue;
-			}
+		// the launch's geometry: workgroups and blocks per wave of every batch
+		ntc::K1hArgs hs[ntc::kK1hSegs], planned[ntc::kK1hSegs];
+		std::memset(hs, 0, sizeof hs);
+		for (uint32_t i = 0; i < na; ++i) {
+			hs[i].n_tiles = (uint32_t)((act[i]->n_reads + ntc::kTileReads - 1) / ntc::kTileReads);
+			hs[i].read_len = act[i]->read_len;
 		}
+		(void)ntc::plan_sketch_k1h(hs, na, k, (unsigned)di.cus, planned);
+		// K1h + K1f: the two bit arrays between them and the suspect list are scratch of a launch pair; the sets of one launch are sized alike
+		size_t need_d = 0, need_t = 0;
+		uint32_t sus_cap = 0;
+		for (uint32_t i = 0; i < na; ++i) {
+			const uint32_t n_chunks = (act[i]->read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, act[i]->read_len);
+			need_d = std::max(need_d, (size_t)hs[i].n_tiles * n_chunks * 256); // (< 2^32: larger batches were cut in two above)
+			need_t = std::max(need_t, (size_t)hs[i].n_tiles * nb * 256);
+			// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
+			// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N).  The share: the
+			// blocks of a wave (plan_sketch_k1h: even shares of a workgroup's quota) + 1, all of
+			// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
+			// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
+			// 2 GiB per set (beyond that a launch may still overflow: slow path, exact).
+			const double lone_blocks = (double)planned[i].blocks_per_wave + 1.0;
+			const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
+			sus_cap = std::max(sus_cap, (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 31) / 16u / max_waves)));
+		}
+		if (const char* ev = std::getenv("NTC_K1H_SUS_CAP")) { // tests: a short list forces the overflow path
+			const long v = std::strtol(ev, nullptr, 10);
+			if (v >= 1 && v <= (long)sus_cap) sus_cap = (uint32_t)v;
+		}
+		// the hand-over arrays of one set; an engine that defers K1f sizes ALL its sets at the first launch of a batch geometry (a set that grows
+		// later would stall the stream in the middle of a run)
+		auto ensure_set = [&](ntc_engine::K1hSet& s2) -> int {
+			if (need_d > s2.dirty_cap || need_t > s2.tie_cap || sus_cap > s2.sus_cap) HIP_TRY(hipStreamSynchronize(e->stream));
+			if (need_d > s2.dirty_cap || need_t > s2.tie_cap) {
+				if (s2.d_dirty) (void)hipFree(s2.d_dirty);
+				if (s2.d_tie) (void)hipFree(s2.d_tie);
+				s2.d_dirty = s2.d_tie = nullptr;
+				s2.dirty_cap = s2.tie_cap = 0;
+				if (hipMalloc((void**)&s2.d_dirty, need_d) != hipSuccess || hipMalloc((void**)&s2.d_tie, need_t) != hipSuccess)
+					return fail(NTC_ERR_MEMORY, "cannot allocate %zu B of scratch for the tiled kernel on device", need_d + need_t);
+				s2.dirty_cap = need_d;
+				s2.tie_cap = need_t;
+			}
+			if (sus_cap > s2.sus_cap) {
+				if (s2.d_sus) (void)hipFree(s2.d_sus);
+				s2.d_sus = nullptr;
+				s2.sus_cap = 0;
+				if (hipMalloc((void**)&s2.d_sus, (size_t)max_waves * sus_cap * 16) != hipSuccess)
+					return fail(NTC_ERR_MEMORY, "cannot allocate the %zu-byte suspect list of the tiled kernel on device", (size_t)max_waves * sus_cap * 16);
+				s2.sus_cap = sus_cap;
+			}
+			if (!s2.d_sus_count) {
+				if (hipMalloc((void**)&s2.d_sus_count, (size_t)max_waves * 4) != hipSuccess || hipMalloc((void**)&s2.d_fix_state, 16) != hipSuccess)
+					return fail(NTC_ERR_MEMORY, "cannot allocate the suspect list of the tiled kernel on device");
+				HIP_TRY(hipMemsetAsync(s2.d_fix_state, 0, 16, e->stream));
+				HIP_TRY(hipMemsetAsync(s2.d_sus_count, 0, (size_t)max_waves * 4, e->stream));
+			}
+			return 0;
+		};
+		bool grow = false;
+		for (uint32_t i = 0; i < na; ++i) {
+			const auto& ks = e->k1h_set[e->k1f_n + i];
+			grow |= need_d > ks.dirty_cap || need_t > ks.tie_cap || sus_cap > ks.sus_cap || !ks.d_sus_count;
+		}
+		if (grow) {
+			if (e->k1f_n != 0) // the sets ahead are in use by launches whose K1f is still to come
+				if (int rc = join_k1f(e)) return rc;
+			for (uint32_t si = 0; si < (e->defer_redo ? ntc::kK1fBatch : na); ++si)
+				if (int rc = ensure_set(e->k1h_set[si])) {
+					// no memory for K1h's hand-over arrays (8 sets with NTC_FLAG_DEFER_REDO: up to ~0.5 GB each per 10 M reads): the
+					// batches are K1's, unless the caller insists on the tiled kernels or part of the k list has been launched already
+					if (e->ts_required || ki != 0 || any_tails) return rc;
+					if (int rc2 = close_run(e)) return rc2;
+					for (const auto& sg : segs)
+						if (int rc3 = run_tiled_as_rows(e, sg.d_tiles, sg.n_reads, sg.read_len)) return rc3;
+					return 0;
+				}
+		}
+		for (uint32_t i = 0; i < na; ++i) {
+			auto& ks0 = e->k1h_set[e->k1f_n + i]; // (k1f_n may be 0 now)
+			ntc::K1hArgs& h = hs[i];
+			h.sus = ks0.d_sus;
+			h.sus_count = ks0.d_sus_count;
+			h.sus_cap = sus_cap; // (<= the allocation's)
+			h.launch_id = ++e->k1h_launch_id;
+			if (h.launch_id == 0) h.launch_id = ++e->k1h_launch_id;
+			h.fix_state = ks0.d_fix_state;
+			h.tiles = act[i]->d_tiles;
+			h.log = e->d_log;
+			h.log_fill = e->d_logfill;
+			h.sketch0 = e->d_sketch;
+			h.f1 = e->d_f1 + ki;
+			h.dirty = ks0.d_dirty;
+			h.tie = ks0.d_tie;
+			h.n_chunks = (act[i]->read_len + 15u) / 16u;
+			h.nv_last = (uint32_t)(act[i]->n_reads - (uint64_t)(h.n_tiles - 1) * ntc::kTileReads);
+			h.key_base = (uint32_t)(ki * e->plane_elems());
+			h.rmask2 = (uint32_t)((2ull << e->r_bits) - 1ull);
+			h.log_regions = e->d_log ? e->log_regions : 0u;
+			h.log_region_cap = e->log_region_cap;
+			h.table = e->d_k1h_tabs[ki];
+			h.s_bits = e->s_bits;
+			h.r_bits = e->r_bits;
+			h.tails = act[i]->d_tails;
+		}
+		ntc::K1hArgs launched[ntc::kK1hSegs];
+		uint32_t n_waves = 0;
+		if (int rc = open_run()) return rc; // (a K1f above may have closed the bracket)
+		HIP_TRY(ntc::launch_sketch_k1h_multi(hs, na, k, e->gap, (unsigned)di.cus, e->stream, launched, &n_waves));
+		for (uint32_t i = 0; i < na; ++i) {
+			auto& it = e->k1f_batch.item[e->k1f_n++];
+			it.a = launched[i];
+			it.t4 = e->d_t4s[ki];
+			it.k = k;
+			it.n_waves = n_waves;
+		}
+		if (!e->defer_redo) // the caller may change the batches once the stream has passed this call: K1f now
+			if (int rc = join_k1f(e)) return rc;
 	}
 	if (!e->profiling)
 		if (int rc = close_run(e)) return rc; // (profiling was switched off inside a run)
@@ -1176,6 +1239,26 @@ int ntc_submit_tiled_ragged_device(ntc_engine* e, const void* d_tiles, uint64_t 
 	return run_tiled(e, (const unsigned char*)d_tiles, n_reads, 16u * n_chunks, d_tails);
 }
 
+int ntc_submit_tiled_bins_device(ntc_engine* e, uint32_t n_bins, const void* const* d_tiles, const uint64_t* n_reads, const uint32_t* read_len,
+                                 const uint32_t* const* d_tails)
+{
+	if (!e) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: null engine");
+	if (n_bins == 0) return 0;
+	if (!d_tiles || !n_reads || !read_len || !d_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: null argument");
+	std::vector<TiledSeg> segs;
+	for (uint32_t i = 0; i < n_bins; ++i) {
+		if (n_reads[i] == 0) continue;
+		if (!d_tiles[i] || ((uintptr_t)d_tiles[i] & 15u) || ((uintptr_t)d_tails[i] & 3u)) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: bin %u: need a 16-byte aligned tile buffer", i);
+		if (read_len[i] == 0 || read_len[i] > 0xffffu || (d_tails[i] && (read_len[i] & 15u)))
+			return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: bin %u: read_len %u (a ragged bin's is 16 x its chunks, at most 65520)", i, read_len[i]);
+		segs.push_back(TiledSeg{(const unsigned char*)d_tiles[i], n_reads[i], read_len[i], d_tails[i]});
+	}
+	if (segs.empty()) return 0;
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	return run_tiled_segs(e, segs.data(), (uint32_t)segs.size());
+}
+
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len)
 {
 	const uint64_t n_tiles = (n_reads + ntc::kTileReads - 1) / ntc::kTileReads;
@@ -1205,7 +1288,15 @@ namespace {
 // ragged == false: every read is `len` bases long.  ragged == true (round 5): the reads are 16 C - 15 .. 16 C bases long, C = len / 16, and come
 // LONGEST FIRST (so every tile is sorted): the tiles are followed, in the same staging buffer, by tails[tile][16] — the reads of the tile with more than d
 // bases in their last piece — and the batch goes to ntc_submit_tiled_ragged_device's path.
-template <class LenFn, class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_t n_reads, uint32_t len, const LenFn& len_of, const PtrFn& ptr_of, bool ragged)
+// A host batch may hold several bins (HostBin: reads idx[0 .. n) of the caller's numbering, or 0 .. n when idx == nullptr): they are packed one behind the other into ONE
+// staging buffer, copied once and hashed by ONE launch per k (run_tiled_segs).
+struct HostBin {
+	const uint64_t* idx;
+	uint64_t n;
+	uint32_t len;  // every read's length, or 16 C for a ragged bin
+	bool ragged;
+};
+template <class LenFn, class PtrFn> int submit_tiled_host(ntc_engine* e, const HostBin* bins, uint32_t n_bins, const LenFn& len_of, const PtrFn& ptr_of)
 {
 	HIP_TRY(hipSetDevice(e->device));
 	ntc_engine::StageSlot* sl = nullptr;
@@ -1237,9 +1328,14 @@ template <class LenFn, class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_
 	} release{e, sl};
 	if (sl->done == nullptr) HIP_TRY(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
 	if (sl->used) HIP_TRY(hipEventSynchronize(sl->done));
-	const size_t tile_bytes = (size_t)ntc_tiled_bytes(n_reads, len);
-	const size_t n_tiles_h = (size_t)((n_reads + ntc::kTileReads - 1) / ntc::kTileReads);
-	const size_t need = tile_bytes + (ragged ? n_tiles_h * 64 : 0);
+	// sections: [tiles of bin 0][tails of bin 0][tiles of bin 1] ... (tile sections are multiples of 32 KiB, tails of 64 B: everything stays 16-byte aligned)
+	std::vector<size_t> off(n_bins), tile_bytes(n_bins);
+	size_t need = 0;
+	for (uint32_t b = 0; b < n_bins; ++b) {
+		off[b] = need;
+		tile_bytes[b] = (size_t)ntc_tiled_bytes(bins[b].n, bins[b].len);
+		need += tile_bytes[b] + (bins[b].ragged ? (size_t)((bins[b].n + ntc::kTileReads - 1) / ntc::kTileReads) * 64 : 0);
+	}
 	if (need > sl->h_stage_cap) {
 		if (sl->h_stage) (void)hipHostFree(sl->h_stage);
 		sl->h_stage = nullptr;
@@ -1260,33 +1356,40 @@ template <class LenFn, class PtrFn> int submit_tiled_host(ntc_engine* e, uint64_
 		}
 		sl->d_stage_cap = cap;
 	}
-	// ---- pack: piece c of read i -> ((tile * C + c) * 2048 + i % 2048) * 16 ----
-	unsigned char* hs = sl->h_stage;
-	const uint32_t C = (len + 15u) / 16u;
-	uint32_t* tails = reinterpret_cast<uint32_t*>(hs + tile_bytes);
-	if (ragged) std::memset(tails, 0, n_tiles_h * 64);
-	for (uint64_t i = 0; i < n_reads; ++i) {
-		const char* src = ptr_of(i);
-		const uint32_t tail = (uint32_t)(ragged ? len_of(i) : len) - (C - 1u) * 16u; // 1 .. 16 bases in the last piece
-		unsigned char* dst = hs + ((i / ntc::kTileReads) * C * ntc::kTileReads + i % ntc::kTileReads) * 16u;
-		for (uint32_t c = 0; c + 1u < C; ++c)
-			std::memcpy(dst + (size_t)c * ntc::kTileReads * 16u, src + 16u * c, 16);
-		unsigned char* last = dst + (size_t)(C - 1u) * ntc::kTileReads * 16u;
-		std::memcpy(last, src + 16u * (C - 1u), tail);
-		std::memset(last + tail, 'A', 16u - tail);
-		if (ragged)
-			for (uint32_t d = 0; d < tail; ++d)
-				++tails[(i / ntc::kTileReads) * 16u + d];
+	// ---- pack: piece c of read i of a bin -> ((tile * C + c) * 2048 + i % 2048) * 16 of the bin's section ----
+	for (uint32_t b = 0; b < n_bins; ++b) {
+		const HostBin& hb = bins[b];
+		unsigned char* hs = sl->h_stage + off[b];
+		const uint32_t C = (hb.len + 15u) / 16u;
+		uint32_t* tails = reinterpret_cast<uint32_t*>(hs + tile_bytes[b]);
+		if (hb.ragged) std::memset(tails, 0, (size_t)((hb.n + ntc::kTileReads - 1) / ntc::kTileReads) * 64);
+		for (uint64_t i = 0; i < hb.n; ++i) {
+			const uint64_t r = hb.idx ? hb.idx[i] : i;
+			const char* src = ptr_of(r);
+			const uint32_t tail = (uint32_t)(hb.ragged ? len_of(r) : hb.len) - (C - 1u) * 16u; // 1 .. 16 bases in the last piece
+			unsigned char* dst = hs + ((i / ntc::kTileReads) * C * ntc::kTileReads + i % ntc::kTileReads) * 16u;
+			for (uint32_t c = 0; c + 1u < C; ++c)
+				std::memcpy(dst + (size_t)c * ntc::kTileReads * 16u, src + 16u * c, 16);
+			unsigned char* last = dst + (size_t)(C - 1u) * ntc::kTileReads * 16u;
+			std::memcpy(last, src + 16u * (C - 1u), tail);
+			std::memset(last + tail, 'A', 16u - tail);
+			if (hb.ragged)
+				for (uint32_t d = 0; d < tail; ++d)
+					++tails[(i / ntc::kTileReads) * 16u + d];
+		}
 	}
 	{
 		std::lock_guard<std::mutex> lk(e->mu);
-		if (hipMemcpyAsync(sl->d_stage, hs, need, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
+		if (hipMemcpyAsync(sl->d_stage, sl->h_stage, need, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
 			(void)hipStreamSynchronize(e->stream);
 			return fail(NTC_ERR_DEVICE, "ntc_submit: host to device copy failed");
 		}
+		std::vector<TiledSeg> segs(n_bins);
+		for (uint32_t b = 0; b < n_bins; ++b)
+			segs[b] = TiledSeg{sl->d_stage + off[b], bins[b].n, bins[b].len, bins[b].ragged ? reinterpret_cast<const uint32_t*>(sl->d_stage + off[b] + tile_bytes[b]) : nullptr};
 		const bool keep = e->defer_redo; // the staging pair is recycled: its K1f may not be deferred
 		e->defer_redo = false;
-		const int rc = run_tiled(e, sl->d_stage, n_reads, ragged ? 16u * C : len, ragged ? reinterpret_cast<const uint32_t*>(sl->d_stage + tile_bytes) : nullptr);
+		const int rc = run_tiled_segs(e, segs.data(), n_bins);
 		e->defer_redo = keep;
 		sl->used = true;
 		if (hipEventRecord(sl->done, e->stream) != hipSuccess) (void)hipStreamSynchronize(e->stream);
@@ -1462,18 +1565,23 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 	const uint32_t kmin = *std::min_element(e->klist.begin(), e->klist.end());
 	if (e->ts_ok && n_reads >= 1024) {
 		// Reads of ONE length (an untrimmed FASTQ file) are one tiled batch.  Otherwise (round 5) the reads are binned by their number of 16-base pieces,
-		// C = ceil(len / 16): a bin of at least 512 Ki reads goes to the tiled kernels as a RAGGED batch — sorted longest first, K1h masks the windows
-		// behind every read's end — and what is left (thin bins, reads shorter than every k, sequences beyond 64 Ki bases) takes row slots and K1.
-		// (A K1h launch over fewer reads than that loses to K1: 0.5 M reads 0.065 ms against 0.042 — profiles/r05_batch_size_sweep.txt,
-		// profiles/r05_ragged_host.txt: 8 M reads of which 5 % are trimmed to 50 .. 149 bp took 0.91 ms with every bin of >= 1024 reads tiled, six of them
-		// thin, against 0.73 ms through K1 alone.  NTC_FLAG_REQUIRE_TILED, the validation flag, lowers the bar to 1024 reads.)
-		const uint32_t bin_min = e->ts_required ? 1024u : 512u * 1024u;
+		// C = ceil(len / 16): every bin of at least 32 Ki reads becomes a RAGGED tiled batch — sorted longest first, K1h masks the windows
+		// behind every read's end — all of them hashed by ONE launch per k that shares its workgroups among the bins (run_tiled_segs), and what is left
+		// (thin bins, reads shorter than every k, sequences beyond 64 Ki bases) takes row slots and K1.  profiles/r05_ragged_host.txt: 8 M reads of which
+		// 5 % are trimmed to 50 .. 149 bp: 0.483 ms with bins from 32 Ki reads, 0.527 from 512 Ki (the thin bins through K1), 0.728 through K1 alone;
+		// lengths uniform in 100 .. 150: 0.385 against 0.647.  (With one launch PER BIN, the first form of this, thin bins lost to K1 and the bar was 512 Ki.)
+		// NTC_FLAG_REQUIRE_TILED, the validation flag, lowers the bar to 1024 reads.
+		uint32_t bin_min = e->ts_required ? 1024u : 32u * 1024u;
+		if (const char* ev = std::getenv("NTC_BIN_MIN")) bin_min = (uint32_t)std::max(1024l, std::strtol(ev, nullptr, 10)); // tuning runs (tools/ragged_time.py)
 		const uint64_t len0 = len_of(0);
 		uint64_t same = 0;
 		for (uint64_t i = 0; i < n_reads; ++i)
 			same += len_of(i) == len0;
 		if (same == n_reads) {
-			if (len0 >= kmin && len0 <= 0xffffu) return submit_tiled_host(e, n_reads, (uint32_t)len0, len_of, ptr_of, false);
+			if (len0 >= kmin && len0 <= 0xffffu) {
+				const HostBin one{nullptr, n_reads, (uint32_t)len0, false};
+				return submit_tiled_host(e, &one, 1, len_of, ptr_of);
+			}
 		} else {
 			constexpr uint32_t kMaxC = 0x10000u / 16u;
 			std::vector<uint32_t> per_c(kMaxC + 1, 0u);
@@ -1497,7 +1605,8 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 					if (b >= 0) bins[(size_t)b].push_back(i);
 					else rest.push_back(i);
 				}
-				for (uint32_t c = 1; c <= kMaxC; ++c) {
+				std::vector<HostBin> hbins;
+				for (uint32_t c = kMaxC; c >= 1; --c) { // (longest bin first)
 					if (bin_of[c] < 0) continue;
 					std::vector<uint64_t>& idx = bins[(size_t)bin_of[c]];
 					// longest first: a counting sort by the 16 possible tails (stable)
@@ -1513,9 +1622,11 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 					}
 					for (uint64_t i : idx)
 						sorted[start[16u - (uint32_t)(len_of(i) - 16u * (c - 1u))]++] = i;
-					if (int rc = submit_tiled_host(e, sorted.size(), 16u * c, [&](uint64_t j) { return len_of(sorted[j]); }, [&](uint64_t j) { return ptr_of(sorted[j]); }, true))
-						return rc;
+					idx.swap(sorted);
+					hbins.push_back(HostBin{idx.data(), idx.size(), 16u * c, true});
 				}
+				// all the bins in one staging buffer and one launch per k (up to 8 bins: run_tiled_segs groups the rest)
+				if (int rc = submit_tiled_host(e, hbins.data(), (uint32_t)hbins.size(), len_of, ptr_of)) return rc;
 				if (rest.empty()) return 0;
 				return submit_rows(e, rest.size(), [&](uint64_t i) { return len_of(rest[i]); }, [&](uint64_t i) { return ptr_of(rest[i]); });
 			}

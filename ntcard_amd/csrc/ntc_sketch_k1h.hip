@@ -43,7 +43,7 @@ constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_b
 
 // the kernels live in ntc_sketch_k1h_body.hip, one object per part
 #define K1H_DECL_PART(p)                                                                                                                      \
-	hipError_t k1h_launch_part##p(uint32_t k, uint32_t gap, bool sb7, unsigned grid, uint32_t lds, hipStream_t st, const K1hArgs& b, bool* found); \
+	hipError_t k1h_launch_part##p(uint32_t k, uint32_t gap, bool sb7, unsigned grid, uint32_t lds, hipStream_t st, const K1hMulti& b, bool* found); \
 	hipError_t k1h_set_smem_part##p();
 K1H_DECL_PART(0) K1H_DECL_PART(1) K1H_DECL_PART(2) K1H_DECL_PART(3)
 static_assert(K1H_GEN_PARTS == 4, "one declaration / call per part");
@@ -528,28 +528,82 @@ hipError_t set_sketch_k1h_smem_limit()
 uint32_t sketch_k1h_min_blocks() { return kK1hMinBlocks; }
 uint32_t sketch_k1h_waves() { return kK1hWaves; } // waves per workgroup (the engine sizes the suspect regions by it)
 
+// Workgroups and block shares of a launch over n batches: the grid is what ONE batch with all the blocks would get (a wave needs ~4 blocks to be worth its
+// start-up), every batch a share of it in proportion to its blocks, at least one workgroup
+unsigned plan_sketch_k1h(const K1hArgs* a, uint32_t n, uint32_t k, unsigned cus, K1hArgs* out)
+{
+	uint64_t total[kK1hSegs], all = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		total[i] = (uint64_t)a[i].n_tiles * sketch_k1h_blocks(k, a[i].read_len);
+		all += total[i];
+	}
+	unsigned grid = (unsigned)std::min<uint64_t>((all + kK1hMinBlocks * kK1hWaves - 1) / (kK1hMinBlocks * kK1hWaves), cus);
+	grid = std::max<unsigned>(grid, n);
+	// largest-remainder apportionment of the workgroups
+	unsigned wg[kK1hSegs], given = 0;
+	double frac[kK1hSegs];
+	for (uint32_t i = 0; i < n; ++i) {
+		const double share = all ? (double)grid * (double)total[i] / (double)all : 1.0;
+		wg[i] = std::max<unsigned>(1u, (unsigned)share);
+		frac[i] = share - (double)wg[i];
+		given += wg[i];
+	}
+	while (given < grid) { // hand the rest to the largest remainders
+		uint32_t best = 0;
+		for (uint32_t i = 1; i < n; ++i)
+			if (frac[i] > frac[best]) best = i;
+		++wg[best];
+		frac[best] -= 1.0;
+		++given;
+	}
+	while (given > grid) { // (the minimum of one pushed the sum over: take from the batch with the fewest blocks per workgroup)
+		uint32_t best = n;
+		for (uint32_t i = 0; i < n; ++i)
+			if (wg[i] > 1u && (best == n || (double)total[i] / wg[i] < (double)total[best] / wg[best])) best = i;
+		if (best == n) break;
+		--wg[best];
+		--given;
+	}
+	unsigned first = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		out[i] = a[i];
+		out[i].first_wg = first;
+		out[i].n_wg = wg[i];
+		out[i].blocks_per_wave = (uint32_t)((total[i] + (uint64_t)wg[i] * kK1hWaves - 1) / ((uint64_t)wg[i] * kK1hWaves));
+		out[i].nb_magic = (uint32_t)((1ull << 32) / sketch_k1h_blocks(k, a[i].read_len));
+		first += wg[i];
+	}
+	return first;
+}
+
+hipError_t launch_sketch_k1h_multi(const K1hArgs* a, uint32_t n, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
+{
+	if (n == 0 || n > kK1hSegs) return hipErrorInvalidValue;
+	for (uint32_t i = 0; i < n; ++i)
+		if (!sketch_k1h_supports(k, gap, a[i].s_bits, a[i].r_bits) || a[i].s_bits != a[0].s_bits || a[i].table != a[0].table) return hipErrorInvalidValue;
+	K1hMulti m;
+	std::memset(&m, 0, sizeof m);
+	m.n_segs = n;
+	const unsigned grid = plan_sketch_k1h(a, n, k, cus, m.seg);
+	const uint32_t lds = k1h_lds_bytes(k);
+	const bool sb7 = a[0].s_bits == 7;
+	bool found = false;
+	hipError_t rc = k1h_launch_part0(k, gap, sb7, grid, lds, st, m, &found);
+	if (!found) rc = k1h_launch_part1(k, gap, sb7, grid, lds, st, m, &found);
+	if (!found) rc = k1h_launch_part2(k, gap, sb7, grid, lds, st, m, &found);
+	if (!found) rc = k1h_launch_part3(k, gap, sb7, grid, lds, st, m, &found);
+	if (!found) return hipErrorInvalidValue;
+	if (rc != hipSuccess) return rc;
+	for (uint32_t i = 0; i < n; ++i)
+		args_out[i] = m.seg[i];
+	*n_waves = grid * kK1hWaves;
+	return hipGetLastError();
+}
+
 // K1h over one batch on stream st; *args_out = the arguments as launched (block shares filled in), *n_waves = its waves (suspect regions)
 hipError_t launch_sketch_k1h(const K1hArgs& a, uint32_t k, uint32_t gap, unsigned cus, hipStream_t st, K1hArgs* args_out, uint32_t* n_waves)
 {
-	if (!sketch_k1h_supports(k, gap, a.s_bits, a.r_bits)) return hipErrorInvalidValue;
-	const uint32_t nb = sketch_k1h_blocks(k, a.read_len);
-	const uint64_t total = (uint64_t)a.n_tiles * nb; // blocks of the batch, shared out evenly: a wave needs at least ~4 blocks to be worth its start-up
-	const unsigned grid = (unsigned)std::min<uint64_t>((total + kK1hMinBlocks * kK1hWaves - 1) / (kK1hMinBlocks * kK1hWaves), cus);
-	K1hArgs b = a;
-	b.blocks_per_wave = (uint32_t)((total + (uint64_t)grid * kK1hWaves - 1) / ((uint64_t)grid * kK1hWaves));
-	b.nb_magic = (uint32_t)((1ull << 32) / nb);
-	const uint32_t lds = k1h_lds_bytes(k);
-	const bool sb7 = a.s_bits == 7;
-	bool found = false;
-	hipError_t rc = k1h_launch_part0(k, gap, sb7, grid, lds, st, b, &found);
-	if (!found) rc = k1h_launch_part1(k, gap, sb7, grid, lds, st, b, &found);
-	if (!found) rc = k1h_launch_part2(k, gap, sb7, grid, lds, st, b, &found);
-	if (!found) rc = k1h_launch_part3(k, gap, sb7, grid, lds, st, b, &found);
-	if (!found) return hipErrorInvalidValue;
-	if (rc != hipSuccess) return rc;
-	*args_out = b;
-	*n_waves = grid * kK1hWaves;
-	return hipGetLastError();
+	return launch_sketch_k1h_multi(&a, 1, k, gap, cus, st, args_out, n_waves);
 }
 
 // K1f for the batches K1h has been launched over (arguments as launched), on any stream ordered behind those launches

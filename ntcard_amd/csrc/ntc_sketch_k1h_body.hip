@@ -72,29 +72,39 @@ K1H_MY_VARIANTS(K1H_BODY_SPECS)
 } // namespace
 
 template <int K, int SB, int GAP>
-__global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hArgs a)
+__global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hMulti m)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	// the segment (batch) this workgroup walks: the segments own consecutive workgroup ranges (K1hMulti; a launch over one batch has one segment)
+	uint32_t s = 0;
+	while (s + 1u < m.n_segs && blockIdx.x >= m.seg[s + 1u].first_wg)
+		++s;
+	s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+	const K1hArgs& a = m.seg[s];
 	{ // the closed-form table: [2 strands][ceil(k / 3)][64] dwords behind the eight wave areas
 		constexpr uint32_t n = 2u * ((K + 2) / 3) * 64u;
 		uint32_t* dst = reinterpret_cast<uint32_t*>(smem + kK1hTableOff);
+		const uint32_t* tab = m.seg[0].table; // (the same for every segment)
 		for (uint32_t i = threadIdx.x; i < n; i += kK1hThreads)
-			dst[i] = a.table[i];
+			dst[i] = tab[i];
 	}
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	__syncthreads();
 	// Eight waves, two on every SIMD (round 4 ran six — two pairs and two lone waves — and weighed their shares by who sat alone): the workgroup's blocks
-	// are shared out evenly, as contiguous ranges of the flat sequence tile * NB + block.
-	const uint32_t quota = a.blocks_per_wave * kK1hWaves, wg0 = blockIdx.x * quota;
-	const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + wave * a.blocks_per_wave));
-	const uint32_t end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + (wave + 1u) * a.blocks_per_wave));
+	// are shared out evenly, as contiguous ranges of the flat sequence tile * NB + block of ITS segment.
+	const uint32_t bpw = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.blocks_per_wave);
+	const uint32_t wg_local = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x - a.first_wg));
+	const uint32_t quota = bpw * kK1hWaves, wg0 = wg_local * quota;
+	const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + wave * bpw));
+	const uint32_t end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + (wave + 1u) * bpw));
 	const uint32_t wave_gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kK1hWaves + wave));
 #ifdef K1H_STATIC_PRIO // timing experiment (tools/k1h_variant.sh): the second wave of every SIMD runs at a fixed higher priority
 	if (wave >= 4) __builtin_amdgcn_s_setprio(K1H_STATIC_PRIO);
 #endif
 	const uint32_t n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * kK1hWaves));
 	const uint32_t lds_wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * kK1hWArea));
-	const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+	// the body reads its arguments with scalar loads from the segment's K1hArgs inside the kernel argument segment
+	const uint64_t karg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(K1hMulti, seg) + (uint64_t)s * sizeof(K1hArgs);
 	const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)karg);
 	const uint32_t karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(karg >> 32));
 	K1hBody<K, SB, GAP>::run(karg_lo, karg_hi, wave_gid, n_waves, lds_wbase, first_block, end_block);
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hArgs a
 	if (rc == hipSuccess) rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<kk, 7, gg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k1h_lds_bytes(kk)); \
 	if (rc == hipSuccess) rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_k1h_kernel<kk, 8, gg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k1h_lds_bytes(kk));
 
-hipError_t K1H_CAT(k1h_launch_part, K1H_PART)(uint32_t k, uint32_t gap, bool sb7, unsigned grid, uint32_t lds, hipStream_t st, const K1hArgs& b, bool* found)
+hipError_t K1H_CAT(k1h_launch_part, K1H_PART)(uint32_t k, uint32_t gap, bool sb7, unsigned grid, uint32_t lds, hipStream_t st, const K1hMulti& b, bool* found)
 {
 	K1H_MY_VARIANTS(K1H_LAUNCH_CASE)
 	*found = false;

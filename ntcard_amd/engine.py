@@ -108,6 +108,16 @@ class Engine:
         d_tails = uint32[n_tiles][16] (include/ntcard_hip.h: ntc_submit_tiled_ragged_device; tile_reads_ragged builds both)"""
         check(self._lib.ntc_submit_tiled_ragged_device(self._h, C.c_void_p(d_tiles_ptr), n_reads, n_chunks, C.c_void_p(d_tails_ptr)))
 
+    def submit_tiled_bins_device(self, bins):
+        """several device-resident tiled batches in one call (include/ntcard_hip.h: ntc_submit_tiled_bins_device); bins: (d_tiles_ptr, n_reads, read_len,
+        d_tails_ptr or 0) — d_tails_ptr = 0: an equal-length batch, else a ragged one with read_len = 16 x its chunks"""
+        n = len(bins)
+        tiles = (C.c_void_p * n)(*[b[0] for b in bins])
+        nr = (C.c_uint64 * n)(*[b[1] for b in bins])
+        rl = (C.c_uint32 * n)(*[b[2] for b in bins])
+        tails = (C.c_void_p * n)(*[(b[3] or None) for b in bins])
+        check(self._lib.ntc_submit_tiled_bins_device(self._h, n, tiles, nr, rl, tails))
+
     def sync(self):
         check(self._lib.ntc_sync(self._h))
 

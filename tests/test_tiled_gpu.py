@@ -334,6 +334,31 @@ def test_tiled_ragged_batches(nt, n, C, k, p_bad, s_bits):
         assert np.array_equal(tc, oc)
 
 
+@pytest.mark.parametrize("klist,s_bits,sizes", [([32], 7, [(10, 9000), (9, 5000), (8, 2048), (7, 100)]), ([20, 32], 8, [(10, 3000), (2, 4000), (1, 2500)]),
+                                               ([25], 7, [(c, 1500 + 37 * c) for c in range(2, 12)])])
+def test_tiled_bins_in_one_launch(nt, klist, s_bits, sizes):
+    """ntc_submit_tiled_bins_device: several length bins — ragged ones and an equal-length one — share ONE K1h launch per k (K1hMulti: every bin its own
+    arguments, bit arrays, suspect list and a share of the workgroups); bins shorter than a k of the list sit that k out; more bins than a launch takes
+    go in groups.  Counters and F1 equal the oracle's over all reads, with and without deferred fix-ups"""
+    rng = np.random.default_rng(len(sizes) + klist[0])
+    bins, all_reads = [], []
+    for C, n in sizes:
+        reads = _ragged_reads(rng, n, 16 * C - 15, 16 * C, 0.004)
+        tiles, tails, order = nt.tile_reads_ragged(reads, C)
+        bins.append((torch.from_numpy(tiles).cuda(), n, 16 * C, torch.from_numpy(tails.reshape(-1).astype(np.int32)).cuda()))
+        all_reads += reads
+    uni = _ragged_reads(rng, 3333, 45, 45, 0.01)  # an equal-length bin (no tails) in the same call
+    bins.append((torch.from_numpy(nt.tile_reads(uni, 45)).cuda(), len(uni), 45, None))
+    all_reads += uni
+    oc, of1 = orc.sketch_reads(all_reads, klist, 0, 18, s_bits)
+    for flags in (0, nt.FLAG_DEFER_REDO):
+        with nt.Engine(klist, r_bits=18, s_bits=s_bits, flags=flags | nt.FLAG_REQUIRE_TILED) as e:
+            e.submit_tiled_bins_device([(t.data_ptr(), n, L, (d.data_ptr() if d is not None else 0)) for t, n, L, d in bins])
+            tc, ph, f1 = e.finish(counters=True)
+        assert np.array_equal(f1, of1), (f1, of1)
+        assert np.array_equal(tc, oc)
+
+
 def test_host_submit_of_mixed_lengths_takes_ragged_tiles(nt):
     """ntc_submit over adapter-trimmed-like reads (100 .. 150 bp, a few shorter than k, one long sequence): binned by ceil(len / 16), bins of >= 1024 reads
     as ragged tiles, the rest in row slots — counters and F1 equal the oracle's"""

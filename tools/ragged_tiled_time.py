@@ -30,16 +30,19 @@ for C in range(7, 11):
     tiles = np.ascontiguousarray(a.reshape(ntl, 2048, C, 16).transpose(0, 2, 1, 3)).reshape(-1)
     bins.append((C, m, torch.from_numpy(tiles).cuda(), torch.from_numpy(tails.reshape(-1)).cuda()))
 kmers = int(sum(np.maximum(lens - 31, 0)))
-for name in ("ragged tiles (K1h + K1f)",):
+for name in ("ragged tiles, one call per bin", "ragged tiles, the bins in one call"):
     with nt.Engine([32], r_bits=27, s_bits=7, flags=nt.FLAG_REQUIRE_TILED | nt.FLAG_DEFER_REDO) as e:
         for rep in range(2):
             e.reset(); e.set_profiling(True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(5):
-                for C, m, dt, dl in bins:
-                    e.submit_tiled_ragged_device(dt.data_ptr(), m, C, dl.data_ptr())
+                if "one call per bin" in name:
+                    for C, m, dt, dl in bins:
+                        e.submit_tiled_ragged_device(dt.data_ptr(), m, C, dl.data_ptr())
+                else:
+                    e.submit_tiled_bins_device([(dt.data_ptr(), m, 16 * C, dl.data_ptr()) for C, m, dt, dl in bins])
             e.flush(); e.sync(); dt_s = time.perf_counter() - t0
         ker, _ = e.kernel_time(); fix = e.fixup_time(); app, _ = e.apply_time()
         _, _, f1 = e.finish()
         assert int(f1[0]) == 5 * kmers, (int(f1[0]), 5 * kmers)
-    print("%-28s %d reads x 5: %.3f ms per pass  %.3f T k-mers/s  (hash %.3f fix-up %.3f apply %.3f ms per pass)" % (name, n, dt_s / 5 * 1e3, 5 * kmers / dt_s / 1e12, ker / 5, fix / 5, app / 5), flush=True)
+    print("%-36s %d reads x 5: %.3f ms per pass  %.3f T k-mers/s  (hash %.3f fix-up %.3f apply %.3f ms per pass)" % (name, n, dt_s / 5 * 1e3, 5 * kmers / dt_s / 1e12, ker / 5, fix / 5, app / 5), flush=True)
