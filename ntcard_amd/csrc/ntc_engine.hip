@@ -947,7 +947,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			it.a = launched[i];
 			it.t4 = e->d_t4s[ki];
 			it.k = k;
-			it.n_waves = n_waves;
+			it.n_waves = launched[i].n_wg * wpg; // (its suspect regions: those of the workgroups that walked it)
 		}
 		if (!e->defer_redo) // the caller may change the batches once the stream has passed this call: K1f now
 			if (int rc = join_k1f(e)) return rc;

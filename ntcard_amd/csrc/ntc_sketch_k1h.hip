@@ -120,8 +120,11 @@ __device__ __forceinline__ void k1f_f1_role(const K1fItem& item, const uint32_t 
 	const uint64_t n_rows = (uint64_t)a.n_tiles * C;
 	uint32_t f1_sub = 0;
 	bool slow = false;
+	// (the suspect regions of THIS batch: those of the workgroups that walked it — a launch over several batches, K1hMulti, leaves the other waves' regions
+	// of this batch's list untouched, with whatever an earlier launch left in their counts)
+	const uint32_t sus_w0 = a.first_wg * kK1hWaves;
 	for (uint32_t i = bx * 256u + tid; i < n_sus_waves; i += nbx * 256u)
-		slow |= a.sus_count[i] == 0xffffffffu; // a K1h wave ran out of room for its suspects
+		slow |= a.sus_count[sus_w0 + i] == 0xffffffffu; // a K1h wave ran out of room for its suspects
 	uint2* const queue = s_q[wv];
 	uint32_t qhead = 0, qtail = 0;
 	auto take = [&](uint32_t n_items) {
@@ -207,7 +210,8 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
 	const uint32_t rmask = (1u << r_bits) - 1u;
 	const uint4* const t4v = reinterpret_cast<const uint4*>(item.t4);
-	for (uint32_t reg = bx; reg < n_sus_waves; reg += nbx) { // a K1h wave's region per block (eight waves per CU: ~180 suspects per region and 10 M reads of dist g)
+	const uint32_t sus_w0 = a.first_wg * kK1hWaves; // (the regions of the workgroups that walked this batch)
+	for (uint32_t reg = sus_w0 + bx; reg < sus_w0 + n_sus_waves; reg += nbx) { // a K1h wave's region per block (eight waves per CU: ~180 suspects per region and 10 M reads of dist g)
 		uint32_t n = a.sus_count[reg];
 		if (n == 0xffffffffu) n = 0; // the region overflowed: the launch takes the slow path, which ignores the suspects
 		for (uint32_t i = tid; i < n; i += 256u) {
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void k1h_slow_kernel(const K1fBatch batch)
 	if (!flagged) return;
 	const bool slow = true;
 	// what the suspect role counted goes back first: every window of a dirty-affected block is re-derived below, tie windows included
-	for (uint32_t reg = blockIdx.x; reg < item.n_waves; reg += gridDim.x) {
+	for (uint32_t reg = a.first_wg * kK1hWaves + blockIdx.x; reg < a.first_wg * kK1hWaves + item.n_waves; reg += gridDim.x) {
 		uint32_t n = a.sus_count[reg];
 		if (n == 0xffffffffu) n = 0;
 		for (uint32_t i = tid; i < n; i += 256u) {

@@ -159,8 +159,9 @@ def test_live_differential_against_reference_binary(tmp_path):
     (tmp_path / "both.txt").write_text("contigs.fa\nragged.fq.gz\n")
     cases = [(["-k", "25"], ["contigs.fa"]), (["-k", "12,33,64"], ["ragged.fq.gz"]), (["-k", "31", "-g", "5"], ["contigs.fa", "ragged.fq.gz"]),
              (["-t", "2", "-k", "32", "-c", "200"], ["@both.txt"])]
+    env = dict(os.environ, NTC_BIN_MIN="1024", NTC_CLI_BLOCK_BYTES="400000")  # length bins from 1024 reads on take the tiled kernels (the default, 32 Ki, would send this small file to K1), in several batches
     for n, (args, files) in enumerate(cases):
-        ours = subprocess.run([BIN] + args + ["-p", "gpu%d" % n] + files, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        ours = subprocess.run([BIN] + args + ["-p", "gpu%d" % n] + files, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         ref = subprocess.run([REF_NTCARD] + args + ["-p", "ref%d" % n] + files, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert ours.returncode == 0 and ref.returncode == 0, (ours.stderr, ref.stderr)
         ks = args[args.index("-k") + 1].split(",")

@@ -25,6 +25,18 @@ for ext in fa sam; do
   echo "-- MI355X, .$ext"; time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p gpu_$ext $W/s_*.$ext
   cmp ref_${ext}_k32.hist gpu_${ext}_k32.hist && echo IDENTICAL
 done
+echo "== adapter-trimmed rendering: every read cut to 100 .. 150 bases (ragged tiles, all length bins in one launch: round 5), -t 8"
+for f in $W/s_*.fq; do
+  awk 'NR%4==1{print} NR%4==2{l=100+int((NR*7919)%51); print substr($0,1,l)} NR%4==3{print} NR%4==0{print substr($0,1,l)}' $f > ${f%.fq}.trim.fastq
+done
+echo "-- reference"; time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 32 -p ref_trim $W/s_*.trim.fastq
+echo "-- MI355X"; time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p gpu_trim $W/s_*.trim.fastq
+cmp ref_trim_k32.hist gpu_trim_k32.hist && echo IDENTICAL
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/e2e_prof_trim
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof_trim -o t -- $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p $W/proft $W/s_*.trim.fastq > /tmp/e2e_prof_trim.log 2>&1
+f=$(find /tmp/e2e_prof_trim -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && head -6 "$f" | cut -c1-150
+cd $W
 echo "== kernels of one CLI run (rocprofv3 --kernel-trace --stats: which hash kernel the parsed reads reach)"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/e2e_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof -o t -- $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p $W/prof $W/s_*.fq > /tmp/e2e_prof.log 2>&1
