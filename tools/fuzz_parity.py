@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/fuzz_parity.py [n_cases] [seed] — randomised parity sweep: engine vs oracle on random shapes
-(read length / raggedness / dirt / k list / gap / sBits / rBits / submit pattern / sketch-update mode and log size).  Prints the first mismatch and exits 1."""
+(read length / raggedness / dirt / k list / gap / sBits / rBits / submit pattern / sketch-update mode and log size).  Prints the first mismatch and exits 1.
+NTC_BIN_MIN=1024 in the environment sends the length bins of the larger ragged cases through the tiled kernels (default: bins from 32 Ki reads)."""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -34,14 +35,14 @@ for case in range(n_cases):
     s_bits, r_bits = rng.choice([2, 3, 5, 7, 7, 8, 11]), rng.choice([12, 16, 18])
     mode = rng.choice(["equal", "equal", "two", "ragged", "long"])
     L = rng.choice([rng.randint(1, 300), 100, 150, 151, 250])
-    n = rng.choice([70, 500, 3000])
+    n = rng.choice([70, 500, 3000, 3000, 40000])  # (40000: with NTC_BIN_MIN=1024 in the environment the length bins of a ragged batch take the tiled kernels, several per launch)
     pn = rng.choice([0, 0, 0.001, 0.02, 0.2])
     if mode == "equal": lens = [L] * n
     elif mode == "two": lens = [L if rng.random() < 0.9 else max(1, L - rng.randint(1, 30)) for _ in range(n)]
     elif mode == "ragged": lens = [rng.randint(0, L) for _ in range(n)]
     else: lens = [rng.choice([L, 1000, 5000, 70000]) for _ in range(max(3, n // 50))]
     reads = [rseq(l, pn, 0.1) for l in lens]
-    cuts = sorted(rng.sample(range(len(reads) + 1), min(len(reads) + 1, rng.choice([0, 1, 3]))))
+    cuts = sorted(rng.sample(range(len(reads) + 1), min(len(reads) + 1, rng.choice([0, 1, 3, 6]))))
     flags, log_entries = rng.choice([(0, 0), (nt.FLAG_ALWAYS_LOG, 0), (nt.FLAG_DIRECT_ATOMICS, 0),
                                      (nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, 0),
                                      (nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, 1 << rng.choice([14, 16, 18]))])
