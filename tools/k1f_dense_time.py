@@ -26,4 +26,4 @@ for p_bad in (0.0, 0.0005, 0.002, 0.005, 0.02, 0.1):
             e.sync()
             ker, launches = e.kernel_time()
             fix = e.fixup_time()
-        print("N rate %.4f  %s: hash %.3f ms  fix-up %.3f ms per 10 M reads" % (p_bad, "K1c" if teams else "K1h + K1f", ker / 10 * 5, fix / 10 * 5), flush=True)
+        print("N rate %.4f  %s: hash %.3f ms  fix-up %.3f ms per 10 M reads" % (p_bad, "K1h + K1f", ker / 10 * 5, fix / 10 * 5), flush=True)
