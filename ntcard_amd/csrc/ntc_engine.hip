@@ -381,7 +381,8 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	ap.slice_bits = std::min<uint32_t>(15, ap.key_bits);
 	const uint32_t pb = ap.key_bits - ap.slice_bits;
 	if (pb > 16) return false;
-	ap.b1 = pb <= 8 ? pb : (pb + 1) / 2; // two passes: balanced fan-out (longer runs per digit coalesce better than 256-way + 32-way)
+	ap.b1 = pb <= 8 ? pb : (pb + 1) / 2; // two passes: balanced fan-out (longer runs per digit coalesce better than 256-way + 32-way); with the second
+	                                     // pass's uint16 runs 7 + 6 bits still beat 6 + 7 and 5 + 8 (0.101 / 0.103 / 0.131 ms per step, profiles/r05_apply_geometry_sweep.txt)
 	ap.b2 = pb - ap.b1;
 	ap.n_slices = (uint32_t)((counters + (1ull << ap.slice_bits) - 1) >> ap.slice_bits);
 	// default: four entries per counter, at most 2^30 (4 GiB at rBits = 27 and one k: the apply's sweep over the whole sketch is then
