@@ -359,6 +359,27 @@ def test_tiled_bins_in_one_launch(nt, klist, s_bits, sizes):
         assert np.array_equal(tc, oc)
 
 
+@pytest.mark.parametrize("cap", ["64", "7"])
+def test_tiled_bins_with_overflowing_suspect_lists(nt, monkeypatch, cap):
+    """several length bins in one launch, reads dense with N, suspect lists far too short (NTC_K1H_SUS_CAP): every bin's K1f finds ITS regions overflowed and
+    takes the slow path; twice per engine, with and without deferred fix-ups"""
+    monkeypatch.setenv("NTC_K1H_SUS_CAP", cap)
+    rng = np.random.default_rng(int(cap))
+    bins, allr = [], []
+    for C, n in ((10, 9000), (9, 4000), (6, 7000), (3, 3000)):
+        reads = _ragged_reads(rng, n, 16 * C - 15, 16 * C, 0.02)
+        tiles, tails, _ = nt.tile_reads_ragged(reads, C)
+        bins.append((torch.from_numpy(tiles).cuda(), n, 16 * C, torch.from_numpy(tails.reshape(-1).astype(np.int32)).cuda()))
+        allr += reads
+    oc, of1 = orc.sketch_reads(allr + allr, [25], 0, 18, 7)
+    for flags in (0, nt.FLAG_DEFER_REDO):
+        with nt.Engine([25], r_bits=18, s_bits=7, flags=flags | nt.FLAG_REQUIRE_TILED) as e:
+            for _ in range(2):
+                e.submit_tiled_bins_device([(t.data_ptr(), n, L, d.data_ptr()) for t, n, L, d in bins])
+            tc, ph, f1 = e.finish(counters=True)
+        assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+
+
 def test_host_batches_of_mixed_lengths_one_after_the_other(nt):
     """several ntc_submit calls on one engine, each a multi-bin launch of a different size and bin composition: a bin's suspect list is indexed by the wave's
     number in the launch, so regions that THIS launch's waves of the bin did not write still hold the counts of an earlier launch — K1f must visit only
