@@ -254,7 +254,8 @@ def main():
     if args.layout == "auto":
         kl = klist_of(args)
         k1h_gap = len(kl) == 1 and (kl[0], args.gap) in ((12, 2), (32, 8))  # K1h's spaced-seed variants (config 5 in both forms of SURVEY 8(d))
-        args.layout = "tiled" if (all(12 <= k <= 32 for k in kl) and (args.gap == 0 or k1h_gap) and args.s_bits >= 7 and not args.lane_kernel) else "rows"
+        # (a list of which only a part is K1h's — config 4: 32,64,96,128 — is tiled too: K1h + K1f take their k from the tiles, K1 stages the same tiles for the rest)
+        args.layout = "tiled" if (any(12 <= k <= 32 for k in kl) and (args.gap == 0 or k1h_gap) and args.s_bits >= 7 and not args.lane_kernel) else "rows"
     import torch
     import torch.distributed as dist
     import ntcard_amd as nt

@@ -289,7 +289,9 @@ struct ntc_engine {
 	uint64_t run_submits = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: deferred K1f launches (outside the hash kernels' events)
 	double k1f_ms = 0.0;
-	bool ts_ok = false;             // the tiled kernel pair K1h + K1f is built for every k of this configuration
+	bool ts_ok = false;             // the tiled kernel pair K1h + K1f is built for SOME k of this configuration (k_tiled says which) ...
+	bool ts_all = false;            // ... for every k (then nothing of a tiled batch is left to K1)
+	std::vector<uint8_t> k_tiled;   // per k of the list: K1h + K1f take it from tiled batches (the others are K1's, which stages the same tiles: round 5)
 	bool ts_required = false;       // NTC_FLAG_REQUIRE_TILED
 	bool defer_redo = false;        // NTC_FLAG_DEFER_REDO
 	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1h is not built for
@@ -547,8 +549,11 @@ int apply_log(ntc_engine* e)
 }
 
 // launch the hash->sample->count kernel for every k of the list over one device-resident batch
+int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_meta, uint64_t n_slots, uint32_t read_len, uint32_t stride, bool tiled = false,
+              const std::vector<uint8_t>* skip = nullptr);
+// tiled: d_slots is a TILED batch (stride = 16 x its chunks: K1 stages the tiles itself); skip: the k of the list that are NOT this call's (K1h has taken them)
 int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_meta, uint64_t n_slots,
-              uint32_t read_len, uint32_t stride)
+              uint32_t read_len, uint32_t stride, bool tiled, const std::vector<uint8_t>* skip)
 {
 	if (n_slots == 0) return 0;
 	if (int rc = close_run(e)) return rc;
@@ -588,9 +593,10 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 	}
 	if (kind == KIND_HF) {
 		// upper estimate of the sampled k-mers per slot (both samples ~2^-sBits of the windows each, App. B of SURVEY.md)
+		auto mine = [&](size_t ki) { return !(skip && (*skip)[ki]); };
 		double per_slot = 0.0;
-		for (uint32_t k : e->klist)
-			per_slot += (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+		for (size_t ki = 0; ki < e->klist.size(); ++ki)
+			if (mine(ki)) per_slot += (double)std::max<int64_t>(0, (int64_t)(d_meta ? stride : read_len) - (int64_t)e->klist[ki] + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
 		// The first sizeable equal-length batch after a reset is cut in two: a small head goes first, the probe samples what
 		// it logged and decides log vs direct atomics on the device, and the bulk of the batch already runs in that mode.
 		// The head is sized to log the ~2^20 entries the probe wants (0.6 M slots at sBits = 7, k = 32); a batch that is
@@ -599,8 +605,9 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 		if (e->d_log && e->adaptive && !e->probed && d_meta == nullptr && per_slot > 0.0) {
 			const uint64_t head = (((uint64_t)(kProbeEntries / per_slot) + 2047) / 2048) * 2048;
 			if (e->log_est < (double)(1u << 20) && n_slots >= 4 * head) {
-				if (int rc = run_batch(e, d_slots, nullptr, head, read_len, stride)) return rc;
-				return run_batch(e, d_slots + head * stride, nullptr, n_slots - head, read_len, stride);
+				// (head is a multiple of 2048 reads: in a tiled batch, whose tiles hold 2048 x stride bytes each, the rest starts at the same offset)
+				if (int rc = run_batch(e, d_slots, nullptr, head, read_len, stride, tiled, skip)) return rc;
+				return run_batch(e, d_slots + head * stride, nullptr, n_slots - head, read_len, stride, tiled, skip);
 			}
 		}
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -644,6 +651,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			a.n_slots = ns;
 			a.stride = stride;
 			a.read_len = read_len;
+			a.tiled = tiled ? 1u : 0u;
 			a.r_bits = e->r_bits;
 			a.s_bits = e->s_bits;
 			a.n_k = (uint32_t)n;
@@ -664,9 +672,17 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
 			return 0;
 		};
-		for (size_t b = 0; b < e->klist.size(); b += ntc::kMaxFusedK)
-			if (int rc = launch_group(b, std::min<size_t>(ntc::kMaxFusedK, e->klist.size() - b), d_slots, n_slots))
-				return rc;
+		for (size_t b = 0; b < e->klist.size();) { // runs of this call's k, up to kMaxFusedK per launch
+			if (!mine(b)) {
+				++b;
+				continue;
+			}
+			size_t n = 1;
+			while (n < ntc::kMaxFusedK && b + n < e->klist.size() && mine(b + n))
+				++n;
+			if (int rc = launch_group(b, n, d_slots, n_slots)) return rc;
+			b += n;
+		}
 		if (e->profiling) {
 			HIP_TRY(hipEventRecord(ev1, e->stream));
 			e->pending.emplace_back(ev0, ev1);
@@ -756,8 +772,8 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 	bool any_tails = false;
 	for (const auto& sg : segs)
 		any_tails |= sg.d_tails != nullptr;
-	if (!e->ts_ok && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
-	if (!e->ts_ok && any_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for this configuration");
+	if (!e->ts_all && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
+	if (!e->ts_all && any_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for every k of this configuration");
 	if (!e->ts_ok) { // this configuration is K1's
 		for (const auto& sg : segs)
 			if (int rc = run_tiled_as_rows(e, sg.d_tiles, sg.n_reads, sg.read_len)) return rc;
@@ -789,13 +805,33 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			return 0;
 		}
 	}
+	if (!e->ts_all && e->d_log && e->adaptive && !e->probed && segs.size() == 1 && e->log_est < (double)(1u << 20)) {
+		// A list of which a part is K1's: K1 appends to the hit log or increments with device atomics, whichever the probe of the FIRST sizeable batch finds
+		// cheaper for this data (run_batch).  The probe needs a log whose sampled entries come from few reads — the head of the batch, hashed by both kernels
+		// before the rest: cut the batch as run_batch cuts a row-slot batch (at a tile boundary: any prefix of a tiled buffer is a batch).
+		const TiledSeg& sg = segs[0];
+		double per_read = 0.0;
+		for (uint32_t k : e->klist)
+			per_read += (double)std::max<int64_t>(0, (int64_t)sg.read_len - (int64_t)k + 1) * std::ldexp(1.15, 1 - (int)e->s_bits);
+		if (per_read > 0.0) {
+			const uint64_t head = (((uint64_t)(1.25 * (1 << 20) / per_read) + 2047) / 2048) * 2048;
+			if (sg.n_reads >= 4 * head) {
+				const TiledSeg first{sg.d_tiles, head, sg.read_len, nullptr};
+				const TiledSeg rest{sg.d_tiles + ntc_tiled_bytes(head, sg.read_len), sg.n_reads - head, sg.read_len, nullptr};
+				if (int rc = run_tiled_segs(e, &first, 1)) return rc;
+				return run_tiled_segs(e, &rest, 1);
+			}
+		}
+	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
 	if (e->d_log) {
 		// candidates of these batches (both samples ~2^-sBits of the windows each, every k) + what every logging wave may leave unused at the
 		// end of a region; a log that could overflow is applied first (outside the hash kernels' timing events)
 		double est = 0;
-		for (uint32_t k : e->klist) {
+		for (size_t kj = 0; kj < e->klist.size(); ++kj) {
+			const uint32_t k = e->klist[kj];
+			if (!e->k_tiled[kj]) continue; // (run_batch books K1's share)
 			bool any = false;
 			for (const auto& sg : segs)
 				if (sg.read_len >= k) {
@@ -818,10 +854,12 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 		return 0;
 	};
 	bool counted = false; // this submit counts as one launch of ntc_kernel_time once its first kernel is queued (not at all when read_len < every k)
+	bool launched_any = false;
 	const uint32_t wpg = ntc::sketch_k1h_waves();                                              // waves per workgroup (one workgroup per CU)
 	const uint32_t max_waves = (uint32_t)di.cus * wpg;
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
+		if (!e->k_tiled[ki]) continue; // K1's (below)
 		std::vector<const TiledSeg*> act; // no window of this k in a shorter read (ntHashIterator.hpp:61-64)
 		for (const auto& sg : segs)
 			if (sg.read_len >= k) act.push_back(&sg);
@@ -905,7 +943,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 				if (int rc = ensure_set(e->k1h_set[si])) {
 					// no memory for K1h's hand-over arrays (8 sets with NTC_FLAG_DEFER_REDO: up to ~0.5 GB each per 10 M reads): the
 					// batches are K1's, unless the caller insists on the tiled kernels or part of the k list has been launched already
-					if (e->ts_required || ki != 0 || any_tails) return rc;
+					if (e->ts_required || launched_any || any_tails) return rc;
 					if (int rc2 = close_run(e)) return rc2;
 					for (const auto& sg : segs)
 						if (int rc3 = run_tiled_as_rows(e, sg.d_tiles, sg.n_reads, sg.read_len)) return rc3;
@@ -943,6 +981,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 		uint32_t n_waves = 0;
 		if (int rc = open_run()) return rc; // (a K1f above may have closed the bracket)
 		HIP_TRY(ntc::launch_sketch_k1h_multi(hs, na, k, e->gap, (unsigned)di.cus, e->stream, launched, &n_waves));
+		launched_any = true;
 		for (uint32_t i = 0; i < na; ++i) {
 			auto& it = e->k1f_batch.item[e->k1f_n++];
 			it.a = launched[i];
@@ -955,6 +994,9 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 	}
 	if (!e->profiling)
 		if (int rc = close_run(e)) return rc; // (profiling was switched off inside a run)
+	if (!e->ts_all) // the k of the list K1h is not built for: K1 over the same tiles (staged straight from the tiled layout)
+		for (const auto& sg : segs)
+			if (int rc = run_batch(e, sg.d_tiles, nullptr, sg.n_reads, sg.read_len, 16u * ((sg.read_len + 15u) / 16u), true, &e->k_tiled)) return rc;
 	return 0;
 }
 
@@ -1084,29 +1126,36 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 	// The tiled kernel pair K1h + K1f: every k of the list must be one K1h is generated for (k = 12 .. 32; ntcard's -g seed at k = 12 / gap 2 and k = 32 / gap 8); a list is
 	// served by one launch per k over the same resident tiles.  Its hit-log keys and K1f's atomics are 32-bit counter indices.  Everything else —
 	// row slots, other k, other seeds, nthll — is K1's (NTC_FLAG_LANE_KERNEL: tiled batches too, re-laid out as row slots).
-	e->ts_ok = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->hll_bits == 0 && e->klist.size() * e->plane_elems() <= (1ull << 32);
-	for (uint32_t k : e->klist)
-		e->ts_ok = e->ts_ok && ntc::sketch_k1h_supports(k, e->gap, e->s_bits, e->r_bits);
+	// A list may mix both kinds (round 5: `-k 16,24,32,48`, BASELINE config 4's `32,64,96,128`): K1h takes its k from the tiles, K1 stages the same tiles for the rest.
+	const bool ts_pre = e->kernel_kind == KIND_HF && !(cfg->flags & NTC_FLAG_LANE_KERNEL) && e->hll_bits == 0 && e->klist.size() * e->plane_elems() <= (1ull << 32);
+	e->k_tiled.assign(e->klist.size(), 0);
+	e->ts_ok = false;
+	e->ts_all = ts_pre;
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		e->k_tiled[ki] = ts_pre && ntc::sketch_k1h_supports(e->klist[ki], e->gap, e->s_bits, e->r_bits) ? 1 : 0;
+		e->ts_ok = e->ts_ok || e->k_tiled[ki];
+		e->ts_all = e->ts_all && e->k_tiled[ki];
+	}
 	e->d_k1h_tabs.assign(e->klist.size(), nullptr);
-	if (e->ts_ok) {
-		for (size_t ki = 0; ki < e->klist.size(); ++ki) {
-			const uint32_t k = e->klist[ki];
-			std::vector<uint32_t> t4((size_t)ntc::t4_groups(k) * 256 * 4); // K1f: both strands' 64-bit terms, 4 bases per entry
-			ntc::build_t4(k, t4.data(), (k - e->gap) / 2, e->gap);
-			std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);     // K1h's resolve pass: the low r_bits + sample bits, 3 bases per entry
-			ntc::build_k1h_table(k, e->gap, e->r_bits, e->s_bits, tab.data());
-			void* d4 = nullptr;
-			uint32_t* d3 = nullptr;
-			if (hipMalloc(&d4, t4.size() * 4) != hipSuccess || hipMemcpy(d4, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-			    hipMalloc((void**)&d3, tab.size() * 4) != hipSuccess || hipMemcpy(d3, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-				if (d4) (void)hipFree(d4);
-				if (d3) (void)hipFree(d3);
-				ntc_destroy(e);
-				return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form tables of the tiled kernels on device");
-			}
-			e->d_t4s.push_back(d4);
-			e->d_k1h_tabs[ki] = d3;
+	e->d_t4s.assign(e->klist.size(), nullptr);
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		if (!e->k_tiled[ki]) continue;
+		const uint32_t k = e->klist[ki];
+		std::vector<uint32_t> t4((size_t)ntc::t4_groups(k) * 256 * 4); // K1f: both strands' 64-bit terms, 4 bases per entry
+		ntc::build_t4(k, t4.data(), (k - e->gap) / 2, e->gap);
+		std::vector<uint32_t> tab((size_t)2 * ((k + 2) / 3) * 64);     // K1h's resolve pass: the low r_bits + sample bits, 3 bases per entry
+		ntc::build_k1h_table(k, e->gap, e->r_bits, e->s_bits, tab.data());
+		void* d4 = nullptr;
+		uint32_t* d3 = nullptr;
+		if (hipMalloc(&d4, t4.size() * 4) != hipSuccess || hipMemcpy(d4, t4.data(), t4.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMalloc((void**)&d3, tab.size() * 4) != hipSuccess || hipMemcpy(d3, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+			if (d4) (void)hipFree(d4);
+			if (d3) (void)hipFree(d3);
+			ntc_destroy(e);
+			return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the closed-form tables of the tiled kernels on device");
 		}
+		e->d_t4s[ki] = d4;
+		e->d_k1h_tabs[ki] = d3;
 	}
 	e->ts_required = (cfg->flags & NTC_FLAG_REQUIRE_TILED) != 0;
 	e->defer_redo = (cfg->flags & NTC_FLAG_DEFER_REDO) != 0;
@@ -1583,7 +1632,7 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 				const HostBin one{nullptr, n_reads, (uint32_t)len0, false};
 				return submit_tiled_host(e, &one, 1, len_of, ptr_of);
 			}
-		} else {
+		} else if (e->ts_all) { // (a list with a k that is K1's keeps ragged batches in row slots: K1 takes per-read lengths from the slot table, not from tails)
 			constexpr uint32_t kMaxC = 0x10000u / 16u;
 			std::vector<uint32_t> per_c(kMaxC + 1, 0u);
 			for (uint64_t i = 0; i < n_reads; ++i) {

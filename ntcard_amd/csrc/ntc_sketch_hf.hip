@@ -112,7 +112,7 @@ __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_bal
 // kDump: validation build (ntc_hash_dump_k1_device): the filter lets EVERY window through, so the resolve stage
 // re-derives the full canonical hash of every window with the production code path, and writes it out instead of
 // sampling it (what ntHashIterator / stHashIterator enumerate, ntHashIterator.hpp:59-86, stHashIterator.hpp:60-87)
-template <bool kMulti, int kMode, int kPref, bool kDump = false>
+template <bool kMulti, int kMode, int kPref, bool kDump = false, bool kTiled = false>
 __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(const HfArgs a)
 {
 	const uint32_t n_k = kMulti ? a.n_k : 1u;
@@ -223,7 +223,21 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	const bool can_prefetch = nchunk <= (uint32_t)kPref;
 	const uint64_t wb_step = (uint64_t)gridDim.x * wpb;
 	uint4 pref[kPref];
+	// A TILED batch (a.tiled, round 5: the k of a list that K1h is not built for are hashed here from the same tiles, without a re-layout pass): the wave's
+	// 64 reads are 64 consecutive 16-byte pieces of every chunk row of their tile, so round c of the staging is ONE coalesced 1 KiB load — piece c of read
+	// `lane` — parked at lane * stride + 16 c: the same LDS picture as a row-slot batch of stride 16 n_chunks.  The slots behind a batch's last read exist
+	// (a tile buffer always holds whole tiles), so a partial last wave loads like a full one and masks its lanes afterwards.
+	constexpr bool tiled = kTiled; // (an instantiation of its own: as a run-time flag the two addressing forms cost every variant 150 - 330 B of scratch per lane)
+	const uint32_t n_pieces = stride >> 4; // (tiled: chunks per read)
 	auto load_round = [&](uint64_t wb_, uint32_t c0) {
+		if (tiled) {
+			const uint64_t r0 = wb_ * 64u;
+			const unsigned char* src = a.slots + ((r0 / kTileReads) * n_pieces * kTileReads + (r0 % kTileReads) + (uint32_t)lane) * 16u;
+#pragma unroll
+			for (int c = 0; c < kPref; ++c)
+				if (c0 + c < n_pieces) pref[c] = *reinterpret_cast<const uint4*>(src + (size_t)(c0 + c) * kTileReads * 16u);
+			return;
+		}
 		const unsigned char* src = a.slots + wb_ * full_bytes;
 #pragma unroll
 		for (int c = 0; c < kPref; ++c) {
@@ -234,8 +248,8 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	auto store_round = [&](uint32_t c0, uint32_t& badacc) {
 #pragma unroll
 		for (int c = 0; c < kPref; ++c) {
-			const uint32_t off = lane * 16u + (c0 + c) * 1024u;
-			if (off + 16u <= full_bytes) {
+			const uint32_t off = tiled ? (uint32_t)lane * stride + (c0 + c) * 16u : lane * 16u + (c0 + c) * 1024u;
+			if (tiled ? c0 + c < n_pieces : off + 16u <= full_bytes) {
 				uint4 v = pref[c];
 				v.x = decode4(v.x, badacc);
 				v.y = decode4(v.y, badacc);
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			}
 		}
 	};
-	auto is_full = [&](uint64_t wb_) { return wb_ * 64 + 64 <= n_slots; };
+	auto is_full = [&](uint64_t wb_) { return tiled || wb_ * 64 + 64 <= n_slots; };
 	if (can_prefetch && gwave < n_wb && is_full(gwave)) load_round(gwave, 0);
 
 	for (uint64_t wb = gwave; wb < n_wb; wb += wb_step) {
@@ -259,10 +273,10 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		// Slots too long for the register prefetch keep the staging at the walk's level (it would starve otherwise).
 		if (can_prefetch) __builtin_amdgcn_s_setprio(0); // without the register prefetch the staging waits for its own loads: keep its rank
 		__builtin_amdgcn_wave_barrier();
-		if (nvalid == 64 && can_prefetch) {
+		if ((nvalid == 64 || tiled) && can_prefetch) {
 			store_round(0, badacc);
 			if (wb + wb_step < n_wb && is_full(wb + wb_step)) load_round(wb + wb_step, 0);
-		} else if (nvalid == 64) {
+		} else if (nvalid == 64 || tiled) {
 			for (uint32_t c0 = 0; c0 < nchunk; c0 += kPref) {
 				load_round(wb, c0);
 				store_round(c0, badacc);
@@ -275,6 +289,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 					*reinterpret_cast<uint32_t*>(wdata + o) = decode4(*reinterpret_cast<const uint32_t*>(src + o), badacc);
 		}
 		__builtin_amdgcn_wave_barrier();
+		if (tiled && (uint32_t)lane >= nvalid) badacc = 0; // (a lane stages its own read there: what lies behind the batch's last read is nobody's)
 		const bool wave_dirty = __builtin_amdgcn_readfirstlane(ballot(badacc != 0u) != 0 ? 1 : 0) != 0;
 		if (can_prefetch) __builtin_amdgcn_s_setprio(1);
 
@@ -748,6 +763,7 @@ hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_b
 {
 	const dim3 g(grid), b(64u * waves_per_block);
 	const bool deep = sketch_hf_deep_prefetch(a.stride) && waves_per_block <= 12; // plain k-mer mode only
+	if (a.tiled != 0u && (a.dump != nullptr || a.gap != 0 || a.hll_bits != 0)) return hipErrorInvalidValue; // (tiled staging: plain k-mer mode only)
 	if (a.dump != nullptr && a.gap != 0)
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 1, 10, true>), g, b, smem, st, a);
 	else if (a.dump != nullptr)
@@ -756,6 +772,14 @@ hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_b
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 2, 10>), g, b, smem, st, a);
 	else if (a.gap != 0)
 		hipLaunchKernelGGL((sketch_hf_kernel<false, 1, 10>), g, b, smem, st, a);
+	else if (a.tiled != 0u && a.n_k > 1 && deep)
+		hipLaunchKernelGGL((sketch_hf_kernel<true, 0, 16, false, true>), g, b, smem, st, a);
+	else if (a.tiled != 0u && a.n_k > 1)
+		hipLaunchKernelGGL((sketch_hf_kernel<true, 0, 10, false, true>), g, b, smem, st, a);
+	else if (a.tiled != 0u && deep)
+		hipLaunchKernelGGL((sketch_hf_kernel<false, 0, 16, false, true>), g, b, smem, st, a);
+	else if (a.tiled != 0u)
+		hipLaunchKernelGGL((sketch_hf_kernel<false, 0, 10, false, true>), g, b, smem, st, a);
 	else if (a.n_k > 1 && deep)
 		hipLaunchKernelGGL((sketch_hf_kernel<true, 0, 16>), g, b, smem, st, a);
 	else if (a.n_k > 1)
@@ -797,7 +821,9 @@ hipError_t set_sketch_hf_smem_limit(size_t smem)
 	const void* fns[] = { reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 10>),
 		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 16>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 16>),
 		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 2, 10>),
-		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10, true>) };
+		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<false, 1, 10, true>),
+		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 10, false, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 10, false, true>),
+		              reinterpret_cast<const void*>(&sketch_hf_kernel<false, 0, 16, false, true>), reinterpret_cast<const void*>(&sketch_hf_kernel<true, 0, 16, false, true>) };
 	for (const void* f : fns) {
 		const hipError_t rc = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 		if (rc != hipSuccess) return rc;

@@ -223,6 +223,58 @@ def test_tiled_fullsize_matches_reference_goldens(nt, name, R, tmp_path):
     assert out.read_bytes() == open(os.path.join(GOLD, pl["hist_file"]), "rb").read()
 
 
+@pytest.mark.parametrize("klist,s_bits,L,sizes", [([16, 24, 32, 48], 7, 150, [5000, 70, 2049]), ([32, 64, 96, 128], 7, 150, [9000, 4100]), ([12, 40], 11, 61, [3000, 1]),
+                                                 ([33, 20, 100], 8, 250, [2500]), ([31, 32, 33, 34, 35, 36], 7, 100, [4096, 100])])
+def test_tiled_batches_with_a_mixed_k_list(nt, klist, s_bits, L, sizes):
+    """a k list of which only a part is K1h's (12 .. 32): K1h + K1f take their k from the tiles, K1 stages the SAME tiles for the others (a.tiled: no
+    re-layout pass) — device batches of several sizes (partial last waves, one read), reads with N, and the same reads through ntc_submit; multi-k
+    through ntRead's loop over kList (ntcard.cpp:147-158)"""
+    rng = np.random.default_rng(sum(klist) + L)
+    parts = [_ragged_reads(rng, n, L, L, 0.003) for n in sizes]
+    allr = sum(parts, [])
+    oc, of1 = orc.sketch_reads(allr, klist, 0, 18, s_bits)
+    keep = [torch.from_numpy(nt.tile_reads(p, L)).cuda() for p in parts]
+    for flags in (0, nt.FLAG_DEFER_REDO, nt.FLAG_ALWAYS_LOG):
+        with nt.Engine(klist, r_bits=18, s_bits=s_bits, flags=flags) as e:
+            for p, t in zip(parts, keep):
+                e.submit_tiled_device(t.data_ptr(), len(p), L)
+            tc, ph, f1 = e.finish(counters=True)
+        assert np.array_equal(f1, of1), (flags, f1, of1)
+        assert np.array_equal(tc, oc), flags
+    with nt.Engine(klist, r_bits=18, s_bits=s_bits) as e:  # host reads: packed into tiles (equal length), both kernels from there
+        for p in parts:
+            e.submit_reads(p)
+        tc, ph, f1 = e.finish(counters=True)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+    with pytest.raises(nt.NtcError):  # the validation flag asks for K1h on EVERY k
+        with nt.Engine(klist, r_bits=18, s_bits=s_bits, flags=nt.FLAG_REQUIRE_TILED) as e:
+            e.submit_tiled_device(keep[0].data_ptr(), len(parts[0]), L)
+
+
+def test_tiled_fullsize_config4_mixed_list(nt, tmp_path):
+    """BASELINE config 4 (k = 32, 64, 96, 128 on 100 M reads) from TILED batches: k = 32 through K1h + K1f, the other three through K1 staging the tiles —
+    F1, the sha1 of every raw t_Counter plane and the .hist bytes of the REAL reference for all four k"""
+    with open(os.path.join(GOLD, "digests.json")) as f:
+        meta = json.load(f)
+    cfg = meta["configs"]["cfg4"]
+    n, L, rb, sb, cov = meta["n_reads"], meta["read_len"], meta["r_bits"], meta["s_bits"], meta["cov_max"]
+    R = 10_000_000
+    buf = torch.empty(nt.tiled_bytes(R, L), dtype=torch.uint8, device="cuda")
+    with nt.Engine(cfg["klist"], gap=cfg["gap"], r_bits=rb, s_bits=sb) as e:
+        for first in range(0, n, R):
+            m = min(R, n - first)
+            nt.gen_reads_tiled_device(buf.data_ptr(), meta["seed"], first, m, L, cfg["dist"], genome_len=100_000_000)
+            e.submit_tiled_device(buf.data_ptr(), m, L)
+        tc, ph, f1 = e.finish(counters=True)
+    for ki, pl in enumerate(cfg["planes"]):
+        assert int(f1[ki]) == pl["f1"]
+        assert hashlib.sha1(np.ascontiguousarray(tc[ki]).data).hexdigest() == pl["t_counter_sha1"]
+        F0, f = nt.estimate(ph[ki], rb, sb, cov)
+        out = tmp_path / f"cfg4_{ki}.hist"
+        nt.write_hist(out, f1[ki], F0, f, cov)
+        assert out.read_bytes() == open(os.path.join(GOLD, pl["hist_file"]), "rb").read()
+
+
 def test_tiled_deferred_fixups(nt):
     """NTC_FLAG_DEFER_REDO: the caller leaves its batches alone until sync, so the engine collects up to eight K1h launches and sends ONE K1f over
     all of them (blockIdx.y = the launch).  Eleven batches of different sizes and read lengths with non-ACGTU bytes: the ninth forces a K1f in
