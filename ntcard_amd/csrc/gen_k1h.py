@@ -42,9 +42,12 @@ WAVES = 8                    # waves per workgroup = tiles in flight per CU: two
 QSLOT = 2048                 # one QUARTER of a packed chunk: 4 bases x 2048 reads = [8 rows][64 lanes] dwords, byte t of row i = the read 64 (i + 8 t) + lane
 RQ_MAX = 9                   # quarter-slots of the ring: 4 j + 5 are in use, j = (k - 1) div 16 (what 4 windows span, see quarter_enter)
 RING_BYTES = RQ_MAX * QSLOT  # 18 KiB (round 4: three packed chunks, 24 KiB)
-QCAP = 64                    # queue items: three dwords each, kept as three arrays (hit word, meta, reverse-strand mask) of QCAP dwords + one
-QSTRIDE = QCAP + 1           # dummy slot: a lane with nothing to queue writes there, so the writes need no exec mask (an exec write costs ~2 issue slots)
-WAREA = (RING_BYTES + QSTRIDE * 12 + 15) // 16 * 16  # 19216 bytes per wave
+QCAP = 128                   # queue items, kept as three arrays — hit word, reverse-strand mask (dwords), meta (16 bits: that is what lets 128 items fit) — of QCAP + one
+QSTRIDE = QCAP + 1           # dummy slot: a lane with nothing to queue writes there, so the writes need no exec mask (an exec write costs ~2 issue slots).
+                             # 128 items, not 64 (round 5): a pass for want of room then always finds 64 items (it ran with 49 on average, the queue could never hold a full
+                             # pass AND a step), 154 passes per two tiles instead of 175 (tools: the queue simulation behind DESIGN 5)
+Q_META_OFF = QSTRIDE * 8     # byte offset of the meta array behind the two dword arrays
+WAREA = (RING_BYTES + QSTRIDE * 10 + 15) // 16 * 16  # 19728 bytes per wave
 TABLE_OFF = WAVES * WAREA    # 153728: [2 strands][NG][64] dwords
 LDS_BYTES = 160 * 1024
 
@@ -462,9 +465,11 @@ class Gen:
         p.i("v_and_b32", v(T + 1), v(V_CQMASK4), v(T + 1))
         p.i("v_or_b32", v(T + 3), hex(meta), v(V_LANE4))
         p.i("v_cndmask_b32_e64", v(T + 1), v(V_QDUMMY), v(T + 1), "vcc")   # V_QDUMMY = 4 QCAP: the dummy slot
+        p.i("v_lshrrev_b32", v(T + 4), 1, v(T + 1))                         # (the meta array is 16 bits wide)
+        p.i("v_add_u32", v(T + 4), v(V_QBASE), v(T + 4))
         p.i("v_add_u32", v(T + 1), v(V_QBASE), v(T + 1))
-        p.i("ds_write2_b32", v(T + 1), v(T + 2), v(T + 3), mods=f"offset0:0 offset1:{QSTRIDE}")
-        p.i("ds_write_b32", v(T + 1), v(xr), mods=f"offset:{QSTRIDE * 8}")
+        p.i("ds_write2_b32", v(T + 1), v(T + 2), v(xr), mods=f"offset0:0 offset1:{QSTRIDE}")
+        p.i("ds_write_b16", v(T + 4), v(T + 3), mods=f"offset:{Q_META_OFF}")
         p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
 
     # ---- pack one group of 64 pieces: RAW slot i -> packed word in register dst; then reload the slot ----
@@ -648,8 +653,8 @@ class Gen:
         # are still idle take them in the next round (and so on for third candidates).  Without this a queue that has to be EMPTIED — before every
         # quarter of a block, quarter_enter — would end in passes of a handful of second and third candidates: 13.9 passes per block measured
         # against 8.6 with whole-chunk ring slots; with it a quarter's ~110 items are two passes.
-        zr = mid                                              # the item's reverse-strand mask (until the requeue below)
-        x, y = item, item + 1
+        x, zr = lo, hi                                        # the item's hit word and reverse-strand mask (until the requeue below: lo / hi are free until the window's bytes are in)
+        y = item + 1                                          # its meta (16 bits)
         p.i("s_mov_b32", s(S_CC), 0)                          # lanes filled so far
         p.label("passload")
         p.i("s_sub_u32", s(S_N), s(S_QTAIL4), s(S_QHEAD4))
@@ -663,9 +668,11 @@ class Gen:
         p.i("s_sub_u32", s(S_B), s(S_QHEAD4), s(S_B))        # lane l takes item l - filled
         p.i("v_add_u32", v(t1), s(S_B), v(V_LANE4))
         p.i("v_and_b32", v(t1), v(V_CQMASK4), v(t1))
+        p.i("v_lshrrev_b32", v(m), 1, v(t1))
+        p.i("v_add_u32", v(m), v(V_QBASE), v(m))
         p.i("v_add_u32", v(t1), v(V_QBASE), v(t1))
-        p.i("ds_read2_b32", vr(item, 2), v(t1), mods=f"offset0:0 offset1:{QSTRIDE}")
-        p.i("ds_read_b32", v(zr), v(t1), mods=f"offset:{QSTRIDE * 8}")
+        p.i("ds_read2_b32", vr(x, 2), v(t1), mods=f"offset0:0 offset1:{QSTRIDE}")
+        p.i("ds_read_u16", v(y), v(m), mods=f"offset:{Q_META_OFF}")
         p.i("s_lshl2_add_u32", s(S_QHEAD4), s(S_N), s(S_QHEAD4))
         p.i("s_add_u32", s(S_CC), s(S_CC), s(S_N))
         p.i("s_waitcnt", "lgkmcnt(0)")
@@ -682,9 +689,11 @@ class Gen:
         p.i("v_lshl_add_u32", v(t1), v(t1), 2, s(S_QTAIL4))
         p.i("v_and_b32", v(t1), v(V_CQMASK4), v(t1))
         p.i("v_cndmask_b32_e64", v(t1), v(V_QDUMMY), v(t1), "vcc")   # (a spent word goes to the dummy slot)
+        p.i("v_lshrrev_b32", v(col), 1, v(t1))
+        p.i("v_add_u32", v(col), v(V_QBASE), v(col))
         p.i("v_add_u32", v(t1), v(V_QBASE), v(t1))
-        p.i("ds_write2_b32", v(t1), v(rest), v(y), mods=f"offset0:0 offset1:{QSTRIDE}")
-        p.i("ds_write_b32", v(t1), v(zr), mods=f"offset:{QSTRIDE * 8}")
+        p.i("ds_write2_b32", v(t1), v(rest), v(zr), mods=f"offset0:0 offset1:{QSTRIDE}")
+        p.i("ds_write_b16", v(col), v(y), mods=f"offset:{Q_META_OFF}")
         p.i("s_lshl2_add_u32", s(S_QTAIL4), s(S_A), s(S_QTAIL4))
         p.i("s_bitcmp1_b32", s(S_USELOG), F_DRAIN)            # another round?  only when the queue is being emptied (drain: a pass run for want of room
         p.i("s_cbranch_scc0", "@passloaded")                  # leaves the words it puts back to the next one, which costs nothing) ...

@@ -714,6 +714,20 @@ class Emu:
         val[em] = self.lds[addr[em]]
         self.wr_v(o[0], val)
 
+    def op_ds_read_u16(self, pc, o, m):
+        em = self.mask_arr()
+        addr = self._lds_addr(o[1], m)
+        assert np.all(addr[em] % 2 == 0) and np.all(addr[em] + 2 <= self.lds.size), "ds_read_u16: bad address"
+        val = np.zeros(64, dtype=np.uint32)
+        val[em] = self.lds.view(np.uint16)[addr[em] // 2]
+        self.wr_v(o[0], val)
+
+    def op_ds_write_b16(self, pc, o, m):
+        em = self.mask_arr()
+        addr = self._lds_addr(o[0], m)
+        assert np.all(addr[em] % 2 == 0) and np.all(addr[em] + 2 <= self.lds.size), "ds_write_b16: bad address"
+        self.lds.view(np.uint16)[addr[em] // 2] = (self.rd_v(o[1])[em] & np.uint32(0xFFFF)).astype(np.uint16)
+
     def op_ds_read_b64(self, pc, o, m):
         em = self.mask_arr()
         addr = self._lds_addr(o[1], m)

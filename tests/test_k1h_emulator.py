@@ -128,4 +128,4 @@ def test_k1h_generator_budgets():
         assert gen_k1h.TABLE_OFF + gen_k1h.table_bytes(k) <= gen_k1h.LDS_BYTES
         for sb in (7, 8):
             prog = gen_k1h.Gen(k, sb, gap).build()
-            assert 3500 < prog.n_insts() < 6000  # (x ~8 bytes: inside the 64 KiB instruction cache two CUs share)
+            assert 3500 < prog.n_insts() < 6200  # (x ~8 bytes: inside the 64 KiB instruction cache two CUs share)
