@@ -75,7 +75,7 @@ typedef struct {
                                       reads with non-ACGTU bytes are then shared by several batches instead of run per batch: the fix-up
                                       kernels K1f behind up to 8 launches of the one-wave-per-tile kernel K1h.  Without the flag a buffer may be
                                       reused as soon as the stream has passed the submit call. */
-#define NTC_FLAG_REQUIRE_TILED 64u  /* validation: ntc_submit_tiled_device fails instead of re-laying a batch out for the general kernel */
+#define NTC_FLAG_REQUIRE_TILED 64u  /* validation: a tiled batch must be served by the tiled kernels for EVERY k of the list, else ntc_submit_tiled_device fails */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
 
@@ -124,10 +124,12 @@ int ntc_submit_device(ntc_engine *e, const void *d_slots, uint64_t n_reads, uint
  * letter ('A'); the slots behind the batch's last read (the rest of the last tile) are ignored whatever they hold, so any
  * prefix of a tiled buffer is a valid batch.  All reads of a batch have the same length.  Asynchronous on the engine's
  * stream; the buffer may be reused as soon as the stream has passed the call — unless the engine was created with
- * NTC_FLAG_DEFER_REDO, see there.  A list of k is served by one launch per k.  Configurations the tiled kernels are not
- * built for (a k outside 12 .. 32, spaced seeds other than ntcard's -g seed at k = 12 / gap 2 or k = 32 / gap 8, nthll, sBits < 7) are re-laid
- * out on the device and take the general kernel: same results, not the fast path.  Host batches of (mostly) equal-length
- * reads reach the same kernels: ntc_submit / ntc_submit_spans pack them into tiles in pinned staging.                   */
+ * NTC_FLAG_DEFER_REDO, see there.  A list of k is served by one launch per k.  The tiled kernels are built for k = 12 .. 32
+ * (spaced seeds: ntcard's -g seed at k = 12 / gap 2 and k = 32 / gap 8) and sBits >= 7; a list of which only a part lies in 12 .. 32
+ * is served by both kernels from the same tiles (the general kernel stages the tiles for its k: no re-layout); a configuration in
+ * which NO k is theirs (every k outside 12 .. 32, other spaced seeds, nthll, sBits < 7) is re-laid out on the device and takes the
+ * general kernel: same results, not the fast path.  Host batches reach the same kernels: ntc_submit / ntc_submit_spans pack them
+ * into tiles in pinned staging (reads of one length as one batch, mixed lengths as the length bins of ntc_submit_tiled_bins_device). */
 int ntc_submit_tiled_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t read_len);
 uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
 
