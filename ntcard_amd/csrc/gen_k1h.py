@@ -65,6 +65,7 @@ def table_bytes(k):
 V_LANE4, V_LANE16, V_QDUMMY, V_QBASE, V_WAVE4, V_ONE, V_EXP1, V_VMASK = range(0, 8)  # V_WAVE4: 4 x the wave's number in the launch
 V_D0, V_D1, V_D2, V_DN, V_CMASK, V_TACC, V_CARRY0, V_CARRY1, V_SPARE1 = range(8, 17)
 V_DMASK = 17       # reads of this block with a dirty piece in one of its three chunks (and valid): their candidates are SUSPECTS
+V_WRAPF, V_WRAPR = V_SPARE1, 254  # second homes of the two state bits that wrap around in a walk step (walk_step)
 V_F = 18           # F[31]   (register tuples — loads, 64-bit LDS items — must start at even registers on gfx90a+)
 V_R = 49           # R[31]
 V_H0 = 80          # chunk n-2 planes / P_next
@@ -343,21 +344,28 @@ class Gen:
                 last = not ops
                 self.emit_update(dst, cur, take[0] if take else None, take[1] if len(take) > 1 else None, inv if last else 0)
                 cur = dst
-        # forward: F'[j] = F[j-1] ^ terms, in place from the top (F[30]'s old value feeds F[0])
-        self.p.i("v_mov_b32", v(tmp), v(V_F + 30))
-        for jj in range(30, 0, -1):
+        # The rotation is in place — F'[j] = F[j-1] ^ terms from the top, R'[j] = R[j+1] ^ terms from the bottom — but for the bit that wraps around (F's bit 0 takes
+        # F's old bit 30, R's bit 30 R's old bit 0): that one alternates between its home register and a second one (V_WRAPF / V_WRAPR), written FIRST, while the
+        # old value it needs is still there: no copy (round 5; two v_mov per step before).  Even steps find the bit at home and leave it in the second register,
+        # odd steps the other way round; a block has 16 steps, so every block starts and ends at home.
+        f0_old, f0_new = (V_F + 0, V_WRAPF) if a % 2 == 0 else (V_WRAPF, V_F + 0)
+        update(f0_new, V_F + 30, *plan["F", 0])
+        for jj in range(30, 1, -1):
             update(V_F + jj, V_F + jj - 1, *plan["F", jj])
-        update(V_F + 0, tmp, *plan["F", 0])
-        # reverse: R'[j] = R[j+1] ^ terms, in place from the bottom
-        self.p.i("v_mov_b32", v(tmp), v(V_R + 0))
-        for jj in range(0, 30):
+        update(V_F + 1, f0_old, *plan["F", 1])
+        r30_old, r30_new = (V_R + 30, V_WRAPR) if a % 2 == 0 else (V_WRAPR, V_R + 30)
+        update(r30_new, V_R + 0, *plan["R", 30])
+        for jj in range(0, 29):
             update(V_R + jj, V_R + jj + 1, *plan["R", jj])
-        update(V_R + 30, tmp, *plan["R", 30])
+        update(V_R + 29, r30_old, *plan["R", 29])
 
     # ---- sample test of one strand: planes a (top bits == sample-1 pattern), g (>=), b (== sample-0 pattern), nz ----
-    def strand_flags(self, base, out):
-        """base: first register of the strand's state; out: dict of result registers a, g, b, nz; temps t1, t2"""
+    def strand_flags(self, base, out, top=None):
+        """base: first register of the strand's state (top: the register that holds its bit 30 right now, walk_step); out: dict of result registers a, g, b, nz;
+        temps t1, t2"""
         t7, b6, b5, b4, b3, b2, b1, b0 = [v(base + 30 - i) for i in range(8)]
+        if top is not None:
+            t7 = v(top)
         ra, rg, rb, rnz, t1, t2 = [v(out[x]) for x in ("a", "g", "b", "nz", "t1", "t2")]
         if self.sb == 7:
             self.bitop3(t1, b6, b5, b4, lambda x, y, z: x & y & z)
@@ -389,7 +397,7 @@ class Gen:
         fo = dict(a=T + 1, g=T + 2, b=T + 3, nz=T + 4, t1=T + 9, t2=T + 10)
         ro = dict(a=T + 5, g=T + 6, b=T + 7, nz=T + 8, t1=T + 9, t2=T + 10)
         self.strand_flags(V_F, fo)
-        self.strand_flags(V_R, ro)
+        self.strand_flags(V_R, ro, top=V_WRAPR if a % 2 == 0 else V_R + 30)  # (behind an even step R's bit 30 sits in its second register)
         cf, cr, tie = T + 11, T + 12, T + 13
         if self.sb == 7:
             p.i("v_and_b32", v(T + 9), v(fo["b"]), v(ro["nz"]))
