@@ -145,7 +145,7 @@ uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
 int ntc_submit_tiled_ragged_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t n_chunks, const uint32_t *d_tails);
 
 /* Several tiled batches of different geometry in ONE call — the length bins of a ragged read set (ABI 5).  Bin i is d_tiles[i] with n_reads[i] reads of
- * read_len[i] bases; d_tails[i] == NULL: an equal-length batch as for ntc_submit_tiled_device, otherwise a ragged one as for
+ * read_len[i] bases; d_tails[i] == NULL (or d_tails == NULL: all of them): an equal-length batch as for ntc_submit_tiled_device, otherwise a ragged one as for
  * ntc_submit_tiled_ragged_device (read_len[i] = 16 * n_chunks).  Counts exactly what n_bins separate calls count; the difference is speed: the
  * hash kernel takes up to 8 bins per launch and shares its workgroups among them in proportion to their work, where separate calls are separate,
  * small launches (four 2.5 M-read bins: 0.55 ms one by one, 0.39 ms together).  Empty bins are skipped.  NTC_ERR_ARG as for the single calls.    */

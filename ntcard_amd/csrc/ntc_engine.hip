@@ -755,6 +755,24 @@ struct TiledSeg {
 };
 int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in);
 
+// A list of which a part is K1's: K1 stages the SAME tiles, 64 slots of 16 x ceil(len / 16) bytes per wave next to its closed-form tables.  Does that fit the
+// CU's LDS for every such k on its own (run_batch splits a fused group that does not fit; a single k has to)?  Equal-length reads beyond ~2.4 kb do not:
+// host batches then take row slots, whose packer cuts long sequences into overlapping chunks, and a device-resident tiled batch is refused BEFORE
+// anything of it has been counted.
+bool k1_fits_tiles(const ntc_engine* e, uint32_t read_len)
+{
+	if (e->ts_all) return true;
+	const uint32_t stride = 16u * ((read_len + 15u) / 16u);
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		if (e->k_tiled[ki]) continue;
+		HfPlan p;
+		size_t shared = 0;
+		hf_shape(stride, &e->klist[ki], 1, e->gap, p, shared);
+		if (p.waves_per_cu == 0 || shared + p.wpb * (64u * (size_t)stride) > kMaxDynLds) return false;
+	}
+	return true;
+}
+
 int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len, const uint32_t* d_tails = nullptr)
 {
 	const TiledSeg one{d_tiles, n_reads, read_len, d_tails};
@@ -779,7 +797,14 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			if (int rc = run_tiled_as_rows(e, sg.d_tiles, sg.n_reads, sg.read_len)) return rc;
 		return 0;
 	}
-	const uint32_t max_segs = std::min<uint32_t>(ntc::kK1hSegs, ntc::kK1fBatch);
+	if (e->ts_ok && !e->ts_all)
+		for (const auto& sg : segs)
+			if (!k1_fits_tiles(e, sg.read_len))
+				return fail(NTC_ERR_ARG, "tiled batch of %u-base reads: the k of this list that the general kernel serves cannot stage such tiles in LDS (submit the reads through ntc_submit / ntc_submit_spans, which cut long sequences into chunks); nothing was counted", sg.read_len);
+	DevInfo di;
+	if (int rc = device_info(e->device, di)) return rc;
+	// (a launch gives every batch at least one workgroup, and the suspect lists are sized for cus x 8 regions: no more batches than CUs)
+	const uint32_t max_segs = std::min<uint32_t>(std::min<uint32_t>(ntc::kK1hSegs, ntc::kK1fBatch), (uint32_t)std::max(1, di.cus));
 	if (segs.size() > max_segs) { // more bins than one launch takes: groups
 		for (size_t i = 0; i < segs.size(); i += max_segs)
 			if (int rc = run_tiled_segs(e, segs.data() + i, (uint32_t)std::min<size_t>(max_segs, segs.size() - i))) return rc;
@@ -823,8 +848,6 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			}
 		}
 	}
-	DevInfo di;
-	if (int rc = device_info(e->device, di)) return rc;
 	if (e->d_log) {
 		// candidates of these batches (both samples ~2^-sBits of the windows each, every k) + what every logging wave may leave unused at the
 		// end of a region; a log that could overflow is applied first (outside the hash kernels' timing events)
@@ -1294,14 +1317,15 @@ int ntc_submit_tiled_bins_device(ntc_engine* e, uint32_t n_bins, const void* con
 {
 	if (!e) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: null engine");
 	if (n_bins == 0) return 0;
-	if (!d_tiles || !n_reads || !read_len || !d_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: null argument");
+	if (!d_tiles || !n_reads || !read_len) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: null argument"); // (d_tails == NULL: every bin is equal-length)
 	std::vector<TiledSeg> segs;
 	for (uint32_t i = 0; i < n_bins; ++i) {
 		if (n_reads[i] == 0) continue;
-		if (!d_tiles[i] || ((uintptr_t)d_tiles[i] & 15u) || ((uintptr_t)d_tails[i] & 3u)) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: bin %u: need a 16-byte aligned tile buffer", i);
-		if (read_len[i] == 0 || read_len[i] > 0xffffu || (d_tails[i] && (read_len[i] & 15u)))
+		const uint32_t* tails_i = d_tails ? d_tails[i] : nullptr;
+		if (!d_tiles[i] || ((uintptr_t)d_tiles[i] & 15u) || ((uintptr_t)tails_i & 3u)) return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: bin %u: need a 16-byte aligned tile buffer", i);
+		if (read_len[i] == 0 || read_len[i] > 0xffffu || (tails_i && (read_len[i] & 15u)))
 			return fail(NTC_ERR_ARG, "ntc_submit_tiled_bins_device: bin %u: read_len %u (a ragged bin's is 16 x its chunks, at most 65520)", i, read_len[i]);
-		segs.push_back(TiledSeg{(const unsigned char*)d_tiles[i], n_reads[i], read_len[i], d_tails[i]});
+		segs.push_back(TiledSeg{(const unsigned char*)d_tiles[i], n_reads[i], read_len[i], tails_i});
 	}
 	if (segs.empty()) return 0;
 	std::lock_guard<std::mutex> lk(e->mu);
@@ -1628,7 +1652,7 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 		for (uint64_t i = 0; i < n_reads; ++i)
 			same += len_of(i) == len0;
 		if (same == n_reads) {
-			if (len0 >= kmin && len0 <= 0xffffu) {
+			if (len0 >= kmin && len0 <= 0xffffu && k1_fits_tiles(e, (uint32_t)len0)) { // (a mixed list with reads too long for K1's tiled staging: row slots, chunked)
 				const HostBin one{nullptr, n_reads, (uint32_t)len0, false};
 				return submit_tiled_host(e, &one, 1, len_of, ptr_of);
 			}

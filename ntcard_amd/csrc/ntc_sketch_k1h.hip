@@ -622,13 +622,15 @@ hipError_t launch_k1h_fixup(const K1fBatch& b, uint32_t n_items, unsigned cus, h
 	}
 	const unsigned n_f1 = (unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8);
 	unsigned n_sus = waves;
-	if (const char* ev = std::getenv("NTC_K1F_TIME_ROLE")) { // timing experiments only (WRONG results): 1 = the F1 role alone, 2 = the suspect role alone
+#ifdef NTC_K1F_TIME_ROLE_BUILD // timing builds only (tools/k1h_variant.sh, EXTRA=-DNTC_K1F_TIME_ROLE_BUILD): never in the product library — the results are WRONG
+	if (const char* ev = std::getenv("NTC_K1F_TIME_ROLE")) { // 1 = the F1 role alone, 2 = the suspect role alone
 		if (ev[0] == '1') n_sus = 0;
 		if (ev[0] == '2') {
 			hipLaunchKernelGGL(k1h_fix_kernel, dim3(waves, n_items), dim3(256), 0, st, b, 0u);
 			return hipGetLastError();
 		}
 	}
+#endif
 	hipLaunchKernelGGL(k1h_fix_kernel, dim3(n_f1 + n_sus, n_items), dim3(256), 0, st, b, n_f1);
 	// the F1 correction of the fast path; the slow path (LDS, a CU's worth of blocks) only for a flagged launch
 	hipLaunchKernelGGL(k1h_slow_kernel, dim3(cus, n_items), dim3(256), 0, st, b);

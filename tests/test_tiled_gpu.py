@@ -251,6 +251,33 @@ def test_tiled_batches_with_a_mixed_k_list(nt, klist, s_bits, L, sizes):
             e.submit_tiled_device(keep[0].data_ptr(), len(parts[0]), L)
 
 
+def test_mixed_k_list_with_reads_too_long_for_tiled_staging(nt):
+    """`-k 32,64` on equal-length 4 kb reads.  K1 cannot stage 64 slots of 4 kb next to its tables, so the host batch must take row slots
+    (chunked) instead of tiles, and a device-resident tiled batch of such reads is refused with NOTHING counted (K1h used to count its k first)"""
+    rng = np.random.default_rng(11)
+    L, n, klist = 4096, 1500, [32, 64]
+    reads = _ragged_reads(rng, n, L, L, 0.001)
+    oc, of1 = orc.sketch_reads(reads, klist, 0, 18, 7)
+    with nt.Engine(klist, r_bits=18, s_bits=7) as e:
+        e.submit_reads(reads)
+        tc, ph, f1 = e.finish(counters=True)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+    tiles = torch.from_numpy(nt.tile_reads(reads, L)).cuda()
+    with nt.Engine(klist, r_bits=18, s_bits=7) as e:
+        with pytest.raises(nt.NtcError):
+            e.submit_tiled_device(tiles.data_ptr(), n, L)
+        tc, ph, f1 = e.finish(counters=True)
+        assert not f1.any() and not tc.any(), "a refused batch left counts behind"
+        e.submit_reads(reads)  # the engine is still usable
+        tc, ph, f1 = e.finish(counters=True)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+    with nt.Engine([32], r_bits=18, s_bits=7, flags=nt.FLAG_REQUIRE_TILED) as e:  # K1h alone has no such limit
+        e.submit_tiled_device(tiles.data_ptr(), n, L)
+        tc, ph, f1 = e.finish(counters=True)
+    o32, f32 = orc.sketch_reads(reads, [32], 0, 18, 7)
+    assert np.array_equal(f1, f32) and np.array_equal(tc, o32)
+
+
 def test_tiled_fullsize_config4_mixed_list(nt, tmp_path):
     """BASELINE config 4 (k = 32, 64, 96, 128 on 100 M reads) from TILED batches: k = 32 through K1h + K1f, the other three through K1 staging the tiles —
     F1, the sha1 of every raw t_Counter plane and the .hist bytes of the REAL reference for all four k"""
