@@ -52,7 +52,13 @@ typedef struct {
     void *stream;              /* hipStream_t to run on, or NULL for the device's null stream    */
     void *ext_sketch;          /* optional caller-owned DEVICE memory for the sketch:
                                   uint32_t [n_k][2][1<<r_bits]; NULL -> engine allocates.
-                                  (lets a host framework own/merge the buffer, e.g. RCCL reduce) */
+                                  (lets a host framework own/merge the buffer, e.g. RCCL reduce)
+                                  Its CONTENTS are the engine's from ntc_create / ntc_reset (which zero
+                                  it) on: the caller may read it behind ntc_flush / ntc_finish, and may
+                                  WRITE to it (an in-place reduce, a merge) only after a call of
+                                  ntc_device_state — which is what tells the engine that the counters
+                                  can change behind its back (the first sketch update after a reset
+                                  otherwise writes its counts into the zeroed buffer without reading) */
     void *ext_f1;              /* optional caller-owned DEVICE uint64_t [n_k]; NULL -> engine    */
     uint32_t flags;            /* NTC_FLAG_*                                                      */
     uint64_t log_entries;      /* capacity of the hit log in 4-byte entries, 0 = default (four per

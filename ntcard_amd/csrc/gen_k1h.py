@@ -142,7 +142,8 @@ S_TACC = (S_F1ACC, S_F1ACC + 1, S_SPARE, S_SUSOFF)  # timing build only (S_SUSCA
 INPUTS = ["karg_lo", "karg_hi", "wave_gid", "n_waves", "lds_wbase", "first_block", "end_block"]
 # byte offsets in struct K1hArgs (ntc_kernels.hpp); the kernel reads them with scalar loads
 KARG = dict(tiles=0, log=8, log_fill=16, sketch0=24, f1=32, dirty=40, tie=48, n_tiles=56, n_chunks=60, read_len=64, nv_last=68, key_base=72,
-            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128, s_bits=96, tails=144)
+            rmask2=76, log_regions=80, log_region_cap=84, table=88, blocks_per_wave=104, nb_magic=108, sus=112, sus_count=120, sus_cap=128, s_bits=96, tails=144,
+            sk_dirty=160)
 
 
 class Gen:
@@ -830,6 +831,17 @@ class Gen:
         p.i("v_mov_b32", v(key1), 0)
         p.i("v_lshl_add_u64", vr(lo, 2), vr(key, 2), 2, sr(S_SK, 2))
         p.i("global_atomic_add", vr(lo, 2), v(V_ONE), "off")
+        # (round 6) the sketch is no longer what the last reset or apply left: the engine's "direct atomics happened" word — the first apply behind a reset
+        # WRITES its counts instead of adding them (ntc_apply.hip, count_kernel) unless this word says otherwise.  Rare path: engines without a log
+        # (their pointer is NULL) and waves that ran out of log regions.
+        skipflag = self.lbl("skipflag")
+        p.i("s_load_dwordx2", sr(S_TMP, 2), sr(S_KARG, 2), hex(KARG["sk_dirty"]))
+        p.i("s_waitcnt", "lgkmcnt(0)")
+        p.i("s_cmp_eq_u64", sr(S_TMP, 2), 0)
+        p.i("s_cbranch_scc1", "@" + skipflag)
+        p.i("v_mov_b32", v(fld[2]), 0)
+        p.i("global_store_dword", v(fld[2]), v(V_ONE), sr(S_TMP, 2))
+        p.label(skipflag)
         p.label(logged)
         # ---- suspects: (key, tile, read | window << 11) -> this wave's region of the suspect list ----
         nosus, susfull = self.lbl("nosus"), self.lbl("susfull")

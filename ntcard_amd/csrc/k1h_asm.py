@@ -399,6 +399,9 @@ class Emu:
     def op_s_cmp_lg_u64(self, pc, o, m):
         self.scc = 1 if self.rd_s(o[0], 2) != self.rd_s(o[1], 2) else 0
 
+    def op_s_cmp_eq_u64(self, pc, o, m):
+        self.scc = 1 if self.rd_s(o[0], 2) == self.rd_s(o[1], 2) else 0
+
     def op_s_branch(self, pc, o, m):
         return self.labels[o[0][1]]
 

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 					const uint64_t at = (uint64_t)((kk >> a.shift) & dmask) * a.out_cap + off;
 					if (narrow) outw16[at] = (uint16_t)kk;
 					else outw[at] = kk;
-				} else
+				} else {
 					atomicAdd(a.sketch + kk, 1u); // run is full: apply directly (exact, slower)
+					if (a.sk_dirty) *a.sk_dirty = 1u;
+				}
 			}
 			__syncthreads(); // sorted / rel are rewritten by the next round
 		}
@@ -154,7 +156,11 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 	extern __shared__ __align__(16) uint32_t cnt[]; // [(1 << slice_bits) / 2]
 	const uint32_t tid = threadIdx.x, nt = blockDim.x;
 	const uint32_t n_cnt = 1u << a.slice_bits, cmask = n_cnt - 1u, n_words = n_cnt >> 1;
+	// the first apply behind a reset, and nothing has incremented the sketch directly: its counters are zero, so a slice's first pass WRITES its counts
+	// (no read: half the sweep's traffic) and leaves the groups it has no key for alone
+	const bool clean = a.first != 0u && (a.sk_dirty == nullptr || __builtin_amdgcn_readfirstlane((int)*a.sk_dirty) == 0);
 	for (uint32_t slice = blockIdx.x; slice < a.n_slices; slice += gridDim.x) {
+		bool fresh = clean; // this slice has not been written yet
 		uint32_t seg_add, seg_mul, seg_cnt;
 		if (a.mode == 0) { // raw log regions, single slice
 			seg_add = 0;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 				for (uint32_t i = tid; i < n_words / 2; i += nt) { // 2 dwords of LDS = 4 counters = one uint4 of the sketch
 					const uint2 c = reinterpret_cast<const uint2*>(cnt)[i];
 					if ((c.x | c.y) != 0u) {
-						uint4 s = reinterpret_cast<uint4*>(dst)[i];
+						uint4 s = fresh ? make_uint4(0, 0, 0, 0) : reinterpret_cast<uint4*>(dst)[i];
 						s.x += c.x & 0xffffu;
 						s.y += c.x >> 16;
 						s.z += c.y & 0xffffu;
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 						reinterpret_cast<uint4*>(dst)[i] = s;
 					}
 				}
+				fresh = false;
 			}
 			__syncthreads();
 		}
@@ -301,9 +308,11 @@ __global__ __launch_bounds__(1024) void log_total_kernel(const uint32_t* __restr
 	}
 }
 __global__ __launch_bounds__(256) void log_atomics_kernel(const uint32_t* __restrict__ log, uint32_t* __restrict__ fill, uint32_t region_cap,
-                                                          uint32_t n_regions, const uint32_t* __restrict__ total16, uint32_t max16, uint32_t* __restrict__ sketch)
+                                                          uint32_t n_regions, const uint32_t* __restrict__ total16, uint32_t max16, uint32_t* __restrict__ sketch,
+                                                          uint32_t* __restrict__ sk_dirty)
 {
 	if (*total16 > max16) return; // plenty: the partition passes take it
+	if (sk_dirty && blockIdx.x == 0 && threadIdx.x == 0) *sk_dirty = 1u;
 	for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
 		uint32_t n = fill[r];
 		n = n < region_cap ? n : region_cap;
@@ -314,11 +323,12 @@ __global__ __launch_bounds__(256) void log_atomics_kernel(const uint32_t* __rest
 	}
 }
 
-hipError_t launch_log_atomics(const uint32_t* log, uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t* total16, uint32_t* sketch, hipStream_t st)
+hipError_t launch_log_atomics(const uint32_t* log, uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t* total16, uint32_t* sketch, uint32_t* sk_dirty,
+                              hipStream_t st)
 {
 	hipLaunchKernelGGL(log_total_kernel, dim3(1), dim3(1024), 0, st, fill, n_regions, total16);
 	hipLaunchKernelGGL(log_atomics_kernel, dim3(n_regions < 4096u ? n_regions : 4096u), dim3(256), 0, st, log, fill, region_cap, n_regions, total16,
-	                   (4u << 20) >> 4, sketch);
+	                   (4u << 20) >> 4, sketch, sk_dirty);
 	return hipGetLastError();
 }
 

@@ -240,7 +240,15 @@ struct ntc_engine {
 	uint32_t* d_log = nullptr;      // [log_regions][log_region_cap]
 	uint32_t* d_logfill = nullptr;  // [log_regions]
 	uint32_t log_regions = 0, log_region_cap = 0;
-	uint64_t log_cap = 0;           // entries
+	uint32_t klog_regions = 0;      // K1f's own regions BEHIND the hash kernels' log_regions (round 6: the suspects it counts are log entries too); the apply reads all of them
+	uint64_t log_cap = 0;           // entries (of the hash kernels' regions)
+	// round 6: does the sketch still hold the zeros of the last reset?  Then the first apply writes its counts instead of adding them (count_kernel).  The
+	// host knows about applies, merges and pointers it has handed out (sk_host_dirty); kernels that increment the sketch themselves — K1 in direct mode, any
+	// wave out of log regions, K1f's slow path, a partition run that overflowed — set the device word.
+	uint32_t* d_skdirty = nullptr;
+	bool sk_host_dirty = true;
+	bool sk_exposed = false;        // ntc_device_state has handed the counters' address out: the caller may add to them whenever it likes
+	uint32_t all_log_regions() const { return log_regions + klog_regions; }
 	double log_est = 0.0;           // host-side upper estimate of the entries logged since the last apply
 	bool log_pending = false;
 	// log or direct atomics: decided ON THE DEVICE from a sample of what the first sizeable batch after a reset logged
@@ -394,14 +402,15 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	e->log_region_cap = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, cap / 8192)); // <= 65535: one run fits a 16-bit count pass
 	e->log_regions = (uint32_t)std::max<uint64_t>(1, cap / e->log_region_cap);
 	e->log_cap = (uint64_t)e->log_regions * e->log_region_cap;
+	e->klog_regions = std::max<uint32_t>(1, std::min<uint32_t>(1024, e->log_regions / 8)); // 32 Mi entries at the default geometry; a full region falls back to atomics
 	// pass 1: g1 workgroups, each owns every g1-th region and writes 2^b1 private runs; a run holds its expected
 	// share of a FULL log + 25 % (+64); what does not fit is applied directly (exact), so the margin is about speed only
 	ap.g1 = std::min<uint32_t>(e->log_regions, 256); // one 1024-thread workgroup per CU: few, long private runs (measured 128 … 4096)
-	const uint64_t share1 = (uint64_t)((e->log_regions + ap.g1 - 1) / ap.g1) * e->log_region_cap;
+	const uint64_t share1 = (uint64_t)((e->all_log_regions() + ap.g1 - 1) / ap.g1) * e->log_region_cap;
 	ap.cap1 = (uint32_t)((share1 >> ap.b1) * 5 / 4 + 64);
 	// pass 2: bucket b of pass 1 is split again by `parts2` workgroups
 	ap.parts2 = 4;
-	const uint64_t share2 = ((e->log_cap >> ap.b1) * 5 / 4) / ap.parts2 + 1;
+	const uint64_t share2 = ((((uint64_t)e->all_log_regions() * e->log_region_cap) >> ap.b1) * 5 / 4) / ap.parts2 + 1;
 	ap.cap2 = (uint32_t)((share2 >> ap.b2) * 13 / 10 + 64);
 	return true;
 }
@@ -469,17 +478,19 @@ int apply_log(ntc_engine* e)
 	}
 	// little in the log (decided on the device: fewer than 4 M entries): plain atomics, and the passes below find it empty
 	if (!e->partition_always)
-		HIP_TRY(ntc::launch_log_atomics(e->d_log, e->d_logfill, e->log_region_cap, e->log_regions, (uint32_t*)(e->d_logstats + 2), e->d_sketch, e->stream));
+		HIP_TRY(ntc::launch_log_atomics(e->d_log, e->d_logfill, e->log_region_cap, e->all_log_regions(), (uint32_t*)(e->d_logstats + 2), e->d_sketch, e->d_skdirty, e->stream));
 	ntc::CountArgs c;
 	std::memset(&c, 0, sizeof c);
 	c.slice_bits = ap.slice_bits;
 	c.n_slices = ap.n_slices;
 	c.sketch = e->d_sketch;
+	c.first = e->sk_host_dirty ? 0u : 1u; // nothing the host knows of has touched the sketch since the reset: the device word decides
+	c.sk_dirty = e->d_skdirty;
 	if (ap.b1 == 0) {
 		c.in = e->d_log;
 		c.in_cnt = e->d_logfill;
 		c.in_cap = e->log_region_cap;
-		c.n_in = e->log_regions;
+		c.n_in = e->all_log_regions();
 		c.mode = 0;
 	} else {
 		ntc::SplitArgs s1;
@@ -487,8 +498,9 @@ int apply_log(ntc_engine* e)
 		s1.in = e->d_log;
 		s1.in_cnt = e->d_logfill;
 		s1.in_cap = e->log_region_cap;
-		s1.n_in = e->log_regions;
+		s1.n_in = e->all_log_regions();
 		s1.mode = 0;
+		s1.sk_dirty = e->d_skdirty;
 		s1.shift = ap.key_bits - ap.b1;
 		s1.bits = ap.b1;
 		s1.out = e->d_s1;
@@ -522,6 +534,7 @@ int apply_log(ntc_engine* e)
 			s2.out_cnt = e->d_c2;
 			s2.out_cap = ap.cap2;
 			s2.sketch = e->d_sketch;
+			s2.sk_dirty = e->d_skdirty;
 			s2.narrow = 1;
 			HIP_TRY(ntc::launch_split(s2, nb1 * ap.parts2, e->stream));
 			c.in = e->d_s2;
@@ -537,7 +550,8 @@ int apply_log(ntc_engine* e)
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
 	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, 2u * (unsigned)di.cus), e->stream));
-	HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
+	e->sk_host_dirty = true;
+	HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->all_log_regions() * 4, e->stream));
 	if (e->profiling) {
 		HIP_TRY(hipEventRecord(ev1, e->stream));
 		e->apply_pending.emplace_back(ev0, ev1);
@@ -669,6 +683,7 @@ int run_batch(ntc_engine* e, const unsigned char* d_slots, const uint32_t* d_met
 				a.log_mode = e->d_logmode;
 			}
 			a.sketch0 = e->d_sketch;
+			a.sk_dirty = e->d_skdirty;
 			HIP_TRY(ntc::launch_sketch_hf(a, hp.grid, hp.wpb, hp.smem, e->stream));
 			return 0;
 		};
@@ -986,6 +1001,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			h.log = e->d_log;
 			h.log_fill = e->d_logfill;
 			h.sketch0 = e->d_sketch;
+			h.sk_dirty = e->d_skdirty;
 			h.f1 = e->d_f1 + ki;
 			h.dirty = ks0.d_dirty;
 			h.tie = ks0.d_tie;
@@ -1011,6 +1027,10 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			it.t4 = e->d_t4s[ki];
 			it.k = k;
 			it.n_waves = launched[i].n_wg * wpg; // (its suspect regions: those of the workgroups that walked it)
+			it.klog = e->d_log ? e->d_log + (size_t)e->log_regions * e->log_region_cap : nullptr;
+			it.klog_fill = e->d_log ? e->d_logfill + e->log_regions : nullptr;
+			it.klog_n = e->d_log ? e->klog_regions : 0u;
+			it.klog_cap = e->log_region_cap;
 		}
 		if (!e->defer_redo) // the caller may change the batches once the stream has passed this call: K1f now
 			if (int rc = join_k1f(e)) return rc;
@@ -1088,6 +1108,10 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		}
 		e->own_f1 = true;
 	}
+	if (hipMalloc((void**)&e->d_skdirty, 64) != hipSuccess) {
+		ntc_destroy(e);
+		return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate engine state on device");
+	}
 	if (hipMalloc((void**)&e->d_phist, e->klist.size() * 2 * 65536 * 4) != hipSuccess) {
 		ntc_destroy(e);
 		return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate histogram on device");
@@ -1121,7 +1145,8 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		while (plan_log(e, want)) {
 			const auto& ap = e->ap;
 			const size_t runs1 = ap.b1 ? (size_t)ap.g1 << ap.b1 : 0, runs2 = ap.b2 ? ((size_t)ap.parts2 << ap.b1) << ap.b2 : 0;
-			bool ok = hipMalloc((void**)&e->d_log, e->log_cap * 4) == hipSuccess && hipMalloc((void**)&e->d_logfill, (size_t)e->log_regions * 4) == hipSuccess;
+			bool ok = hipMalloc((void**)&e->d_log, (size_t)e->all_log_regions() * e->log_region_cap * 4) == hipSuccess &&
+			          hipMalloc((void**)&e->d_logfill, (size_t)e->all_log_regions() * 4) == hipSuccess;
 			ok = ok && (e->d_logmode || hipMalloc((void**)&e->d_logmode, 4) == hipSuccess) && (e->d_logstats || hipMalloc((void**)&e->d_logstats, 24) == hipSuccess) &&
 			     (e->d_probe || hipMalloc((void**)&e->d_probe, 4u << 20) == hipSuccess);
 			ok = ok && (!runs1 || (hipMalloc((void**)&e->d_s1, runs1 * ap.cap1 * ap.key_bytes(1)) == hipSuccess && hipMalloc((void**)&e->d_c1, runs1 * 4) == hipSuccess));
@@ -1139,7 +1164,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 					ntc_destroy(e);
 					return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate the %llu-entry hit log and its partition areas on device", asked);
 				}
-				e->log_regions = e->log_region_cap = 0;
+				e->log_regions = e->log_region_cap = e->klog_regions = 0;
 				e->log_cap = 0;
 				break;
 			}
@@ -1209,6 +1234,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_untile) (void)hipFree(e->d_untile);
+	if (e->d_skdirty) (void)hipFree(e->d_skdirty);
 	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
@@ -1258,7 +1284,9 @@ int ntc_reset(ntc_engine* e)
 	if (int rc = join_k1f(e)) return rc;
 	HIP_TRY(hipMemsetAsync(e->d_sketch, 0, e->hll_bits ? (sizeof(uint32_t) << e->hll_bits) : e->klist.size() * e->plane_elems() * sizeof(uint32_t), e->stream));
 	e->hll_reads_seen = 0;
-	if (e->d_logfill) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->log_regions * 4, e->stream));
+	if (e->d_logfill) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->all_log_regions() * 4, e->stream));
+	if (e->d_skdirty) HIP_TRY(hipMemsetAsync(e->d_skdirty, 0, 4, e->stream));
+	e->sk_host_dirty = e->sk_exposed; // (a caller that has asked for the counters' address may write there at any time; ext_sketch: include/ntcard_hip.h)
 	if (e->d_logmode) {
 		HIP_TRY(hipMemsetAsync(e->d_logmode, 0, 4, e->stream));
 		HIP_TRY(hipMemsetAsync(e->d_logstats, 0, 24, e->stream));
@@ -1826,6 +1854,7 @@ int ntc_merge_counters(ntc_engine* e, const uint16_t* t_counter, const uint64_t*
 	for (size_t ki = 0; ki < nk; ++ki) {
 		HIP_TRY(hipMemcpyAsync(e->d_out16, t_counter + ki * per_k, per_k * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
 		HIP_TRY(ntc::launch_add_counters(e->d_sketch + ki * per_k, e->d_out16, per_k, e->stream));
+		e->sk_host_dirty = true;
 	}
 	if (f1) {
 		std::vector<unsigned long long> cur(nk);
@@ -2038,6 +2067,7 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 				HIP_TRY(hipStreamWaitEvent(r0.e->stream, r0.arrived[j], 0));
 			}
 			HIP_TRY(ntc::launch_widen_u16(r0.narrow, r0.e->d_sketch, counters, r0.e->stream));
+			r0.e->sk_host_dirty = true;
 			for (MergePeer& p : peers) {
 				HIP_TRY(hipSetDevice(p.e->device));
 				for (hipStream_t s : p.lanes)
@@ -2067,7 +2097,10 @@ int ntc_device_state(ntc_engine* e, void** d_sketch_u32, uint64_t* n_counters, v
 		HIP_TRY(hipSetDevice(e->device));
 		if (int rc = apply_log(e)) return rc; // the caller is about to read or reduce the counters
 	}
-	if (d_sketch_u32) *d_sketch_u32 = e->d_sketch;
+	if (d_sketch_u32) {
+		*d_sketch_u32 = e->d_sketch;
+		e->sk_host_dirty = e->sk_exposed = true; // (the caller may add to the counters: nothing is known about them any more)
+	}
 	if (n_counters) *n_counters = e->klist.size() * e->plane_elems();
 	if (d_f1_u64) *d_f1_u64 = e->d_f1;
 	return 0;

@@ -212,8 +212,10 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 			lfill += c;
 		} else if (hit) {
 			atomicAdd(a.sketch0 + key, 1u);
+			if (a.sk_dirty) *a.sk_dirty = 1u; // (out of log regions: the sketch is no longer what the last reset / apply left, ntc_apply.hip count_kernel)
 		}
 	};
+	if (kMode != 2 && !use_log && a.sk_dirty != nullptr && lane == 0) *a.sk_dirty = 1u; // direct atomics from here on (the device mode word, or no regions)
 	uint64_t f1_acc[kMaxFusedK] = {0, 0, 0, 0};
 	uint32_t shb = (0u - k) & 3u; // byte phase of the outgoing-base stream
 

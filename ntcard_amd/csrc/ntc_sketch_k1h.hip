@@ -202,11 +202,40 @@ __device__ __forceinline__ void k1f_f1_role(const K1fItem& item, const uint32_t 
 // loads; side by side they take little longer than one of them), so it cannot know yet whether the launch must take the slow path (a table-slot
 // byte in some dirty piece): it counts, and leaves the counter it incremented in the entry (x = counter index, w = 1) — the slow path takes
 // those increments back before it re-derives everything from the bytes.  No LDS, few registers.
+// Round 6: "counts" = appends the counter index to the hit log (ntc_apply.hip applies it with everything else: counting commutes, ntcard.cpp:142-143) — the
+// 0.3 M scattered device atomics per 10 M reads of dist g were a fifth of K1f's scattered accesses, and with them gone the sketch stays untouched
+// between a reset and the first apply.  A wave takes a place for its hits in one of K1f's own log regions with ONE cursor atomic; a full region falls
+// back to the atomic (exact) and says so in the engine's sk_dirty word.
 __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint32_t bx, const uint32_t nbx)
 {
 	const K1hArgs& a = item.a;
 	const uint32_t k = item.k, n_sus_waves = item.n_waves;
-	const uint32_t tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	uint32_t kreg = 0;
+	auto count_hit = [&](bool hit, uint32_t idx) {
+		const uint64_t bm = __builtin_amdgcn_ballot_w64(hit);
+		if (bm == 0) return;
+		if (item.klog_n == 0u) {
+			if (hit) {
+				atomicAdd(a.sketch0 + idx, 1u);
+				if (a.sk_dirty) *a.sk_dirty = 1u;
+			}
+			return;
+		}
+		const uint32_t leader = (uint32_t)__builtin_ctzll(bm);
+		uint32_t base = 0;
+		if (lane == leader) base = atomicAdd(item.klog_fill + kreg, (uint32_t)__popcll(bm));
+		base = (uint32_t)__shfl((int)base, (int)leader);
+		if (hit) {
+			const uint32_t pos = base + ballot_rank(bm);
+			if (pos < item.klog_cap) {
+				item.klog[(size_t)kreg * item.klog_cap + pos] = idx;
+			} else {
+				atomicAdd(a.sketch0 + idx, 1u);
+				if (a.sk_dirty) *a.sk_dirty = 1u;
+			}
+		}
+	};
 	const uint32_t C = a.n_chunks, s_bits = a.s_bits, r_bits = a.r_bits;
 	const uint32_t rmask = (1u << r_bits) - 1u;
 	const uint4* const t4v = reinterpret_cast<const uint4*>(item.t4);
@@ -214,7 +243,12 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 	for (uint32_t reg = sus_w0 + bx; reg < sus_w0 + n_sus_waves; reg += nbx) { // a K1h wave's region per block (eight waves per CU: ~180 suspects per region and 10 M reads of dist g)
 		uint32_t n = a.sus_count[reg];
 		if (n == 0xffffffffu) n = 0; // the region overflowed: the launch takes the slow path, which ignores the suspects
-		for (uint32_t i = tid; i < n; i += 256u) {
+		if (item.klog_n) kreg = (reg * 4u + (tid >> 6) + blockIdx.y * 61u) % item.klog_n; // (the K1f waves of a launch spread over K1f's log regions)
+		for (uint32_t i0 = 0; i0 < n; i0 += 256u) { // (n is the block's: every wave takes every turn)
+		  const uint32_t i = i0 + tid;
+		  bool hit = false;
+		  uint32_t hit_idx = 0;
+		  if (i < n) do {
 			uint4* const ep = a.sus + (size_t)reg * a.sus_cap + i;
 			const uint4 e = *ep;
 			const uint32_t t = e.y, r = e.z & 2047u, w = e.z >> 11;
@@ -233,7 +267,8 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 					if (c0 + j < C && 16u * j < off + k && ((e.w >> (4u + j)) & 1u))
 						inv |= (uint64_t)tilebits::inv16(raw_piece(a, t, c0 + j, r)) << (16u * j);
 				if (((inv >> off) & win) != 0ull) continue; // a non-letter byte inside the window: nothing (ntHashIterator.hpp:59-86)
-				atomicAdd(a.sketch0 + e.x, 1u);
+				hit = true;
+				hit_idx = e.x;
 				ep->w = 1u; // (x already is the counter index)
 				continue;
 			}
@@ -266,10 +301,13 @@ __device__ __forceinline__ void k1f_suspect_role(const K1fItem& item, const uint
 			if ((h >> (64u - s_bits)) == (1ull << (s_bits - 1u)) - 1ull) smp = 1;
 			if (smp < 2u) {
 				const uint32_t idx = a.key_base + (smp << r_bits) + (uint32_t)(h & (uint64_t)rmask); // (engines with a hit log have < 2^32 counters; K1h itself keys them with 32 bits)
-				atomicAdd(a.sketch0 + idx, 1u);
+				hit = true;
+				hit_idx = idx;
 				ep->x = idx;
 				ep->w = 1u;
 			}
+		  } while (false);
+		  count_hit(hit, hit_idx);
 		}
 	}
 }
@@ -334,6 +372,7 @@ __global__ __launch_bounds__(256) void k1h_slow_kernel(const K1fBatch batch)
 	}
 	if (!flagged) return;
 	const bool slow = true;
+	if (a.sk_dirty && tid == 0) *a.sk_dirty = 1u; // (the slow path takes increments back and counts with device atomics: the sketch is no longer what the last apply left)
 	// what the suspect role counted goes back first: every window of a dirty-affected block is re-derived below, tie windows included
 	for (uint32_t reg = a.first_wg * kK1hWaves + blockIdx.x; reg < a.first_wg * kK1hWaves + item.n_waves; reg += gridDim.x) {
 		uint32_t n = a.sus_count[reg];

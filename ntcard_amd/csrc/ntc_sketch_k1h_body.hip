@@ -23,7 +23,7 @@ static_assert(offsetof(K1hArgs, tiles) == 0 && offsetof(K1hArgs, log) == 8 && of
                   offsetof(K1hArgs, n_chunks) == 60 && offsetof(K1hArgs, read_len) == 64 && offsetof(K1hArgs, nv_last) == 68 && offsetof(K1hArgs, key_base) == 72 &&
                   offsetof(K1hArgs, rmask2) == 76 && offsetof(K1hArgs, log_regions) == 80 && offsetof(K1hArgs, log_region_cap) == 84 && offsetof(K1hArgs, table) == 88 &&
                   offsetof(K1hArgs, blocks_per_wave) == 104 && offsetof(K1hArgs, nb_magic) == 108 && offsetof(K1hArgs, sus) == 112 &&
-                  offsetof(K1hArgs, sus_count) == 120 && offsetof(K1hArgs, sus_cap) == 128 && offsetof(K1hArgs, tails) == 144,
+                  offsetof(K1hArgs, sus_count) == 120 && offsetof(K1hArgs, sus_cap) == 128 && offsetof(K1hArgs, tails) == 144 && offsetof(K1hArgs, sk_dirty) == 160,
               "gen_k1h.KARG");
 constexpr uint32_t kK1hWaves = K1H_GEN_WAVES;
 constexpr uint32_t kK1hWArea = K1H_GEN_WAREA;

@@ -64,7 +64,7 @@ class Layout:
         return a
 
 
-def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096, gap=0, tails=None):
+def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_regions=None, log_region_cap=4096, use_log=True, sus_cap=4096, gap=0, tails=None, sk_dirty_word=True):
     """-> dict(keys=uint32[], f1=int, dirty=[n_tiles][C][64], tie=[n_tiles][NB][64], insts=executed per wave)"""
     Cn = (read_len + 15) // 16
     n_tiles = (n_reads + 2047) // 2048
@@ -83,6 +83,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     a_tie = lay.alloc(n_tiles * NB * 256)
     a_sus = lay.alloc(n_waves * sus_cap * 16)
     a_susn = lay.alloc(n_waves * 4)
+    a_skd = lay.alloc(64)  # the engine's "direct atomics happened" word (round 6)
     a_tails = lay.alloc(n_tiles * 64) if tails is not None else 0  # ragged batch: uint32 [n_tiles][16], reads of the tile with more than d bases in their last piece
     mem = lay.mem
     mem[a_tiles:a_tiles + tiles.size] = tiles
@@ -102,6 +103,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     m32[(a_karg + K["nb_magic"]) // 4] = (1 << 32) // NB
     m32[(a_karg + K["sus_cap"]) // 4] = sus_cap
     m64[(a_karg + K["tails"]) // 8] = a_tails
+    m64[(a_karg + K["sk_dirty"]) // 8] = a_skd if sk_dirty_word else 0
     if tails is not None:
         m32[a_tails // 4: a_tails // 4 + n_tiles * 16] = np.asarray(tails, dtype=np.uint32).reshape(-1)
     lds = np.zeros(gen_k1h.LDS_BYTES, dtype=np.uint8)
@@ -126,7 +128,7 @@ def run_k1h(tiles, n_reads, read_len, k, r_bits=16, s_bits=7, n_waves=2, log_reg
     sk = m32[a_sk // 4: a_sk // 4 + (2 << r_bits)].copy()
     susn = m32[a_susn // 4: a_susn // 4 + n_waves].copy()
     sus = [m32[a_sus // 4 + w * sus_cap * 4: a_sus // 4 + (w * sus_cap + min(int(susn[w]), sus_cap)) * 4].reshape(-1, 4).copy() for w in range(n_waves)]
-    return dict(sus=np.concatenate(sus) if sus else np.zeros((0, 4), dtype=np.uint32), sus_overflow=bool(np.any(susn == 0xFFFFFFFF)), keys=keys.copy(), sketch=sk, f1=int(m64[a_f1 // 8]), f1_raw=m64[a_f1 // 8: a_f1 // 8 + 8].copy(), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
+    return dict(sus=np.concatenate(sus) if sus else np.zeros((0, 4), dtype=np.uint32), sus_overflow=bool(np.any(susn == 0xFFFFFFFF)), keys=keys.copy(), sketch=sk, sk_dirty=int(m32[a_skd // 4]), f1=int(m64[a_f1 // 8]), f1_raw=m64[a_f1 // 8: a_f1 // 8 + 8].copy(), dirty=m32[a_dirty // 4: a_dirty // 4 + n_tiles * Cn * 64].reshape(n_tiles, Cn, 64).copy(),
                 tie=m32[a_tie // 4: a_tie // 4 + n_tiles * NB * 64].reshape(n_tiles, NB, 64).copy(), insts=insts, NB=NB, C=Cn)
 
 

@@ -86,8 +86,14 @@ def test_k1h_emulated_150bp_two_tiles():
 
 
 def test_k1h_emulated_log_regions_and_direct_atomics():
-    run(4096, 100, 31, 0.005, log_region_cap=256, log_regions=6)  # region switches, then out of regions: device atomics
-    run(2048, 80, 32, use_log=False)
+    res = run(4096, 100, 31, 0.005, log_region_cap=256, log_regions=6)  # region switches, then out of regions: device atomics
+    assert res["sketch"].any() and res["sk_dirty"] == 1              # ... which the wave reports in the engine's "direct atomics happened" word (round 6)
+    res = run(2048, 80, 32, use_log=False)
+    assert res["sketch"].any() and res["sk_dirty"] == 1
+    res = run(2048, 80, 32, use_log=False, sk_dirty_word=False)        # an engine without a log passes no such word
+    assert res["sk_dirty"] == 0
+    res = run(2048, 80, 32)                                           # everything logged: the word stays clear
+    assert not res["sketch"].any() and res["sk_dirty"] == 0
 
 
 def test_k1h_emulated_suspect_overflow_and_dense_non_bases():

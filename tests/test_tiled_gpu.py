@@ -34,6 +34,13 @@ def gen_host(n, L, dist, genome_len=200_000, seed=1):
     return [sl[i * stride: i * stride + L].tobytes() for i in range(n)]
 
 
+class _DevArray:
+    """zero-copy view of a device int32 array for torch.as_tensor (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
 VARIANT_FLAGS = 0  # (rounds 3-4 ran every test of this module a second time through K1c, NTC_FLAG_TILED_TEAMS; round 5 retired that kernel)
 
 
@@ -107,6 +114,53 @@ def test_tiled_batches_and_modes(nt):
     check(nt, reads, 150, pieces=3)
     check(nt, reads, 150, flags=nt.FLAG_DIRECT_ATOMICS)
     check(nt, reads, 150, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, pieces=2)
+
+
+def test_first_apply_writes_and_later_ones_add(nt):
+    """round 6: the first sketch update behind a reset WRITES its counts into the zeroed sketch (count_kernel, no read) unless some kernel has incremented the
+    sketch itself — K1h waves out of log regions, K1f's overflow / slow path, a partition run that overflowed; K1f's suspects are log entries of regions of
+    their own.  Every order of (logged | direct) x (first | later apply), across flushes and a reset, against the oracle"""
+    rng = np.random.default_rng(6)
+    alpha = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    n, L = 40_000, 150
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    arr = np.where(rng.random((n, L)) < 0.004, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    reads = [arr[i].tobytes() for i in range(n)]
+    parts = [reads[:15_000], reads[15_000:22_000], reads[22_000:]]
+    tiles = [torch.from_numpy(nt.tile_reads(p, L)).cuda() for p in parts]
+    oc, of1 = orc.sketch_reads(reads, [32], 0, 18, 7)
+    oc2, of12 = orc.sketch_reads(parts[1] + parts[2], [32], 0, 18, 7)
+    # log_entries: default (everything logged, one apply), 2^18 (several applies inside a batch), 2^14 (64 regions of 256: the waves run out of regions and count
+    # with device atomics before the first apply: it must add, not write)
+    for le in (0, 1 << 18, 1 << 14):
+        for flags in (nt.FLAG_PARTITION_ALWAYS | nt.FLAG_REQUIRE_TILED, nt.FLAG_PARTITION_ALWAYS | nt.FLAG_REQUIRE_TILED | nt.FLAG_DEFER_REDO, nt.FLAG_REQUIRE_TILED):
+            with nt.Engine([32], r_bits=18, s_bits=7, flags=flags, log_entries=le) as e:
+                e.submit_tiled_device(tiles[0].data_ptr(), len(parts[0]), L)
+                e.flush()                                            # first apply
+                e.submit_tiled_device(tiles[1].data_ptr(), len(parts[1]), L)
+                e.flush()                                            # adds
+                e.flush()                                            # nothing pending
+                e.submit_tiled_device(tiles[2].data_ptr(), len(parts[2]), L)
+                tc, ph, f1 = e.finish(counters=True)
+                assert np.array_equal(f1, of1) and np.array_equal(tc, oc), (le, flags)
+                e.reset()                                            # the sketch is zero again: the next apply is a first one
+                e.submit_tiled_device(tiles[1].data_ptr(), len(parts[1]), L)
+                e.submit_tiled_device(tiles[2].data_ptr(), len(parts[2]), L)
+                tc, ph, f1 = e.finish(counters=True)
+                assert np.array_equal(f1, of12) and np.array_equal(tc, oc2), (le, flags, "after reset")
+    # the address of the counters handed out: the caller may have added to them, so no apply may overwrite
+    with nt.Engine([32], r_bits=18, s_bits=7, flags=nt.FLAG_PARTITION_ALWAYS | nt.FLAG_REQUIRE_TILED) as e:
+        sk, ncnt, _ = e.device_state()
+        view = torch.as_tensor(_DevArray(sk, ncnt), device="cuda")
+        view[12345] += 7
+        torch.cuda.synchronize()
+        e.submit_tiled_device(tiles[0].data_ptr(), len(parts[0]), L)
+        e.submit_tiled_device(tiles[1].data_ptr(), len(parts[1]), L)
+        e.submit_tiled_device(tiles[2].data_ptr(), len(parts[2]), L)
+        tc, ph, f1 = e.finish(counters=True)
+    want = oc.reshape(-1).copy()
+    want[12345] += 7
+    assert np.array_equal(tc.reshape(-1), want)
 
 
 @pytest.mark.parametrize("k", list(range(12, 32)))
