@@ -192,16 +192,29 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 				const uint32_t take = n - off < 65535u - taken ? n - off : 65535u - taken;
 				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap + off;
 				const uint16_t* src16 = reinterpret_cast<const uint16_t*>(a.in) + (uint64_t)seg * a.in_cap + off;
-				for (uint32_t i = tid; i < take; i += nt) {
-					const uint32_t kk = (a.in16 ? (uint32_t)src16[i] : src[i]) & cmask;
-					// hot counters (a few thousand distinct k-mers sampled at huge coverage: every key of a run is the same) would put all 64
-					// lanes on one LDS word, 64 serialised atomics per instruction: a wave whose keys are all equal adds their number once
-					const uint64_t act = __ballot(true);
-					const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kk);
-					if (__ballot(kk == first) == act) {
-						if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&cnt[kk >> 1], (uint32_t)__popcll(act) << ((kk & 1u) * 16u));
-					} else {
-						atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
+				// eight loads in flight per thread before the first LDS atomic (round 6: one load per iteration left a wave with a single request in
+				// flight — 36 us per slice and workgroup, 3.1 TB/s for the whole pass)
+				for (uint32_t base = 0; base < take; base += nt * 8u) {
+					uint32_t kq[8];
+#pragma unroll
+					for (uint32_t j = 0; j < 8u; ++j) {
+						const uint32_t i = base + j * nt + tid;
+						const uint32_t ic = i < take ? i : take - 1u; // (clamped address, not a predicated load)
+						kq[j] = a.in16 ? (uint32_t)src16[ic] : src[ic];
+					}
+#pragma unroll
+					for (uint32_t j = 0; j < 8u; ++j) {
+						if (base + j * nt + tid >= take) continue;
+						const uint32_t kk = kq[j] & cmask;
+						// hot counters (a few thousand distinct k-mers sampled at huge coverage: every key of a run is the same) would put all 64
+						// lanes on one LDS word, 64 serialised atomics per instruction: a wave whose keys are all equal adds their number once
+						const uint64_t act = __ballot(true);
+						const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kk);
+						if (__ballot(kk == first) == act) {
+							if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&cnt[kk >> 1], (uint32_t)__popcll(act) << ((kk & 1u) * 16u));
+						} else {
+							atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
+						}
 					}
 				}
 				taken += take;
@@ -213,15 +226,31 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 			}
 			__syncthreads();
 			if (taken != 0) {
-				for (uint32_t i = tid; i < n_words / 2; i += nt) { // 2 dwords of LDS = 4 counters = one uint4 of the sketch
-					const uint2 c = reinterpret_cast<const uint2*>(cnt)[i];
-					if ((c.x | c.y) != 0u) {
-						uint4 s = fresh ? make_uint4(0, 0, 0, 0) : reinterpret_cast<uint4*>(dst)[i];
-						s.x += c.x & 0xffffu;
-						s.y += c.x >> 16;
-						s.z += c.y & 0xffffu;
-						s.w += c.y >> 16;
-						reinterpret_cast<uint4*>(dst)[i] = s;
+				// 2 dwords of LDS = 4 counters = one uint4 of the sketch; four groups per thread and turn, their sketch words loaded together
+				for (uint32_t i0 = tid; i0 < n_words / 2; i0 += nt * 4u) {
+					uint2 c[4];
+					uint4 s4[4];
+#pragma unroll
+					for (uint32_t j = 0; j < 4u; ++j) {
+						const uint32_t i = i0 + j * nt;
+						c[j] = i < n_words / 2 ? reinterpret_cast<const uint2*>(cnt)[i] : make_uint2(0, 0);
+					}
+#pragma unroll
+					for (uint32_t j = 0; j < 4u; ++j) {
+						const uint32_t i = i0 + j * nt;
+						s4[j] = (!fresh && (c[j].x | c[j].y) != 0u) ? reinterpret_cast<const uint4*>(dst)[i] : make_uint4(0, 0, 0, 0);
+					}
+#pragma unroll
+					for (uint32_t j = 0; j < 4u; ++j) {
+						const uint32_t i = i0 + j * nt;
+						if ((c[j].x | c[j].y) != 0u) {
+							uint4 s = s4[j];
+							s.x += c[j].x & 0xffffu;
+							s.y += c[j].x >> 16;
+							s.z += c[j].y & 0xffffu;
+							s.w += c[j].y >> 16;
+							reinterpret_cast<uint4*>(dst)[i] = s;
+						}
 					}
 				}
 				fresh = false;
@@ -343,7 +372,7 @@ hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st)
 hipError_t launch_count(const CountArgs& a, unsigned grid, hipStream_t st)
 {
 	const size_t smem = (sizeof(uint32_t) << a.slice_bits) / 2;
-	hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(1024), smem, st, a);
+	hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(a.slice_bits >= 15 ? 1024 : 512), smem, st, a); // (two workgroups of 1024 threads or four of 512 per CU)
 	return hipGetLastError();
 }
 

@@ -214,6 +214,18 @@ int hash_grid(int dev, uint64_t n_slots, uint32_t stride, unsigned& grid, size_t
 	return 0;
 }
 
+// geometry of the partition passes (plan_log); A/B builds override them (tools/ab_build.sh <name> -DNTC_AB_G1=512): the product has no run-time knob
+#ifndef NTC_AB_G1
+#define NTC_AB_G1 256
+#endif
+#ifndef NTC_AB_PARTS2
+#define NTC_AB_PARTS2 4
+#endif
+#ifndef NTC_AB_SLICE_BITS
+#define NTC_AB_SLICE_BITS 15
+#endif
+constexpr uint32_t kApplyG1 = NTC_AB_G1, kApplyParts2 = NTC_AB_PARTS2, kApplySliceBits = NTC_AB_SLICE_BITS;
+
 uint32_t ceil_log2(uint64_t x)
 {
 	uint32_t b = 0;
@@ -388,7 +400,7 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	if (counters > (1ull << 32)) return false;
 	auto& ap = e->ap;
 	ap.key_bits = ceil_log2(counters);
-	ap.slice_bits = std::min<uint32_t>(15, ap.key_bits);
+	ap.slice_bits = std::min<uint32_t>(kApplySliceBits, ap.key_bits);
 	const uint32_t pb = ap.key_bits - ap.slice_bits;
 	if (pb > 16) return false;
 	ap.b1 = pb <= 8 ? pb : (pb + 1) / 2; // two passes: balanced fan-out (longer runs per digit coalesce better than 256-way + 32-way); with the second
@@ -405,11 +417,11 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	e->klog_regions = std::max<uint32_t>(1, std::min<uint32_t>(1024, e->log_regions / 8)); // 32 Mi entries at the default geometry; a full region falls back to atomics
 	// pass 1: g1 workgroups, each owns every g1-th region and writes 2^b1 private runs; a run holds its expected
 	// share of a FULL log + 25 % (+64); what does not fit is applied directly (exact), so the margin is about speed only
-	ap.g1 = std::min<uint32_t>(e->log_regions, 256); // one 1024-thread workgroup per CU: few, long private runs (measured 128 … 4096)
+	ap.g1 = std::min<uint32_t>(e->log_regions, kApplyG1); // one 1024-thread workgroup per CU: few, long private runs (measured 128 … 4096)
 	const uint64_t share1 = (uint64_t)((e->all_log_regions() + ap.g1 - 1) / ap.g1) * e->log_region_cap;
 	ap.cap1 = (uint32_t)((share1 >> ap.b1) * 5 / 4 + 64);
 	// pass 2: bucket b of pass 1 is split again by `parts2` workgroups
-	ap.parts2 = 4;
+	ap.parts2 = kApplyParts2;
 	const uint64_t share2 = ((((uint64_t)e->all_log_regions() * e->log_region_cap) >> ap.b1) * 5 / 4) / ap.parts2 + 1;
 	ap.cap2 = (uint32_t)((share2 >> ap.b2) * 13 / 10 + 64);
 	return true;
@@ -549,7 +561,7 @@ int apply_log(ntc_engine* e)
 	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
-	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, 2u * (unsigned)di.cus), e->stream));
+	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, (ap.slice_bits >= 15 ? 2u : 4u) * (unsigned)di.cus), e->stream));
 	e->sk_host_dirty = true;
 	HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->all_log_regions() * 4, e->stream));
 	if (e->profiling) {
