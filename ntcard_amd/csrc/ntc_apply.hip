@@ -159,6 +159,11 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 	// the first apply behind a reset, and nothing has incremented the sketch directly: its counters are zero, so a slice's first pass WRITES its counts
 	// (no read: half the sweep's traffic) and leaves the groups it has no key for alone
 	const bool clean = a.first != 0u && (a.sk_dirty == nullptr || __builtin_amdgcn_readfirstlane((int)*a.sk_dirty) == 0);
+	// the counts are zero between passes: zeroed once here, and the sweep clears every word it reads (round 6: no zeroing loop and one barrier less per pass:
+	// 0.57 -> 0.50 ms per apply of 366 M keys)
+	for (uint32_t i = tid; i < n_words / 4; i += nt)
+		reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+	__syncthreads();
 	for (uint32_t slice = blockIdx.x; slice < a.n_slices; slice += gridDim.x) {
 		bool fresh = clean; // this slice has not been written yet
 		uint32_t seg_add, seg_mul, seg_cnt;
@@ -181,9 +186,6 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 		while (t < seg_cnt && a.in_cnt[t * seg_mul + seg_add] == 0u) // leading empty runs (an empty log costs no LDS traffic at all)
 			++t;
 		while (t < seg_cnt) {
-			for (uint32_t i = tid; i < n_words / 4; i += nt)
-				reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
-			__syncthreads();
 			uint32_t taken = 0; // keys of this pass (the same for every thread): at most 65535, so that no 16-bit count wraps into its neighbour
 			while (t < seg_cnt && taken < 65535u) {
 				const uint32_t seg = t * seg_mul + seg_add;
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 				const uint32_t take = n - off < 65535u - taken ? n - off : 65535u - taken;
 				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap + off;
 				const uint16_t* src16 = reinterpret_cast<const uint16_t*>(a.in) + (uint64_t)seg * a.in_cap + off;
-				// eight loads in flight per thread before the first LDS atomic (round 6: one load per iteration left a wave with a single request in
-				// flight — 36 us per slice and workgroup, 3.1 TB/s for the whole pass)
+				// eight loads in flight per thread before the first LDS atomic (measured: no faster than one per turn; nor is a form that reads eight uint16
+				// keys per lane and load from up to four runs at once — profiles/r06_apply_kernels.txt — the pass is not bound by its key loads)
 				for (uint32_t base = 0; base < take; base += nt * 8u) {
 					uint32_t kq[8];
 #pragma unroll
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 					for (uint32_t j = 0; j < 4u; ++j) {
 						const uint32_t i = i0 + j * nt;
 						c[j] = i < n_words / 2 ? reinterpret_cast<const uint2*>(cnt)[i] : make_uint2(0, 0);
+						if ((c[j].x | c[j].y) != 0u) reinterpret_cast<uint2*>(cnt)[i] = make_uint2(0, 0);
 					}
 #pragma unroll
 					for (uint32_t j = 0; j < 4u; ++j) {

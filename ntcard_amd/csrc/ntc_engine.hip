@@ -419,11 +419,11 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 	// share of a FULL log + 25 % (+64); what does not fit is applied directly (exact), so the margin is about speed only
 	ap.g1 = std::min<uint32_t>(e->log_regions, kApplyG1); // one 1024-thread workgroup per CU: few, long private runs (measured 128 … 4096)
 	const uint64_t share1 = (uint64_t)((e->all_log_regions() + ap.g1 - 1) / ap.g1) * e->log_region_cap;
-	ap.cap1 = (uint32_t)((share1 >> ap.b1) * 5 / 4 + 64);
+	ap.cap1 = (uint32_t)(((share1 >> ap.b1) * 5 / 4 + 64 + 7) & ~7ull); // (multiples of 8 keys: the count pass reads uint16 runs 16 bytes at a time)
 	// pass 2: bucket b of pass 1 is split again by `parts2` workgroups
 	ap.parts2 = kApplyParts2;
 	const uint64_t share2 = ((((uint64_t)e->all_log_regions() * e->log_region_cap) >> ap.b1) * 5 / 4) / ap.parts2 + 1;
-	ap.cap2 = (uint32_t)((share2 >> ap.b2) * 13 / 10 + 64);
+	ap.cap2 = (uint32_t)(((share2 >> ap.b2) * 13 / 10 + 64 + 7) & ~7ull);
 	return true;
 }
 
