@@ -292,6 +292,19 @@ struct ntc_engine {
 	} k1h_set[ntc::kK1fBatch];
 	ntc::K1fBatch k1f_batch;        // the launches waiting for K1f (k1f_batch.item[i] uses k1h_set[i])
 	uint32_t k1f_n = 0;
+	// Round 6: with NTC_FLAG_DEFER_REDO the HASH launches wait as well — up to eight device-resident tiled batches are hashed by ONE K1h launch per k, as
+	// segments that share its workgroups (K1hMulti, built for the length bins of a ragged read set).  A K1h wave that starts inside a tile walks two masked
+	// blocks first to fill its window: 8 % of a 10 M-read launch (24 blocks per wave), 1 % of an 80 M-read one; and a launch's ramp and tail are paid once.
+	// The caller's promise is the same as for K1f: the batches stay unchanged until ntc_sync.  Everything that reads counters or F1, or ends the promise,
+	// goes through join_k1f, which launches what waits here first.
+	struct DeferredSeg {
+		const unsigned char* d_tiles;
+		uint64_t n_reads;
+		uint32_t read_len;
+		const uint32_t* d_tails;
+	};
+	std::vector<DeferredSeg> deferred;
+	bool in_flush = false;
 	// ntc_merge_devices: exchange buffers, copy streams and events, kept between merges (grow-only)
 	struct MergeCache {
 		uint16_t *narrow = nullptr, *recv = nullptr;
@@ -443,8 +456,11 @@ int close_run(ntc_engine* e) // the end of a bracketed run of tiled hash launche
 	return 0;
 }
 
+int flush_deferred(ntc_engine* e); // the hash launches of the batches that wait in e->deferred (below, behind run_tiled_segs)
+
 int join_k1f(ntc_engine* e)
 {
+	if (int rc = flush_deferred(e)) return rc;
 	if (int rc = close_run(e)) return rc;
 	if (e->k1f_n == 0) return 0;
 	DevInfo di;
@@ -780,7 +796,7 @@ struct TiledSeg {
 	uint32_t read_len;
 	const uint32_t* d_tails;
 };
-int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in);
+int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64_t n_submits = 1);
 
 // A list of which a part is K1's: K1 stages the SAME tiles, 64 slots of 16 x ceil(len / 16) bytes per wave next to its closed-form tables.  Does that fit the
 // CU's LDS for every such k on its own (run_batch splits a fused group that does not fit; a single k has to)?  Equal-length reads beyond ~2.4 kb do not:
@@ -808,7 +824,7 @@ int run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uin
 
 // K1h + K1f over up to kK1hSegs tiled batches of different geometry in ONE launch per k (launch_sketch_k1h_multi): the length bins of a ragged read set
 // share the launch's workgroups in proportion to their blocks instead of queueing as small launches, each of which would pay the waves' start-up again
-int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
+int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64_t n_submits) // n_submits: the caller's submits these batches came in (ntc_kernel_time's launch count)
 {
 	std::vector<TiledSeg> segs;
 	for (uint32_t i = 0; i < n_in; ++i)
@@ -919,7 +935,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			if (int rc = join_k1f(e)) return rc;
 		if (int rc = open_run()) return rc;
 		if (e->profiling && !counted) {
-			++e->run_submits;
+			e->run_submits += n_submits;
 			counted = true;
 		}
 		// the launch's geometry: workgroups and blocks per wave of every batch
@@ -942,10 +958,11 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 			// blocks of a wave (plan_sketch_k1h: even shares of a workgroup's quota) + 1, all of
 			// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
 			// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
-			// 2 GiB per set (beyond that a launch may still overflow: slow path, exact).
+			// 1 GiB per launch (beyond that a launch may still overflow: slow path, exact).  Round 6: the batches of ONE launch share one list — a wave's region is
+			// its number in the launch, and every batch is walked by waves of its own — so a launch over eight batches needs one list, not eight.
 			const double lone_blocks = (double)planned[i].blocks_per_wave + 1.0;
 			const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
-			sus_cap = std::max(sus_cap, (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 31) / 16u / max_waves)));
+			sus_cap = std::max(sus_cap, (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 30) / 16u / max_waves)));
 		}
 		if (const char* ev = std::getenv("NTC_K1H_SUS_CAP")) { // tests: a short list forces the overflow path
 			const long v = std::strtol(ev, nullptr, 10);
@@ -953,8 +970,8 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 		}
 		// the hand-over arrays of one set; an engine that defers K1f sizes ALL its sets at the first launch of a batch geometry (a set that grows
 		// later would stall the stream in the middle of a run)
-		auto ensure_set = [&](ntc_engine::K1hSet& s2) -> int {
-			if (need_d > s2.dirty_cap || need_t > s2.tie_cap || sus_cap > s2.sus_cap) HIP_TRY(hipStreamSynchronize(e->stream));
+		auto ensure_set = [&](ntc_engine::K1hSet& s2, bool with_sus) -> int { // with_sus: the first set of a launch holds the launch's suspect list
+			if (need_d > s2.dirty_cap || need_t > s2.tie_cap || (with_sus && sus_cap > s2.sus_cap)) HIP_TRY(hipStreamSynchronize(e->stream));
 			if (need_d > s2.dirty_cap || need_t > s2.tie_cap) {
 				if (s2.d_dirty) (void)hipFree(s2.d_dirty);
 				if (s2.d_tie) (void)hipFree(s2.d_tie);
@@ -965,7 +982,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 				s2.dirty_cap = need_d;
 				s2.tie_cap = need_t;
 			}
-			if (sus_cap > s2.sus_cap) {
+			if (with_sus && sus_cap > s2.sus_cap) {
 				if (s2.d_sus) (void)hipFree(s2.d_sus);
 				s2.d_sus = nullptr;
 				s2.sus_cap = 0;
@@ -984,13 +1001,13 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 		bool grow = false;
 		for (uint32_t i = 0; i < na; ++i) {
 			const auto& ks = e->k1h_set[e->k1f_n + i];
-			grow |= need_d > ks.dirty_cap || need_t > ks.tie_cap || sus_cap > ks.sus_cap || !ks.d_sus_count;
+			grow |= need_d > ks.dirty_cap || need_t > ks.tie_cap || (i == 0 && sus_cap > ks.sus_cap) || !ks.d_sus_count;
 		}
 		if (grow) {
 			if (e->k1f_n != 0) // the sets ahead are in use by launches whose K1f is still to come
 				if (int rc = join_k1f(e)) return rc;
 			for (uint32_t si = 0; si < (e->defer_redo ? ntc::kK1fBatch : na); ++si)
-				if (int rc = ensure_set(e->k1h_set[si])) {
+				if (int rc = ensure_set(e->k1h_set[si], si == 0 || na == 1)) { // (launches of one batch each — K1's share of a list, single submits — may start at any set)
 					// no memory for K1h's hand-over arrays (8 sets with NTC_FLAG_DEFER_REDO: up to ~0.5 GB each per 10 M reads): the
 					// batches are K1's, unless the caller insists on the tiled kernels or part of the k list has been launched already
 					if (e->ts_required || launched_any || any_tails) return rc;
@@ -1003,8 +1020,8 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 		for (uint32_t i = 0; i < na; ++i) {
 			auto& ks0 = e->k1h_set[e->k1f_n + i]; // (k1f_n may be 0 now)
 			ntc::K1hArgs& h = hs[i];
-			h.sus = ks0.d_sus;
-			h.sus_count = ks0.d_sus_count;
+			h.sus = e->k1h_set[e->k1f_n].d_sus; // (the launch's list: that of its first set)
+			h.sus_count = e->k1h_set[e->k1f_n].d_sus_count;
 			h.sus_cap = sus_cap; // (<= the allocation's)
 			h.launch_id = ++e->k1h_launch_id;
 			if (h.launch_id == 0) h.launch_id = ++e->k1h_launch_id;
@@ -1052,6 +1069,29 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in)
 	if (!e->ts_all) // the k of the list K1h is not built for: K1 over the same tiles (staged straight from the tiled layout)
 		for (const auto& sg : segs)
 			if (int rc = run_batch(e, sg.d_tiles, nullptr, sg.n_reads, sg.read_len, 16u * ((sg.read_len + 15u) / 16u), true, &e->k_tiled)) return rc;
+	return 0;
+}
+
+int flush_deferred(ntc_engine* e)
+{
+	if (e->deferred.empty() || e->in_flush) return 0;
+	e->in_flush = true; // (run_tiled_segs calls join_k1f itself when it runs out of hand-over sets)
+	std::vector<TiledSeg> segs;
+	segs.reserve(e->deferred.size());
+	for (const auto& d : e->deferred)
+		segs.push_back(TiledSeg{d.d_tiles, d.n_reads, d.read_len, d.d_tails});
+	e->deferred.clear();
+	const int rc = run_tiled_segs(e, segs.data(), (uint32_t)segs.size(), segs.size());
+	e->in_flush = false;
+	return rc;
+}
+
+// a device-resident tiled batch under NTC_FLAG_DEFER_REDO, every k K1h's: it waits for up to seven more (one K1h launch per k over all of them)
+int defer_or_run_tiled(ntc_engine* e, const unsigned char* d_tiles, uint64_t n_reads, uint32_t read_len, const uint32_t* d_tails)
+{
+	if (!(e->defer_redo && e->ts_all)) return run_tiled(e, d_tiles, n_reads, read_len, d_tails);
+	e->deferred.push_back(ntc_engine::DeferredSeg{d_tiles, n_reads, read_len, d_tails});
+	if (e->deferred.size() >= std::min<size_t>(ntc::kK1hSegs, ntc::kK1fBatch)) return flush_deferred(e);
 	return 0;
 }
 
@@ -1338,7 +1378,7 @@ int ntc_submit_tiled_device(ntc_engine* e, const void* d_tiles, uint64_t n_reads
 	if (read_len == 0 || read_len > 0xffffu) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: read_len %u outside 1..65535", read_len);
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	return run_tiled(e, (const unsigned char*)d_tiles, n_reads, read_len);
+	return defer_or_run_tiled(e, (const unsigned char*)d_tiles, n_reads, read_len, nullptr);
 }
 
 int ntc_submit_tiled_ragged_device(ntc_engine* e, const void* d_tiles, uint64_t n_reads, uint32_t n_chunks, const uint32_t* d_tails)
@@ -1349,7 +1389,7 @@ int ntc_submit_tiled_ragged_device(ntc_engine* e, const void* d_tiles, uint64_t 
 	if (n_chunks == 0 || n_chunks > 0xffffu / 16u) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: n_chunks %u outside 1..4095", n_chunks);
 	std::lock_guard<std::mutex> lk(e->mu);
 	HIP_TRY(hipSetDevice(e->device));
-	return run_tiled(e, (const unsigned char*)d_tiles, n_reads, 16u * n_chunks, d_tails);
+	return defer_or_run_tiled(e, (const unsigned char*)d_tiles, n_reads, 16u * n_chunks, d_tails);
 }
 
 int ntc_submit_tiled_bins_device(ntc_engine* e, uint32_t n_bins, const void* const* d_tiles, const uint64_t* n_reads, const uint32_t* read_len,

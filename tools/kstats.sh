@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for n in "$@"; do
   if [ "$n" = cur ]; then L=""; else L="--lib $ROOT/tools/lib_$n.so"; fi
   rm -rf /tmp/ks_$n
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$n -o t -- python $ROOT/bench.py --no-cpu-baseline --no-live-pmc --no-nodefer --steps 20 --warmup 5 --repeats ${KS_REPEATS:-3} $L ${KS_ARGS:-} > $OUT/$n.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$n -o t -- python $ROOT/bench.py --no-cpu-baseline --no-live-pmc ${KS_NODEFER:---no-nodefer} --steps 20 --warmup 5 --repeats ${KS_REPEATS:-3} $L ${KS_ARGS:-} > $OUT/$n.log 2>&1
   f=$(find /tmp/ks_$n -name '*kernel_stats.csv' | head -1)
   cp "$f" $OUT/${n}_kernel_stats.csv
   echo "== $n"; python - "$f" <<'PY'
