@@ -96,6 +96,32 @@ def test_gpu_large_device_batch_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_gpu_fullsize_matches_the_reference():
+    """BASELINE config 5 names nthll too: 100 M synthetic 150 bp reads (the device generator's stream) against the register file and the printed line of the
+    REAL reference (oracle/_ref/ref_hll_tool fullsize = nthll.cpp's ntRead over the same stream: tools/make_fullsize_digests.py hll)"""
+    import hashlib
+    import json
+    import torch
+    import ntcard_amd as nt
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize")
+    with open(os.path.join(gold, "digests.json")) as f:
+        meta = json.load(f)
+    c = meta["configs"]["hll"]
+    n, L, stride, R = meta["n_reads"], meta["read_len"], 152, 10_000_000
+    d = torch.empty(R * stride + 16, dtype=torch.uint8, device="cuda")
+    with nt.HllEngine(c["k"], c["n_bits"]) as e:
+        for first in range(0, n, R):
+            m = min(R, n - first)
+            nt.gen_reads_device(d.data_ptr(), meta["seed"], first, m, L, stride, c["dist"], genome_len=100_000_000)
+            e.submit_device(d.data_ptr(), m, L, stride)
+        regs, f1 = e.finish()
+    want = np.fromfile(os.path.join(gold, c["regs_file"]), dtype=np.uint8)
+    assert hashlib.sha1(want.tobytes()).hexdigest() == c["regs_sha1"]
+    assert np.array_equal(regs, want)
+    assert "F0, Exp# of distnt kmers(k=%d): %d\n" % (c["k"], int(nt.hll_estimate(regs, c["n_bits"]))) == c["line"]
+
+
+@pytest.mark.gpu
 def test_nthll_cli_prints_the_reference_line(tmp_path):
     _, fq = small_reads()
     (tmp_path / "reads.fq").write_bytes(fq)

@@ -73,6 +73,14 @@ def main():
                 os.remove(f"{prefix}_k{k}.tcounter")
             meta["configs"][name] = ent
             print(name, json.dumps(ent["planes"]))
+        # BASELINE config 5 names nthll as well: the reference's nthll ntRead (nthll.cpp:92-105) over the same stream -> its register file and the line its main prints
+        if not only or "hll" in only:
+            hll_tool = os.path.join(ROOT, "oracle", "_ref", "ref_hll_tool")
+            regs_path = os.path.join(OUT, "hll_k32_b16.regs")
+            line = subprocess.run([hll_tool, "fullsize", "1", str(n), "150", "1", "32", "16", str(threads), regs_path], stdout=subprocess.PIPE, check=True).stdout.decode()
+            meta["configs"]["hll"] = {"dist": 1, "k": 32, "n_bits": 16, "regs_file": "hll_k32_b16.regs", "regs_sha1": sha1_file(regs_path), "line": line,
+                                      "made_by": "oracle/_ref/ref_hll_tool fullsize (the reference's nthll ntRead + the estimate of its main)"}
+            print("hll", json.dumps(meta["configs"]["hll"]))
     with open(os.path.join(OUT, "digests.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
