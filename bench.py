@@ -70,6 +70,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu():
+    """model string, sockets and PHYSICAL cores of the host from /proc/cpuinfo (`cores` in cpu_baseline is the number of threads used = logical CPUs)"""
+    model, phys = None, set()
+    cur = {}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().splitlines() + [""]:
+                if not line.strip():
+                    if cur:
+                        phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor", "0"))))
+                        model = model or cur.get("model name")
+                    cur = {}
+                    continue
+                k, _, v = line.partition(":")
+                cur[k.strip()] = v.strip()
+    except OSError:
+        pass
+    return {"model": model, "physical_cores": len(phys) or None, "sockets": len({p for p, _ in phys}) or None}
+
+
 def cpu_baseline(args, nt_stride):
     """The reference's own ntRead/stRead on this box's host cores (kind "reference": oracle/_ref/ref_tool, the real
     ntcard.cpp compiled where it lies, built in the build container and shipped with the snapshot), one thread per
@@ -78,6 +98,7 @@ def cpu_baseline(args, nt_stride):
     reference's speed per thread in the build container).  Reported, never the target."""
     import subprocess
     cores = os.cpu_count() or 1
+    host = host_cpu()
     n = args.cpu_sample_reads or min(4_000_000, 250_000 * cores)
     dist = 1 if args.dist == "g" else 0
     kl = klist_of(args)
@@ -86,7 +107,8 @@ def cpu_baseline(args, nt_stride):
         cmd = [tool, "bench", str(args.seed), "0", str(n), str(args.read_len), str(dist), ",".join(map(str, kl)), str(args.gap),
                str(args.r_bits), str(args.s_bits), str(cores), "10"]
         j = json.loads(subprocess.run(cmd, stdout=subprocess.PIPE, check=True, timeout=600).stdout.decode().strip().splitlines()[-1])
-        return {"value": j["kmers"] / j["seconds"], "unit": "k-mers/s", "cores": cores, "kind": "reference",
+        return {"value": j["kmers"] / j["seconds"], "unit": "k-mers/s", "cores": cores, "cpu_model": host["model"], "physical_cores": host["physical_cores"],
+                "sockets": host["sockets"], "kind": "reference",
                 "sample": f"{j['chunks']} x {n} reads x {args.read_len} bp (same generator, dist={args.dist}), k={kl}, gap={args.gap}, "
                           f"the reference's ntRead/stRead (ntcard.cpp compiled from /root/reference by oracle/Makefile), one thread per "
                           f"shard, shared t_Counter with omp atomic, {j['seconds']:.2f} s timed"}
@@ -112,7 +134,8 @@ def cpu_baseline(args, nt_stride):
         dt += time.perf_counter() - t0
         total_f1 += int(sum(int(x) for x in f1))
         chunks += 1
-    return {"value": float(total_f1) / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
+    return {"value": float(total_f1) / dt, "unit": "k-mers/s", "cores": cores, "cpu_model": host["model"], "physical_cores": host["physical_cores"],
+            "sockets": host["sockets"], "kind": "port",
             "sample": f"{chunks} x {n} reads x {args.read_len} bp (same generator, dist={args.dist}), k={kl}, gap={args.gap}, "
                       f"oracle port of ntRead+ntComp (per-k tables, one thread per shard; 1.40 x the reference's per-thread speed in "
                       f"the build container), {dt:.2f} s timed"}

@@ -47,7 +47,7 @@ def main():
             if "sketch_" in r["Name"] or "k1h_" in r["Name"]:
                 lines.append("   -> %s: %d dispatches over %d bench steps (%d warm-up + %d x %d timed) = %.4f ms per step" %
                              (r["Name"][:48], int(r["Calls"]), n_trace, bench["warmup"], bench.get("repeats", 1), bench["steps"], float(r["TotalDurationNs"]) / n_trace / 1e6))
-    hash_kernels = {}
+    hash_kernels, apply_kernels = {}, {}
     for k, v in agg.items():
         if any(t in k for t in ("sketch_", "k1h_", "split_kernel", "count_kernel", "finalize")):
             lines.append(f"== counters (separate --pmc passes), mean per dispatch | per bench step: {k}")
@@ -56,17 +56,25 @@ def main():
                 lines.append("  %-28s %18.1f  n=%d | %s" % (c, sum(vals) / len(vals), len(vals), per_step))
             if "sketch_" in k or "k1h_" in k:
                 hash_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
+            elif any(t in k for t in ("split_kernel", "count_kernel", "log_")):
+                apply_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
     open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
-    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) of the hash kernels per bench step (K1h + K1f, or K1)
+    # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) per bench step of the hash kernels (K1h + K1f, or K1) AND of the sketch-update kernels (split / count /
+    # log_*), which is what bench.py's live passes report as roofline.traffic (round 6: the table used to hold the hash kernels' share only)
     if bench and hash_kernels:
-        fetch = sum(v.get("FETCH_SIZE", 0.0) for v in hash_kernels.values())
-        write = sum(v.get("WRITE_SIZE", 0.0) for v in hash_kernels.values())
+        allk = list(hash_kernels.values()) + list(apply_kernels.values())
+        fetch = sum(v.get("FETCH_SIZE", 0.0) for v in allk)
+        write = sum(v.get("WRITE_SIZE", 0.0) for v in allk)
+        fetch_h = sum(v.get("FETCH_SIZE", 0.0) for v in hash_kernels.values())
+        write_h = sum(v.get("WRITE_SIZE", 0.0) for v in hash_kernels.values())
         key = bench["config"]["traffic_key"]
         tj = os.path.join(ROOT, "profiles", "traffic_pmc.json")
         table = json.load(open(tj))
         table[key] = {"fetch_kb": fetch, "write_kb": write, "traffic_bytes": int((2 * fetch + write) * 1024),
+                      "traffic_bytes_hash": int((2 * fetch_h + write_h) * 1024),
                       "source": f"profiles/{rnd}_{tag}/summary.txt",
-                      "valu_insts_per_launch": sum(v.get("SQ_INSTS_VALU", 0.0) for v in hash_kernels.values())}
+                      "valu_insts_per_launch": sum(v.get("SQ_INSTS_VALU", 0.0) for v in allk),
+                      "valu_insts_per_launch_hash": sum(v.get("SQ_INSTS_VALU", 0.0) for v in hash_kernels.values())}
         json.dump(table, open(tj, "w"), indent=1)
         print("traffic entry", key, table[key])
     print("wrote", dst)
