@@ -65,6 +65,10 @@ def parse():
                          "(ntc_submit_tiled_device: K1h + K1f); auto = tiled where K1h is built "
                          "for the configuration (every k of the list within 12..32, no gap, sBits >= 7), rows otherwise (a tiled batch would only be re-laid out)")
     ap.add_argument("--log-entries", type=int, default=0, help="capacity of the hit log in entries (0 = the engine's default: one per counter)")
+    ap.add_argument("--merge", choices=["auto", "slices", "owner"], default="auto",
+                    help="multi-GPU merge: slices = all-to-all of 16-bit counter slices (parallel.merge_to_value_histograms); owner = ship the sampled k-mers "
+                         "to the rank that owns their counter range (parallel.merge_owner_engine; falls back to slices when a sketch update ran during the "
+                         "steps); auto = owner for sBits >= 11 (fewer hits than counter bytes: BASELINE config 3), slices otherwise")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this build of libntcard_hip.so instead of the in-tree one")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
     return ap.parse_args()
@@ -380,13 +384,20 @@ def main():
         t0 = time.perf_counter()
         for s in range(K):
             submit_to(e, batches[s % nb])
-        e.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter
         merged, merge_t = None, {}
-        if use_dist:
+        if use_dist and merge_mode == "owner":
+            # the merge that ships hits (round 6): the pending log split by counter-range owner, one variable-size all-to-all, every rank counts the keys of
+            # ITS range with the engine's own sketch update, histograms to rank 0.  None: some rank's sketch already holds counts -> counters are merged
+            res = parallel.merge_owner_engine(e, sketch, f1_dev, nk, args.r_bits, dst=0, timings=merge_t)
+            if res is not None:
+                merged = res[0]
+        e.flush()  # the sketch is final on the device inside the timed region: pending hit log -> t_Counter (owner mode: done above, nothing pending)
+        if use_dist and merged is None:
             # the path's one exchange step: all-to-all of the 16-bit counter slices, wrapping local sums, per-rank value
             # histograms of the summed slices, histograms to rank 0 (what compEst consumes) — parallel.merge_to_value_histograms; narrowing,
             # sums and histograms are the library's kernels (ntc_narrow_u16_device / ntc_sum_slices_u16_device / ntc_value_hist_u16_device)
             merged, _ = parallel.merge_to_value_histograms(sketch, f1_dev, nk, args.r_bits, dst=0, timings=merge_t)
+            merge_t["mode"] = "slices"
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -397,6 +408,7 @@ def main():
         return {"dt": float(tmax.item()), "ker_ms": ker, "launches": launches, "apply_ms": app, "applies": applies, "fix_ms": e.fixup_time(),
                 "merged": merged, "merge_t": merge_t}
 
+    merge_mode = args.merge if args.merge != "auto" else ("owner" if args.s_bits >= 11 else "slices")
     sclk_before = read_sclk_mhz(local_rank) if rank == 0 else None
     warm(eng)
     n_rep = max(1, args.repeats)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NTC_ABI_VERSION 5
+#define NTC_ABI_VERSION 6
 #define NTC_MAX_K_LIST 32
 
 typedef enum {
@@ -188,6 +188,22 @@ int ntc_value_hist_device(int32_t device, void *stream, const void *d_counters_u
 int ntc_narrow_u16_device(int32_t device, void *stream, const void *d_counters_u32, uint64_t n, void *d_out_u16);
 int ntc_sum_slices_u16_device(int32_t device, void *stream, void *d_slices_u16, uint64_t stride, uint32_t n_slices, uint64_t len);
 int ntc_value_hist_u16_device(int32_t device, void *stream, const void *d_counters_u16, uint64_t n, void *d_hist_u32);
+
+/* The multi-GPU merge that ships HITS instead of counters (ABI 6) — for runs whose sampled k-mers are fewer than their counters' bytes, i.e. the reference's
+ * sBits = 11 branch (inputs >= 50 GB, ntcard.cpp:427-431; BASELINE config 3: 125 M reads per GPU log 14.5 M keys = 58 MB where the 16-bit slice exchange
+ * moves 448 MiB per rank).  Counter range p of n_parts ("owner" p) = the counters [p * C / n_parts, (p + 1) * C / n_parts), C = n_k * 2 * 2^r_bits.
+ *   ntc_log_export_device   the PENDING hit log (everything counted since the last sketch update: the operands of ntComp's `++t_Counter[...]`,
+ *                           ntcard.cpp:142-143) split by owner.  counts_out[p] (host) = the keys of owner p; with d_keys_u32 != NULL they are written, 32-bit
+ *                           counter indices in arbitrary order, to d_keys_u32[part_offset[p] .. part_offset[p] + counts_out[p]) (part_offset: host, n_parts
+ *                           entries; call once with d_keys_u32 == NULL to learn the counts).  Synchronises the engine's stream.  The log stays pending.
+ *                           NTC_ERR_STATE when the sketch already holds counts (an update ran since the last reset, or a kernel incremented it directly) or
+ *                           the engine has no hit log: the caller then merges counters (ntc_narrow_u16_device ...), which is always possible.
+ *   ntc_log_replace_device  drops the pending log and makes the n_keys counter indices at d_keys_u32 (device) the pending log instead: the next
+ *                           ntc_flush / ntc_finish counts exactly them.  An owner calls it with the keys it received for its range (its own included):
+ *                           its sketch then holds the SUMMED counters of its range (and zeros elsewhere), to be histogrammed with ntc_value_hist_device.
+ * ntcard_amd/parallel.py (merge_owner) runs the exchange between the two calls with one RCCL all-to-all.                                              */
+int ntc_log_export_device(ntc_engine *e, uint32_t n_parts, void *d_keys_u32, const uint64_t *part_offset, uint64_t *counts_out);
+int ntc_log_replace_device(ntc_engine *e, const void *d_keys_u32, uint64_t n_keys);
 
 /* Sketch load / merge: adds a t_Counter image dumped by ntc_finish (same k list, r_bits;
  * uint16 [n_k][2][1<<r_bits]) and its F1 values (may be NULL) into this engine.  Counting is a commutative sum

@@ -17,6 +17,7 @@ ABI_SYMBOLS = [
     "ntc_kernel_time", "ntc_apply_time", "ntc_fixup_time", "ntc_merge_allocations", "ntc_update_mode", "ntc_flush", "ntc_set_profiling", "ntc_merge_counters", "ntc_merge_devices", "ntc_value_hist_device", "ntc_hll_create", "ntc_hll_finish", "ntc_hll_estimate",
     "ntc_submit_tiled_device", "ntc_submit_tiled_ragged_device", "ntc_submit_tiled_bins_device", "ntc_tiled_bytes", "ntc_gen_reads_tiled_device",
     "ntc_narrow_u16_device", "ntc_sum_slices_u16_device", "ntc_value_hist_u16_device",
+    "ntc_log_export_device", "ntc_log_replace_device",
 ]
 
 
@@ -86,6 +87,8 @@ def lib():
     L.ntc_sum_slices_u16_device.argtypes = [i32, p, p, u64, u32, u64]
     L.ntc_value_hist_u16_device.argtypes = [i32, p, p, u64, p]
     L.ntc_device_state.argtypes = [p, C.POINTER(p), C.POINTER(u64), C.POINTER(p)]
+    L.ntc_log_export_device.argtypes = [p, u32, p, C.POINTER(u64), C.POINTER(u64)]
+    L.ntc_log_replace_device.argtypes = [p, p, u64]
     L.ntc_hash_dump_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_hash_dump_k1_device.argtypes = [i32, p, p, u64, u32, u32, u32, u32, u32, p, p]
     L.ntc_gen_reads_device.argtypes = [i32, p, p, u64, u64, u64, u32, u32, u32, u64]

@@ -364,6 +364,65 @@ hipError_t launch_log_atomics(const uint32_t* log, uint32_t* fill, uint32_t regi
 	return hipGetLastError();
 }
 
+// ntc_log_export_device: the keys of a region counted per owner in LDS, ONE cursor atomic per owner and region, then placed by a second LDS count
+// (the region is read twice; the second time from L2)
+__global__ __launch_bounds__(256) void log_export_kernel(const uint32_t* __restrict__ log, const uint32_t* __restrict__ fill, uint32_t region_cap, uint32_t n_regions,
+                                                         uint32_t n_parts, uint32_t keys_per_part, uint32_t* __restrict__ out,
+                                                         const unsigned long long* __restrict__ part_off, unsigned long long* __restrict__ cursor)
+{
+	__shared__ uint32_t cnt[64];
+	__shared__ unsigned long long base[64];
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+		uint32_t n = fill[r];
+		n = n < region_cap ? n : region_cap;
+		if (n == 0) continue; // (the same for every thread)
+		const uint32_t* src = log + (uint64_t)r * region_cap;
+		if (tid < 64) cnt[tid] = 0;
+		__syncthreads();
+		for (uint32_t i = tid; i < n; i += 256u) {
+			const uint32_t o = src[i] / keys_per_part;
+			atomicAdd(&cnt[o < n_parts ? o : n_parts - 1u], 1u);
+		}
+		__syncthreads();
+		if (tid < n_parts) {
+			base[tid] = cnt[tid] ? atomicAdd(&cursor[tid], (unsigned long long)cnt[tid]) : 0ull;
+			cnt[tid] = 0;
+		}
+		__syncthreads();
+		if (out != nullptr)
+			for (uint32_t i = tid; i < n; i += 256u) {
+				const uint32_t key = src[i];
+				uint32_t o = key / keys_per_part;
+				o = o < n_parts ? o : n_parts - 1u;
+				out[part_off[o] + base[o] + atomicAdd(&cnt[o], 1u)] = key;
+			}
+		__syncthreads();
+	}
+}
+
+hipError_t launch_log_export(const uint32_t* log, const uint32_t* fill, uint32_t region_cap, uint32_t n_regions, uint32_t n_parts, uint32_t keys_per_part,
+                             uint32_t* out, const unsigned long long* part_off, unsigned long long* cursor, hipStream_t st)
+{
+	hipLaunchKernelGGL(log_export_kernel, dim3(n_regions < 2048u ? n_regions : 2048u), dim3(256), 0, st, log, fill, region_cap, n_regions, n_parts, keys_per_part, out,
+	                   part_off, cursor);
+	return hipGetLastError();
+}
+
+__global__ void log_set_fill_kernel(uint32_t* __restrict__ fill, uint32_t n_regions, uint32_t region_cap, unsigned long long n_keys)
+{
+	for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_regions; r += gridDim.x * blockDim.x) {
+		const unsigned long long lo = (unsigned long long)r * region_cap;
+		fill[r] = n_keys <= lo ? 0u : (n_keys - lo < region_cap ? (uint32_t)(n_keys - lo) : region_cap);
+	}
+}
+
+hipError_t launch_log_set_fill(uint32_t* fill, uint32_t n_regions, uint32_t region_cap, unsigned long long n_keys, hipStream_t st)
+{
+	hipLaunchKernelGGL(log_set_fill_kernel, dim3((n_regions + 255u) / 256u), dim3(256), 0, st, fill, n_regions, region_cap, n_keys);
+	return hipGetLastError();
+}
+
 hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st)
 {
 	static_assert(kSplitKeysMax == 8, "two instantiations");

@@ -2141,6 +2141,61 @@ int ntc_merge_devices(ntc_engine* const* engines, int32_t n_engines)
 	return 0;
 }
 
+int ntc_log_export_device(ntc_engine* e, uint32_t n_parts, void* d_keys_u32, const uint64_t* part_offset, uint64_t* counts_out)
+{
+	if (!e || !counts_out) return fail(NTC_ERR_ARG, "ntc_log_export_device: null argument");
+	if (n_parts < 1 || n_parts > 64) return fail(NTC_ERR_ARG, "ntc_log_export_device: n_parts %u outside 1..64", n_parts);
+	if (d_keys_u32 && !part_offset) return fail(NTC_ERR_ARG, "ntc_log_export_device: keys without part offsets");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	if (!e->d_log || e->hll_bits) return fail(NTC_ERR_STATE, "ntc_log_export_device: this engine has no hit log");
+	const uint64_t counters = e->klist.size() * e->plane_elems();
+	if (counters % n_parts) return fail(NTC_ERR_ARG, "ntc_log_export_device: %u parts do not divide %llu counters", n_parts, (unsigned long long)counters);
+	if (int rc = join_k1f(e)) return rc; // (K1f's suspects are log entries too)
+	// the sketch must still hold the zeros of the last reset: everything counted so far is in the log
+	uint32_t dirty = 0;
+	HIP_TRY(hipMemcpyAsync(&dirty, e->d_skdirty, 4, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (e->sk_host_dirty || dirty != 0u)
+		return fail(NTC_ERR_STATE, "ntc_log_export_device: the sketch already holds counts (a sketch update ran, or a kernel incremented it directly): merge counters instead");
+	unsigned long long *d_cursor = nullptr, *d_off = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_cursor, 2 * 64 * 8));
+	d_off = d_cursor + 64;
+	unsigned long long h_off[64] = {0};
+	if (part_offset)
+		for (uint32_t p = 0; p < n_parts; ++p)
+			h_off[p] = part_offset[p];
+	hipError_t rc = hipMemsetAsync(d_cursor, 0, 64 * 8, e->stream);
+	if (rc == hipSuccess) rc = hipMemcpyAsync(d_off, h_off, 64 * 8, hipMemcpyHostToDevice, e->stream);
+	if (rc == hipSuccess)
+		rc = ntc::launch_log_export(e->d_log, e->d_logfill, e->log_region_cap, e->all_log_regions(), n_parts, (uint32_t)(counters / n_parts), (uint32_t*)d_keys_u32, d_off,
+		                            d_cursor, e->stream);
+	unsigned long long h_cnt[64] = {0};
+	if (rc == hipSuccess) rc = hipMemcpyAsync(h_cnt, d_cursor, 64 * 8, hipMemcpyDeviceToHost, e->stream);
+	if (rc == hipSuccess) rc = hipStreamSynchronize(e->stream);
+	(void)hipFree(d_cursor);
+	if (rc != hipSuccess) return fail(NTC_ERR_DEVICE, "ntc_log_export_device: %s", hipGetErrorString(rc));
+	for (uint32_t p = 0; p < n_parts; ++p)
+		counts_out[p] = h_cnt[p];
+	return 0;
+}
+
+int ntc_log_replace_device(ntc_engine* e, const void* d_keys_u32, uint64_t n_keys)
+{
+	if (!e || (!d_keys_u32 && n_keys)) return fail(NTC_ERR_ARG, "ntc_log_replace_device: null argument");
+	std::lock_guard<std::mutex> lk(e->mu);
+	HIP_TRY(hipSetDevice(e->device));
+	if (!e->d_log || e->hll_bits) return fail(NTC_ERR_STATE, "ntc_log_replace_device: this engine has no hit log");
+	const uint64_t room = (uint64_t)e->all_log_regions() * e->log_region_cap;
+	if (n_keys > room) return fail(NTC_ERR_ARG, "ntc_log_replace_device: %llu keys do not fit the %llu-entry log", (unsigned long long)n_keys, (unsigned long long)room);
+	if (int rc = join_k1f(e)) return rc; // (nothing may append behind this point)
+	if (n_keys) HIP_TRY(hipMemcpyAsync(e->d_log, d_keys_u32, n_keys * 4, hipMemcpyDeviceToDevice, e->stream));
+	HIP_TRY(ntc::launch_log_set_fill(e->d_logfill, e->all_log_regions(), e->log_region_cap, n_keys, e->stream));
+	e->log_pending = n_keys != 0;
+	e->log_est = (double)n_keys;
+	return 0;
+}
+
 int ntc_device_state(ntc_engine* e, void** d_sketch_u32, uint64_t* n_counters, void** d_f1_u64)
 {
 	if (!e) return fail(NTC_ERR_ARG, "ntc_device_state: null engine");

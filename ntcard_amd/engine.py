@@ -146,6 +146,18 @@ class Engine:
         check(self._lib.ntc_device_state(self._h, C.byref(sk), C.byref(n), C.byref(f1)))
         return sk.value, n.value, f1.value
 
+    def log_export(self, n_parts, d_keys_ptr=None, part_offset=None):
+        """the pending hit log split by counter-range owner (include/ntcard_hip.h: ntc_log_export_device) -> counts per owner (list of int); with d_keys_ptr
+        (device uint32 buffer) and part_offset (n_parts ints) the keys are written as well.  NtcError(NTC_ERR_STATE) when the sketch already holds counts."""
+        counts = (C.c_uint64 * n_parts)()
+        offs = (C.c_uint64 * n_parts)(*[int(x) for x in part_offset]) if part_offset is not None else None
+        check(self._lib.ntc_log_export_device(self._h, n_parts, C.c_void_p(d_keys_ptr) if d_keys_ptr else None, offs, counts))
+        return [int(c) for c in counts]
+
+    def log_replace(self, d_keys_ptr, n_keys):
+        """the n_keys counter indices at d_keys_ptr (device uint32) become the pending hit log (ntc_log_replace_device)"""
+        check(self._lib.ntc_log_replace_device(self._h, C.c_void_p(d_keys_ptr) if n_keys else None, n_keys))
+
     def set_profiling(self, on=True):
         check(self._lib.ntc_set_profiling(self._h, 1 if on else 0))
 

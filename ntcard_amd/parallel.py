@@ -169,6 +169,122 @@ def merge_to_value_histograms(sketch, f1, n_k, r_bits, value_hist=None, dst=0, t
     return hist.view(n_k, 2, 65536), f1
 
 
+def exchange_keys(send, send_counts):
+    """One variable-size all-to-all of hit-log keys: `send` (int32, the counter indices of this rank's sampled k-mers grouped by owner: owner p's
+    send_counts[p] keys follow owner p - 1's) -> (recv, recv_counts): what every rank holds for THIS rank's counter range, rank by rank.
+    RCCL: all_gather of the counts + all_to_all_single with split sizes; gloo (CPU tests): the same as batched isend / irecv."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sc = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=send.device)
+    table = [torch.empty_like(sc) for _ in range(world)]
+    dist.all_gather(table, sc)
+    recv_counts = [int(t[rank]) for t in table]  # (one small device-to-host copy per peer: the sizes of the receive buffer)
+    recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
+    soff = [0]
+    for c in send_counts:
+        soff.append(soff[-1] + int(c))
+    roff = [0]
+    for c in recv_counts:
+        roff.append(roff[-1] + c)
+    if dist.get_backend() == "gloo":
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                recv[roff[rank]:roff[rank + 1]] = send[soff[rank]:soff[rank + 1]]
+                continue
+            if soff[peer + 1] > soff[peer]:
+                ops.append(dist.P2POp(dist.isend, send[soff[peer]:soff[peer + 1]].contiguous(), peer))
+            if recv_counts[peer]:
+                ops.append(dist.P2POp(dist.irecv, recv[roff[peer]:roff[peer + 1]], peer))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+    else:
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=[int(c) for c in send_counts])
+    return recv, recv_counts
+
+
+def merge_owner(send, send_counts, count_keys, f1, n_k, r_bits, value_hist=None, dst=0, timings=None, ph=None):
+    """The merge that ships HITS instead of counters ("owner" mode, round 6): every rank owns the counter range
+    [rank * C / N, (rank + 1) * C / N) of the ONE merged sketch, receives every rank's sampled k-mers of that range (exchange_keys), counts them
+    (count_keys(recv) -> int32 tensor of the range's C / N counters; device: the engine's own sketch update over ntc_log_replace_device, CPU: bincount),
+    histograms its range and only the 256 KiB histograms and F1 travel to rank dst — as in merge_to_value_histograms, whose counter slices are what this
+    mode does not send.  Counting is a commutative sum (ntcard.cpp:142-143), so it is exact whichever rank counts a k-mer.  Pays when a run's hits are
+    fewer than its counters' bytes: the reference's sBits = 11 branch (BASELINE config 3: 58 MB of keys per rank against 448 MiB of 16-bit slices)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ph = ph or _Phases(send.device, timings is not None)
+    if not ph.marks:
+        ph.mark("start")
+    plane = 1 << r_bits
+    n = n_k * 2 * plane
+    assert n % world == 0
+    shard = n // world
+    recv, _ = exchange_keys(send, send_counts)
+    ph.mark("exchange")
+    mine = count_keys(recv)
+    assert mine.numel() == shard
+    ph.mark("count")
+    if value_hist is None:
+        if mine.is_cuda:
+            from . import engine as _eng
+            dev, st = _dev_args(mine)
+
+            def value_hist(c, h):
+                _eng.value_hist_device(c.data_ptr(), c.numel(), h.data_ptr(), device=dev, stream=st)
+        else:
+            def value_hist(c, h):
+                h += torch.bincount(c.to(torch.int64) & 0xFFFF, minlength=65536).to(torch.int32)
+    hist = torch.zeros(n_k * 2 * 65536, dtype=torch.int32, device=send.device)
+    pos, end = rank * shard, (rank + 1) * shard
+    while pos < end:  # a range may cover several (k, sample) planes, or a fraction of one
+        pl = pos // plane
+        stop = min((pl + 1) * plane, end)
+        value_hist(mine[pos - rank * shard:stop - rank * shard], hist[pl * 65536:(pl + 1) * 65536])
+        pos = stop
+    ph.mark("histogram")
+    dist.reduce(hist, dst=dst, op=dist.ReduceOp.SUM)
+    dist.reduce(f1, dst=dst, op=dist.ReduceOp.SUM)
+    ph.mark("reduce")
+    if timings is not None:
+        timings.update(ph.result())
+        timings["mode"] = "owner"
+        timings["keys_sent"] = int(sum(int(c) for c in send_counts))
+    return hist.view(n_k, 2, 65536), f1
+
+
+def merge_owner_engine(engine, sketch, f1, n_k, r_bits, dst=0, timings=None):
+    """merge_owner for an engine on this rank's GPU: the pending hit log is split by owner (ntc_log_export_device), exchanged, and the keys this rank receives
+    become its engine's pending log (ntc_log_replace_device) — the engine's own sketch update then counts them into `sketch` (the engine's ext_sketch).
+    -> (p_hist, f1), or None when some rank's sketch already holds counts (an update ran during the run, or direct atomics): every rank then returns None
+    and the caller merges counters (merge_to_value_histograms), which is always possible."""
+    from . import _abi
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ph = _Phases(sketch.device, timings is not None)
+    ph.mark("start")
+    try:
+        counts = engine.log_export(world)
+        ok = 1
+    except _abi.NtcError:
+        counts, ok = [0] * world, 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=sketch.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag[0]) == 0:
+        return None
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    send = torch.empty(max(offs[-1], 1), dtype=torch.int32, device=sketch.device)
+    engine.log_export(world, send.data_ptr(), offs[:-1])
+    send = send[:offs[-1]]
+    ph.mark("export")
+    shard = sketch.numel() // world
+
+    def count_keys(recv):
+        engine.log_replace(recv.data_ptr(), recv.numel())
+        engine.flush()
+        count_keys.keep = recv  # (until the stream has passed the copy)
+        return sketch[rank * shard:(rank + 1) * shard]
+    return merge_owner(send, counts, count_keys, f1, n_k, r_bits, dst=dst, timings=timings, ph=ph)
+
+
 def reduce_hll(regs, f1, dst=0):
     """in-place MAX reduce of nthll's register file (any integer tensor) and SUM of F1 to rank dst.
     The reference merges its per-thread register files the same way (nthll.cpp:240-245)."""

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/ntcard_hip.h but not exported"
     assert sorted(_abi.ABI_SYMBOLS) == declared
-    assert L.ntc_abi_version() == 5
+    assert L.ntc_abi_version() == 6
     assert L.ntc_max_k() >= 128
 
 

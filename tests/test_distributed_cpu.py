@@ -120,6 +120,72 @@ def test_value_histogram_merge(tmp_path, world):
     assert np.array_equal(np.load(tmp_path / "f1.npy").astype(np.uint64), of1)
 
 
+def _owner_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    klist = [21, 40]
+    first, n = parallel.split_reads(N, world)[rank]
+    slots = orc.gen_reads(3, first, n, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(n)]
+    counters, f1 = orc.sketch_reads(reads, klist, 0, RB, SB)
+    # this rank's hit log: every increment of its private sketch as one key (+ one counter hit 30000 times per rank: the merged value wraps past 65535;
+    # rank 1 has no hits at all for the last owner's range: an empty message)
+    c = counters.astype(np.int64).reshape(-1)
+    keys = np.repeat(np.arange(c.size, dtype=np.int64), c)
+    keys = np.concatenate([keys, np.full(30000, 5, dtype=np.int64)])
+    ncnt = c.size
+    shard = ncnt // world
+    if rank == 1:
+        keys = keys[keys < (world - 1) * shard]
+    rng = np.random.default_rng(rank)
+    rng.shuffle(keys)
+    owner = keys // shard
+    order = np.argsort(owner, kind="stable")
+    send = torch.from_numpy(keys[order].astype(np.int32))
+    send_counts = np.bincount(owner, minlength=world).tolist()
+
+    def count_keys(recv):
+        assert bool(((recv.to(torch.int64) // shard) == rank).all())
+        return torch.bincount(recv.to(torch.int64) - rank * shard, minlength=shard).to(torch.int32)
+    t = {}
+    ph, f1t = parallel.merge_owner(send, send_counts, count_keys, torch.from_numpy(f1.astype(np.int64)), len(klist), RB, dst=0, timings=t)
+    assert t["mode"] == "owner" and t["keys_sent"] == len(keys) and "exchange_ms" in t and "count_ms" in t
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ph.npy"), ph.numpy())
+        np.save(os.path.join(out_dir, "f1.npy"), f1t.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_owner_mode_merge(tmp_path, world):
+    """the merge that ships hits (round 6): keys by counter-range owner in one variable-size exchange, counted by the owner, histograms to rank 0 ==
+    the value histogram of the single-process sketch (incl. a counter that wraps past 65535 and an empty message)"""
+    klist = [21, 40]
+    mp.spawn(_owner_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    oc = np.zeros((len(klist), 2, 1 << RB), dtype=np.int64)
+    ncnt = oc.size
+    shard = ncnt // world
+    for rank in range(world):  # the sum of what the ranks logged (rank 1 dropped its hits of the last range)
+        first, n = parallel.split_reads(N, world)[rank]
+        slots = orc.gen_reads(3, first, n, L, L + 4, 1, genome_len=20_000)
+        reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(n)]
+        c, _ = orc.sketch_reads(reads, klist, 0, RB, SB)
+        c = c.astype(np.int64).reshape(-1)
+        if rank == 1:
+            c[(world - 1) * shard:] = 0
+        oc += c.reshape(oc.shape)
+    oc.reshape(-1)[5] += world * 30000
+    oc &= 0xFFFF
+    ph = np.load(tmp_path / "ph.npy")
+    for ki in range(len(klist)):
+        assert np.array_equal(ph[ki].astype(np.uint32), orc.value_hist(oc[ki].astype(np.uint16), RB))
+    slots = orc.gen_reads(3, 0, N, L, L + 4, 1, genome_len=20_000)
+    reads = [slots[i * (L + 4): i * (L + 4) + L].tobytes() for i in range(N)]
+    _, of1 = orc.sketch_reads(reads, klist, 0, RB, SB)
+    assert np.array_equal(np.load(tmp_path / "f1.npy").astype(np.uint64), of1)
+
+
 def test_split_reads_covers_everything():
     for n, w in ((10, 3), (100_000_000, 8), (7, 8)):
         parts = parallel.split_reads(n, w)

@@ -745,6 +745,70 @@ def test_bench_under_torchrun_single_rank(tmp_path):
                           "--no-cpu-baseline", "--no-live-pmc"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
     k = json.loads(ref.stdout.decode().strip().splitlines()[-1])
     assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"] and j["n_gpus"] == 1
+    assert j["merge"]["mode"] == "slices"
+    # the merge that ships hits (round 6: ntc_log_export_device -> all-to-all of keys -> ntc_log_replace_device -> the engine's own sketch update), and sBits = 11,
+    # whose default it is
+    for extra in (["--merge", "owner"], ["--s-bits", "11"]):
+        r = subprocess.run(cmd + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--reads-per-step", "1000000",
+                              "--no-cpu-baseline", "--no-live-pmc"] + [a for a in extra if a not in ("--merge", "owner")], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=600, cwd=root)
+        k = json.loads(ref.stdout.decode().strip().splitlines()[-1])
+        assert j["merge"]["mode"] == "owner" and j["merge"]["keys_sent"] == j["sampled_increments"], j["merge"]
+        assert j["f1_total"] == k["f1_total"] and j["sampled_increments"] == k["sampled_increments"]
+
+
+@pytest.mark.parametrize("n_eng,r_bits", [(2, 18), (4, 16), (8, 21)])
+def test_owner_mode_between_engines_on_one_device(nt, n_eng, r_bits):
+    """the device steps of the merge that ships hits, without a communicator: N engines on this device hash N shares of the reads; every engine's pending log
+    is split by counter-range owner (ntc_log_export_device), owner j gets part j of every engine as its pending log (ntc_log_replace_device) and its own
+    sketch update counts them: range j of engine j's sketch == range j of ONE engine's sketch over all the reads (uint32 counters: before the wrap)"""
+    rng = np.random.default_rng(n_eng)
+    alpha = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    n, L = 6000 * n_eng, 150
+    arr = alpha[rng.integers(0, 4, size=(n, L))]
+    arr = np.where(rng.random((n, L)) < 0.003, alpha[rng.integers(4, len(alpha), size=(n, L))], arr).astype(np.uint8)
+    reads = [arr[i].tobytes() for i in range(n)]
+    share = n // n_eng
+    tiles = [torch.from_numpy(nt.tile_reads(reads[i * share:(i + 1) * share], L)).cuda() for i in range(n_eng)]
+    with nt.Engine([32], r_bits=r_bits, s_bits=7) as one:
+        for t in tiles:
+            one.submit_tiled_device(t.data_ptr(), share, L)
+        one.flush()
+        sk, ncnt, _ = one.device_state()
+        torch.cuda.synchronize()
+        want = torch.as_tensor(_DevArray(sk, ncnt), device="cuda").clone()
+    engs = [nt.Engine([32], r_bits=r_bits, s_bits=7, flags=nt.FLAG_DEFER_REDO if i % 2 else 0) for i in range(n_eng)]
+    try:
+        for e, t in zip(engs, tiles):
+            e.submit_tiled_device(t.data_ptr(), share, L)
+        parts = []
+        for e in engs:
+            counts = e.log_export(n_eng)
+            offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            buf = torch.empty(max(int(offs[-1]), 1), dtype=torch.int32, device="cuda")
+            assert e.log_export(n_eng, buf.data_ptr(), offs[:-1]) == counts
+            torch.cuda.synchronize()
+            parts.append([buf[int(offs[p]):int(offs[p + 1])] for p in range(n_eng)])
+        assert sum(int(p.numel()) for ps in parts for p in ps) == int(want.to(torch.int64).sum())
+        rng_len = ncnt // n_eng
+        for j, e in enumerate(engs):
+            mine = torch.cat([parts[i][j] for i in range(n_eng)])
+            assert bool(((mine.to(torch.int64) // rng_len) == j).all())
+            e.log_replace(mine.data_ptr(), mine.numel())
+            e.flush()
+            sk, _, _ = e.device_state()
+            torch.cuda.synchronize()
+            got = torch.as_tensor(_DevArray(sk, ncnt), device="cuda")
+            assert torch.equal(got[j * rng_len:(j + 1) * rng_len], want[j * rng_len:(j + 1) * rng_len]), j
+            assert int(got.to(torch.int64).sum()) == int(mine.numel())  # nothing outside its range
+        with pytest.raises(nt.NtcError):  # the sketch holds counts now: hits can no longer be shipped (the caller merges counters)
+            engs[0].log_export(n_eng)
+    finally:
+        for e in engs:
+            e.close()
 
 
 def test_bench_gpus_flag_launches_real_ranks(tmp_path):
