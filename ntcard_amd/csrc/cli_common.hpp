@@ -5,14 +5,20 @@
 #pragma once
 #include <sys/stat.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <functional>
 #include <future>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ntcard_hip.h"
@@ -127,11 +133,57 @@ public:
 		return std::fread(dst, 1, cap, fp_);
 	}
 
+	// the same, filled by several threads when the input is a plain file: what is left of the line buffer first; from then on the file is read with pread at
+	// offsets this object keeps itself (run(n, fn) runs fn(0 .. n - 1) on the caller's helper threads).  A pipe (decompressor) is read by the caller alone.
+	template <class Pool> size_t read_parallel(char* dst, size_t cap, Pool& pool)
+	{
+		if (!fp_ || cap == 0) return 0;
+		if (pos_ < len_ || piped_) return read_raw(dst, cap);
+		if (fd_off_ < 0) { // first call behind the line buffer: the stdio position is where the buffer ended
+			fd_off_ = (long long)ftello(fp_);
+			struct stat st;
+			fd_size_ = fstat(fileno(fp_), &st) == 0 ? (long long)st.st_size : -1;
+			if (fd_off_ < 0 || fd_size_ < 0) {
+				piped_ = true; // (not seekable after all: plain sequential reads)
+				return read_raw(dst, cap);
+			}
+		}
+		const long long left = fd_size_ - fd_off_;
+		if (left <= 0) { // the file may have grown since fstat: one more look
+			const ssize_t n = pread(fileno(fp_), dst, cap, (off_t)fd_off_);
+			if (n > 0) fd_off_ += n;
+			return n > 0 ? (size_t)n : 0;
+		}
+		const size_t want = (size_t)std::min<long long>((long long)cap, left);
+		const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(pool.size(), want / (1u << 20) + 1));
+		std::vector<size_t> got(parts, 0);
+		const int fd = fileno(fp_);
+		const long long off0 = fd_off_;
+		pool.run(parts, [&](unsigned i) {
+			const size_t lo = want * i / parts, hi = want * (i + 1) / parts;
+			size_t done = 0;
+			while (lo + done < hi) {
+				const ssize_t n = pread(fd, dst + lo + done, hi - lo - done, (off_t)(off0 + (long long)(lo + done)));
+				if (n <= 0) break;
+				done += (size_t)n;
+			}
+			got[i] = done;
+		});
+		size_t total = 0;
+		for (unsigned i = 0; i < parts; ++i) { // (a short part — the file shrank — ends the block there)
+			total += got[i];
+			if (got[i] != want * (i + 1) / parts - want * i / parts) break;
+		}
+		fd_off_ += (long long)total;
+		return total;
+	}
+
 private:
 	FILE* fp_ = nullptr;
 	bool piped_ = false;
 	std::string buf_;
 	size_t pos_ = 0, len_ = 0;
+	long long fd_off_ = -1, fd_size_ = -1;
 };
 
 // ---- the seam: what replaces ntRead / stRead (ntcard.cpp:147-171) ---------------------------------
@@ -208,64 +260,213 @@ struct SpanBlock {
 	}
 };
 
+// Round 6: ONE file no longer means one core.  With helper threads (g_file_helpers: the -t threads that have no file of their own — `-t 8` on one file gives it
+// eight) a block is READ in parallel (pread of sub-ranges; plain files only) and its newlines are FOUND in parallel (memchr over sub-ranges); the record state
+// machine then runs over the list of line ends, which is cheap, while the helpers already fetch the next block, and up to three blocks are being packed
+// (ntc_submit_spans) at the same time.  Blocks keep a headroom in front of their data: the unfinished record of block i is copied there when block i has been
+// parsed, so fetching block i + 1 does not have to wait for it.
+inline unsigned g_file_helpers = 1;
+
+class HelperPool { // parallel_for over a few indices on persistent threads (the caller takes part)
+public:
+	explicit HelperPool(unsigned n) : n_(n > 1 ? n : 1)
+	{
+		for (unsigned t = 1; t < n_; ++t)
+			th_.emplace_back([this] { loop(); });
+	}
+	~HelperPool()
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			quit_ = true;
+		}
+		cv_.notify_all();
+		for (auto& t : th_)
+			t.join();
+	}
+	unsigned size() const { return n_; }
+	void run(unsigned n_tasks, const std::function<void(unsigned)>& fn)
+	{
+		if (n_ == 1 || n_tasks <= 1) {
+			for (unsigned i = 0; i < n_tasks; ++i)
+				fn(i);
+			return;
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			fn_ = &fn;
+			total_ = n_tasks;
+			next_ = 0;
+			left_ = n_tasks;
+			++gen_;
+		}
+		cv_.notify_all();
+		work();
+		std::unique_lock<std::mutex> lk(mu_);
+		done_.wait(lk, [this] { return left_ == 0; });
+		fn_ = nullptr;
+	}
+
+private:
+	void work()
+	{
+		for (;;) {
+			unsigned i;
+			const std::function<void(unsigned)>* f;
+			{
+				std::lock_guard<std::mutex> lk(mu_);
+				if (!fn_ || next_ >= total_) return;
+				i = next_++;
+				f = fn_;
+			}
+			(*f)(i);
+			std::lock_guard<std::mutex> lk(mu_);
+			if (--left_ == 0) done_.notify_all();
+		}
+	}
+	void loop()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] { return quit_ || gen_ != seen; });
+				if (quit_) return;
+				seen = gen_;
+			}
+			work();
+		}
+	}
+	unsigned n_;
+	std::vector<std::thread> th_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_;
+	const std::function<void(unsigned)>* fn_ = nullptr;
+	unsigned total_ = 0, next_ = 0, left_ = 0;
+	uint64_t gen_ = 0;
+	bool quit_ = false;
+};
+
 template <class Handler> inline void parse_blocks(LineReader& in, ntc_engine* eng, Handler& h)
 {
 	size_t kBlock = 32u << 20;
 	if (const char* t = std::getenv("NTC_CLI_BLOCK_BYTES")) // test knob: tiny blocks put every record across a block boundary
 		kBlock = std::max<size_t>(64, std::strtoull(t, nullptr, 10));
-	SpanBlock blk[2];
-	int cur = 0;
-	blk[0].buf.resize(kBlock);
-	blk[1].buf.resize(kBlock);
-	size_t have = 0, pos = 0;  // bytes in the current block, next unparsed byte
-	bool eof = false, last_nl = true;
+	const size_t kHead = std::min<size_t>(1u << 20, kBlock); // headroom in front of a block's data for the previous block's unfinished record (grown on demand)
+	HelperPool pool(g_file_helpers);
+	constexpr int kRing = 4; // blocks: one being parsed, one being fetched, up to two more being packed (the engine has four staging pairs)
+	struct Block : SpanBlock {
+		size_t head = 0;             // buf[head ..) is where a fetch puts its bytes
+		size_t begin = 0, end = 0;   // the block's bytes: buf[begin .. end) (begin <= head: the carried-over tail sits in [begin, head))
+		std::vector<size_t> nl;      // positions of the newlines in [head, end), ascending
+		bool eof = false;            // the fetch hit the end of the file
+	};
+	Block blk[kRing];
 	auto wait = [&](SpanBlock& b) {
 		if (!b.pending.valid()) return;
 		const std::string err = b.pending.get();
 		if (!err.empty()) die_engine(err);
 	};
-	for (;;) {
-		SpanBlock& b = blk[cur];
-		if (!eof) {
-			const size_t n = in.read_raw(b.buf.data() + have, b.buf.size() - have);
-			if (n == 0) eof = true;
-			have += n;
-		}
-		for (;;) { // split the lines of [pos, have)
+	// newlines of buf[from, to) appended to b.nl (parallel over sub-ranges)
+	auto scan = [&](Block& b, size_t from, size_t to) {
+		const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(pool.size(), (to - from) / (256u << 10) + 1));
+		std::vector<std::vector<size_t>> found(parts);
+		pool.run(parts, [&](unsigned i) {
+			const size_t lo = from + (to - from) * i / parts, hi = from + (to - from) * (i + 1) / parts;
 			const char* base = b.buf.data();
-			const char* nl = static_cast<const char*>(std::memchr(base + pos, '\n', have - pos));
-			size_t line_end, next;
-			if (nl) {
-				line_end = (size_t)(nl - base);
-				next = line_end + 1;
-			} else if (eof && pos < have) { // last line of the file, no newline
-				line_end = next = have;
-				last_nl = false;
-			} else {
-				break;
+			auto& v = found[i];
+			v.reserve((hi - lo) / 64 + 16);
+			for (const char* p = base + lo; p < base + hi;) {
+				const char* q = static_cast<const char*>(std::memchr(p, '\n', (size_t)(base + hi - p)));
+				if (!q) break;
+				v.push_back((size_t)(q - base));
+				p = q + 1;
 			}
-			h.line(b, pos, line_end);
-			pos = next;
+		});
+		for (auto& v : found)
+			b.nl.insert(b.nl.end(), v.begin(), v.end());
+	};
+	// up to `want` more bytes behind b.end (parallel pread for a plain file once the line buffer is drained), then their newlines
+	auto fetch_more = [&](Block& b, size_t want) {
+		if (b.buf.size() < b.end + want) b.buf.resize(b.end + want);
+		const size_t from = b.end;
+		size_t got = 0;
+		while (got < want && !b.eof) {
+			const size_t n = in.read_parallel(b.buf.data() + from + got, want - got, pool);
+			if (n == 0) b.eof = true;
+			got += n;
 		}
-		if (eof && pos >= have) {
+		b.end = from + got;
+		scan(b, from, b.end);
+	};
+	auto fetch = [&](Block& b) { // a fresh block
+		wait(b); // its previous contents have been packed
+		b.starts.clear();
+		b.lens.clear();
+		b.nl.clear();
+		b.eof = false;
+		if (b.head < kHead) b.head = kHead;
+		if (b.buf.size() < b.head + kBlock) b.buf.resize(b.head + kBlock);
+		b.begin = b.end = b.head;
+		fetch_more(b, kBlock);
+	};
+	int cur = 0;
+	fetch(blk[0]);
+	size_t pos = blk[0].begin; // next unparsed byte of the current block
+	bool last_nl = true;
+	for (;;) {
+		Block& b = blk[cur];
+		Block& nx = blk[(cur + 1) % kRing];
+		std::future<void> pre;
+		if (!b.eof) pre = std::async(std::launch::async, [&] { fetch(nx); }); // (runs the pool: the coordinator does not use it meanwhile)
+		// a line longer than everything fetched so far (a chromosome on one FASTA line): read on into THIS block, doubling
+		if (b.nl.empty() && !b.eof) {
+			if (pre.valid()) pre.get(); // (the next block has consumed file bytes that belong to this line: fold them in)
+			for (;;) {
+				Block& n2 = blk[(cur + 1) % kRing];
+				const size_t add = n2.end - n2.head;
+				if (b.buf.size() < b.end + add) b.buf.resize(std::max(b.buf.size() * 2, b.end + add));
+				std::memcpy(b.buf.data() + b.end, n2.buf.data() + n2.head, add);
+				for (size_t x : n2.nl)
+					b.nl.push_back(x - n2.head + b.end);
+				b.end += add;
+				b.eof = n2.eof;
+				if (!b.nl.empty() || b.eof) break;
+				fetch(n2);
+			}
+			if (!b.eof) pre = std::async(std::launch::async, [&] { fetch(nx); });
+		}
+		for (size_t x : b.nl) { // the record state machine over the line ends
+			h.line(b, pos, x);
+			pos = x + 1;
+		}
+		if (b.eof) {
+			if (pos < b.end) { // last line of the file, no newline
+				h.line(b, pos, b.end);
+				pos = b.end;
+				last_nl = false;
+			}
 			h.finish(b, last_nl);
 			if (!b.starts.empty() && ntc_submit_spans(eng, b.buf.data(), b.starts.data(), b.lens.data(), b.starts.size()) != 0) die_engine();
 			break;
 		}
-		// the block is exhausted: everything from the first byte still needed moves to the front of the other block
+		pre.get();
+		// the block is exhausted: everything from the first byte still needed moves into the headroom of the next block
 		const size_t keep = h.keep(pos);
-		SpanBlock& o = blk[cur ^ 1];
-		wait(o); // its previous contents have been packed
-		if (keep == 0 && have == b.buf.size()) { // one record longer than the block: grow and read on
-			b.buf.resize(b.buf.size() * 2);
-			continue;
+		const size_t tail = b.end - keep;
+		if (tail > nx.head) { // (rare: an unfinished record longer than the headroom — make room in front of the fetched bytes)
+			const size_t grow = ((tail - nx.head) + (1u << 20)) & ~(size_t)0xfffff;
+			std::vector<char> nb(nx.buf.size() + grow);
+			std::memcpy(nb.data() + nx.head + grow, nx.buf.data() + nx.head, nx.end - nx.head);
+			nx.buf.swap(nb);
+			for (auto& x : nx.nl)
+				x += grow;
+			nx.head += grow;
+			nx.end += grow;
 		}
-		const size_t tail = have - keep;
-		if (o.buf.size() < b.buf.size()) o.buf.resize(b.buf.size());
-		h.rebase(b, keep);
-		std::memcpy(o.buf.data(), b.buf.data() + keep, tail);
-		o.starts.clear();
-		o.lens.clear();
+		h.rebase(b, keep - (nx.head - tail)); // positions held by the handler: byte `keep` of this block becomes byte nx.head - tail of the next
+		std::memcpy(nx.buf.data() + nx.head - tail, b.buf.data() + keep, tail);
+		nx.begin = nx.head - tail;
 		if (!b.starts.empty()) {
 			SpanBlock* pb = &b;
 			b.pending = std::async(std::launch::async, [eng, pb]() -> std::string {
@@ -274,12 +475,11 @@ template <class Handler> inline void parse_blocks(LineReader& in, ntc_engine* en
 				return msg.empty() ? std::string("ntc_submit_spans failed") : msg;
 			});
 		}
-		pos -= keep;
-		have = tail;
-		cur ^= 1;
+		pos = nx.begin + (pos - keep);
+		cur = (cur + 1) % kRing;
 	}
-	wait(blk[0]);
-	wait(blk[1]);
+	for (auto& b : blk)
+		wait(b);
 }
 
 // FASTQ, ntcard.cpp:173-189 (four-line records, the first header already consumed by the sniffer): a record counts once its quality line could be

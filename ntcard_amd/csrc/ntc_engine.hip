@@ -1160,7 +1160,7 @@ int ntc_create(const ntc_config* cfg, ntc_engine** out)
 		}
 		e->own_f1 = true;
 	}
-	if (hipMalloc((void**)&e->d_skdirty, 64) != hipSuccess) {
+	if (hipMalloc((void**)&e->d_skdirty, 64 + 2 * 64 * 8) != hipSuccess) { // (the word, then ntc_log_export_device's cursors and offsets)
 		ntc_destroy(e);
 		return fail(NTC_ERR_MEMORY, "ntc_create: cannot allocate engine state on device");
 	}
@@ -2158,9 +2158,8 @@ int ntc_log_export_device(ntc_engine* e, uint32_t n_parts, void* d_keys_u32, con
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (e->sk_host_dirty || dirty != 0u)
 		return fail(NTC_ERR_STATE, "ntc_log_export_device: the sketch already holds counts (a sketch update ran, or a kernel incremented it directly): merge counters instead");
-	unsigned long long *d_cursor = nullptr, *d_off = nullptr;
-	HIP_TRY(hipMalloc((void**)&d_cursor, 2 * 64 * 8));
-	d_off = d_cursor + 64;
+	unsigned long long* const d_cursor = reinterpret_cast<unsigned long long*>(e->d_skdirty + 16);
+	unsigned long long* const d_off = d_cursor + 64;
 	unsigned long long h_off[64] = {0};
 	if (part_offset)
 		for (uint32_t p = 0; p < n_parts; ++p)
@@ -2173,7 +2172,6 @@ int ntc_log_export_device(ntc_engine* e, uint32_t n_parts, void* d_keys_u32, con
 	unsigned long long h_cnt[64] = {0};
 	if (rc == hipSuccess) rc = hipMemcpyAsync(h_cnt, d_cursor, 64 * 8, hipMemcpyDeviceToHost, e->stream);
 	if (rc == hipSuccess) rc = hipStreamSynchronize(e->stream);
-	(void)hipFree(d_cursor);
 	if (rc != hipSuccess) return fail(NTC_ERR_DEVICE, "ntc_log_export_device: %s", hipGetErrorString(rc));
 	for (uint32_t p = 0; p < n_parts; ++p)
 		counts_out[p] = h_cnt[p];

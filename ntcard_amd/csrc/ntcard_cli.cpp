@@ -226,6 +226,8 @@ int main(int argc, char** argv)
 	};
 	std::vector<std::thread> pool;
 	const unsigned n_threads = opt.threads == 0 ? 1 : opt.threads;
+	// the threads that have no file of their own help the others read and split their blocks (round 6; the reference gives a file one thread, ntcard.cpp:445-446)
+	cli::g_file_helpers = std::max<unsigned>(1, n_threads / (unsigned)std::max<size_t>(1, std::min<size_t>(n_threads, files.size())));
 	for (unsigned t = 1; t < n_threads && t < files.size(); ++t)
 		pool.emplace_back(worker);
 	worker();

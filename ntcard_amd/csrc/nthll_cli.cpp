@@ -115,6 +115,7 @@ int main(int argc, char** argv)
 			process_file(files[files.size() - i - 1], eng); // nthll.cpp:225-226 walks the list backwards
 	};
 	std::vector<std::thread> pool;
+	cli::g_file_helpers = std::max<unsigned>(1, (threads ? threads : 1) / (unsigned)std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, files.size())));
 	for (unsigned t = 1; t < (threads ? threads : 1) && t < files.size(); ++t)
 		pool.emplace_back(worker);
 	worker();

@@ -173,12 +173,14 @@ def test_live_differential_against_reference_binary(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_NTCARD), reason="the real reference binary (oracle/_ref) was not built")
+@pytest.mark.parametrize("threads", [None, "5"])
 @pytest.mark.parametrize("block", [None, "64", "4096"])
-def test_block_splitters_against_reference_binary(tmp_path, block):
+def test_block_splitters_against_reference_binary(tmp_path, block, threads):
     """the block-based FASTA and SAM splitters (cli_common.hpp) against the reference's line-based ones (ntcard.cpp:191-235), quirks included:
     one-line and wrapped FASTA records mixed, blank lines, CR line ends, no final newline; SAM lines with fewer than ten fields and blank lines
     (the reference counts the PREVIOUS sequence again), spaces as separators, header-only files with and without a final newline.  With
-    NTC_CLI_BLOCK_BYTES at 64 and 4096 every record straddles a block boundary and the grow path (a record longer than the block) runs."""
+    NTC_CLI_BLOCK_BYTES at 64 and 4096 every record straddles a block boundary and the grow path (a record longer than the block) runs.
+    threads = 5 (round 6): a file's blocks are read and scanned for line ends by helper threads (`-t` threads beyond the number of files), FASTQ included."""
     import random
     rng = random.Random(7)
 
@@ -222,10 +224,17 @@ def test_block_splitters_against_reference_binary(tmp_path, block):
     env = dict(os.environ)
     if block:
         env["NTC_CLI_BLOCK_BYTES"] = block
+    fq = []
+    for i in range(4000):
+        s2 = seq(rng.choice([0, 20, 100, 150, 151]))
+        fq.append("@r%d\n%s%s\n+\n%s\n" % (i, s2, "\r" if rng.random() < 0.05 else "", "I" * len(s2)))
+    fq.append("@last\n" + seq(150) + "\n+\n" + "I" * 150)  # the quality line ends the file without a newline: the record counts
+    (tmp_path / "quirky.fq").write_text("".join(fq), newline="")
     cases = [(["-k", "21"], ["reads1.fa"]), (["-k", "32"], ["long1.fa"]), (["-k", "25"], ["quirky.sam"]), (["-k", "25", "-g", "3"], ["nohdr2.sam"]),
-             (["-k", "12"], ["hdr_nl.sam", "reads1.fa"]), (["-k", "12"], ["hdr_nonl.sam", "reads1.fa"]), (["-k", "17"], ["hdr_nonl.sam"])]
+             (["-k", "12"], ["hdr_nl.sam", "reads1.fa"]), (["-k", "12"], ["hdr_nonl.sam", "reads1.fa"]), (["-k", "17"], ["hdr_nonl.sam"]),
+             (["-k", "20"], ["quirky.fq"])]
     for n, (args, files) in enumerate(cases):
-        ours = subprocess.run([BIN] + args + ["-p", "gpu%d" % n] + files, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        ours = subprocess.run([BIN] + args + (["-t", threads] if threads else []) + ["-p", "gpu%d" % n] + files, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         ref = subprocess.run([REF_NTCARD] + args + ["-p", "ref%d" % n] + files, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert ours.returncode == ref.returncode, (args, files, ours.stderr, ref.stderr)
         if ref.returncode != 0:

@@ -11,6 +11,14 @@ for t in 1 8; do
   echo "== MI355X ntcard -t $t"; time $ROOT/ntcard_amd/bin/ntcard -t $t -k 32 -p gpu$t $W/s_*.fq
   cmp ref${t}_k32.hist gpu${t}_k32.hist && echo IDENTICAL
 done
+echo "== ONE file holding all the reads (round 6: the threads without a file of their own read and split its blocks), -t 8 and -t 1"
+cat $W/s_*.fq > $W/all.fastq; ls -la $W/all.fastq
+echo "-- reference -t 8"; time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 32 -p ref_one $W/all.fastq
+echo "-- MI355X -t 8"; time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p gpu_one $W/all.fastq
+cmp ref_one_k32.hist gpu_one_k32.hist && echo IDENTICAL
+echo "-- MI355X -t 1"; time $ROOT/ntcard_amd/bin/ntcard -t 1 -k 32 -p gpu_one1 $W/all.fastq
+cmp ref_one_k32.hist gpu_one1_k32.hist && echo IDENTICAL
+rm -f $W/all.fastq
 echo "== multi-k 16,24,32,48 -t 8"
 time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 16,24,32,48 -p refm $W/s_*.fq
 time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 16,24,32,48 -p gpum $W/s_*.fq
