@@ -329,6 +329,8 @@ struct ntc_engine {
 	bool defer_redo = false;        // NTC_FLAG_DEFER_REDO
 	unsigned char* d_untile = nullptr; // row-major scratch for tiled batches of configurations K1h is not built for
 	size_t untile_cap = 0;
+	uint32_t* d_tmeta = nullptr;       // K1's slot table (len | len << 16 per read) of a RAGGED tiled batch under a list of which a part is K1's (round 6)
+	size_t tmeta_cap = 0;              // reads
 	double apply_ms = 0.0;
 	uint64_t applies = 0;
 	uint32_t hll_bits = 0;       // != 0: nthll engine (d_sketch holds uint32 M[1<<hll_bits])
@@ -834,7 +836,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 	for (const auto& sg : segs)
 		any_tails |= sg.d_tails != nullptr;
 	if (!e->ts_all && e->ts_required) return fail(NTC_ERR_ARG, "ntc_submit_tiled_device: the tiled kernel is not available for this configuration (NTC_FLAG_REQUIRE_TILED)");
-	if (!e->ts_all && any_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for every k of this configuration");
+	if (!e->ts_ok && any_tails) return fail(NTC_ERR_ARG, "ntc_submit_tiled_ragged_device: the tiled kernels are not built for any k of this configuration");
 	if (!e->ts_ok) { // this configuration is K1's
 		for (const auto& sg : segs)
 			if (int rc = run_tiled_as_rows(e, sg.d_tiles, sg.n_reads, sg.read_len)) return rc;
@@ -873,7 +875,7 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 			return 0;
 		}
 	}
-	if (!e->ts_all && e->d_log && e->adaptive && !e->probed && segs.size() == 1 && e->log_est < (double)(1u << 20)) {
+	if (!e->ts_all && e->d_log && e->adaptive && !e->probed && segs.size() == 1 && segs[0].d_tails == nullptr && e->log_est < (double)(1u << 20)) {
 		// A list of which a part is K1's: K1 appends to the hit log or increments with device atomics, whichever the probe of the FIRST sizeable batch finds
 		// cheaper for this data (run_batch).  The probe needs a log whose sampled entries come from few reads — the head of the batch, hashed by both kernels
 		// before the rest: cut the batch as run_batch cuts a row-slot batch (at a tile boundary: any prefix of a tiled buffer is a batch).
@@ -1067,8 +1069,25 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 	if (!e->profiling)
 		if (int rc = close_run(e)) return rc; // (profiling was switched off inside a run)
 	if (!e->ts_all) // the k of the list K1h is not built for: K1 over the same tiles (staged straight from the tiled layout)
-		for (const auto& sg : segs)
-			if (int rc = run_batch(e, sg.d_tiles, nullptr, sg.n_reads, sg.read_len, 16u * ((sg.read_len + 15u) / 16u), true, &e->k_tiled)) return rc;
+		for (const auto& sg : segs) {
+			const uint32_t* d_meta = nullptr;
+			if (sg.d_tails) {
+				// a ragged batch (round 6): K1 takes every read's length from a slot table, built here from the tiles' prefix tables — the batch stays on tiles,
+				// K1h + K1f serve their k from it and K1 the rest (before: the whole batch went to row slots and K1 for every k)
+				if (sg.n_reads > e->tmeta_cap) {
+					HIP_TRY(hipStreamSynchronize(e->stream));
+					if (e->d_tmeta) (void)hipFree(e->d_tmeta);
+					e->d_tmeta = nullptr;
+					e->tmeta_cap = 0;
+					const size_t cap = std::max<size_t>((size_t)sg.n_reads, 1u << 20);
+					if (hipMalloc((void**)&e->d_tmeta, cap * 4) != hipSuccess) return fail(NTC_ERR_MEMORY, "cannot allocate the slot table of a ragged tiled batch on device");
+					e->tmeta_cap = cap;
+				}
+				HIP_TRY(ntc::launch_tails_to_meta(sg.d_tails, sg.n_reads, (sg.read_len + 15u) / 16u, e->d_tmeta, e->stream));
+				d_meta = e->d_tmeta;
+			}
+			if (int rc = run_batch(e, sg.d_tiles, d_meta, sg.n_reads, sg.read_len, 16u * ((sg.read_len + 15u) / 16u), true, &e->k_tiled)) return rc;
+		}
 	return 0;
 }
 
@@ -1286,6 +1305,7 @@ void ntc_destroy(ntc_engine* e)
 	if (e->d_phist) (void)hipFree(e->d_phist);
 	if (e->d_out16) (void)hipFree(e->d_out16);
 	if (e->d_untile) (void)hipFree(e->d_untile);
+	if (e->d_tmeta) (void)hipFree(e->d_tmeta);
 	if (e->d_skdirty) (void)hipFree(e->d_skdirty);
 	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
@@ -1736,7 +1756,7 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 				const HostBin one{nullptr, n_reads, (uint32_t)len0, false};
 				return submit_tiled_host(e, &one, 1, len_of, ptr_of);
 			}
-		} else if (e->ts_all) { // (a list with a k that is K1's keeps ragged batches in row slots: K1 takes per-read lengths from the slot table, not from tails)
+		} else { // (round 6: also under a list of which a part is K1's — K1 gets a slot table derived from the tiles' prefix tables)
 			constexpr uint32_t kMaxC = 0x10000u / 16u;
 			std::vector<uint32_t> per_c(kMaxC + 1, 0u);
 			for (uint64_t i = 0; i < n_reads; ++i) {
@@ -1747,7 +1767,7 @@ template <class LenFn, class PtrFn> int submit_impl(ntc_engine* e, uint64_t n_re
 			std::vector<std::vector<uint64_t>> bins; // (only the bins that are taken)
 			std::vector<int32_t> bin_of(kMaxC + 1, -1);
 			for (uint32_t c = 1; c <= kMaxC; ++c)
-				if (per_c[c] >= bin_min) {
+				if (per_c[c] >= bin_min && k1_fits_tiles(e, 16u * c)) {
 					bin_of[c] = (int32_t)bins.size();
 					bins.emplace_back();
 					bins.back().reserve(per_c[c]);

@@ -647,6 +647,29 @@ hipError_t launch_gen_tiled(unsigned char* out, uint64_t seed, uint64_t first, u
 	return hipGetLastError();
 }
 
+// K1's slot table for a RAGGED tiled batch: a read's length from the tile's prefix table (ntc_submit_tiled_ragged_device)
+__global__ __launch_bounds__(256) void tails_to_meta_kernel(const uint32_t* __restrict__ tails, uint64_t n_reads, uint32_t n_chunks, uint32_t* __restrict__ meta)
+{
+	for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n_reads; i += (uint64_t)gridDim.x * 256ull) {
+		const uint64_t t = i / kTileReads;
+		const uint32_t r = (uint32_t)(i % kTileReads);
+		uint32_t tail = 0;
+#pragma unroll
+		for (uint32_t d = 0; d < 16u; ++d)
+			tail += tails[t * 16u + d] > r;
+		const uint32_t len = 16u * (n_chunks - 1u) + tail;
+		meta[i] = len | (len << 16);
+	}
+}
+
+hipError_t launch_tails_to_meta(const uint32_t* tails, uint64_t n_reads, uint32_t n_chunks, uint32_t* meta, hipStream_t st)
+{
+	const uint64_t want = (n_reads + 255) / 256;
+	const unsigned grid = (unsigned)(want < 4096 ? (want ? want : 1) : 4096);
+	hipLaunchKernelGGL(tails_to_meta_kernel, dim3(grid), dim3(256), 0, st, tails, n_reads, n_chunks, meta);
+	return hipGetLastError();
+}
+
 hipError_t launch_untile(const unsigned char* tiles, unsigned char* slots, uint64_t n_reads, uint32_t read_len, uint32_t stride, hipStream_t st)
 {
 	uint64_t blocks = (n_reads * (stride / 4u) + 255) / 256;

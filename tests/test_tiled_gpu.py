@@ -492,6 +492,35 @@ def test_tiled_bins_in_one_launch(nt, klist, s_bits, sizes):
         assert np.array_equal(tc, oc)
 
 
+@pytest.mark.parametrize("klist", [[32, 64], [16, 24, 32, 48], [40, 20]])
+def test_ragged_tiles_under_a_mixed_k_list(nt, monkeypatch, klist):
+    """round 6: ragged tiled batches under a k list of which only a part is K1h's — K1h + K1f take their k from the tiles, K1 stages the SAME tiles and learns
+    every read's length from a slot table derived from the tiles' prefix tables (tails): length bins through ntc_submit_tiled_bins_device and
+    ntc_submit_tiled_ragged_device, reads shorter than the larger k, and the same reads through ntc_submit (host packer: bins on tiles, the rest in row slots)"""
+    rng = np.random.default_rng(sum(klist))
+    bins, all_reads = [], []
+    for C, n in ((10, 5000), (9, 3000), (4, 2500), (2, 2100)):
+        reads = _ragged_reads(rng, n, 16 * C - 15, 16 * C, 0.004)
+        tiles, tails, order = nt.tile_reads_ragged(reads, C)
+        bins.append((torch.from_numpy(tiles).cuda(), n, 16 * C, torch.from_numpy(tails.reshape(-1).astype(np.int32)).cuda()))
+        all_reads += reads
+    oc, of1 = orc.sketch_reads(all_reads, klist, 0, 18, 7)
+    for flags in (0, nt.FLAG_DEFER_REDO, nt.FLAG_ALWAYS_LOG):
+        with nt.Engine(klist, r_bits=18, s_bits=7, flags=flags) as e:
+            e.submit_tiled_bins_device([(t.data_ptr(), n, L, d.data_ptr()) for t, n, L, d in bins[:2]])
+            for t, n, L, d in bins[2:]:
+                e.submit_tiled_ragged_device(t.data_ptr(), n, L // 16, d.data_ptr())
+            tc, ph, f1 = e.finish(counters=True)
+        assert np.array_equal(f1, of1), (flags, f1, of1)
+        assert np.array_equal(tc, oc), flags
+    monkeypatch.setenv("NTC_BIN_MIN", "1024")  # (the host packer's bar for a bin: 32 Ki reads by default)
+    mixed = [all_reads[i] for i in rng.permutation(len(all_reads))]
+    with nt.Engine(klist, r_bits=18, s_bits=7) as e:
+        e.submit_reads(mixed)
+        tc, ph, f1 = e.finish(counters=True)
+    assert np.array_equal(f1, of1) and np.array_equal(tc, oc)
+
+
 @pytest.mark.parametrize("cap", ["64", "7"])
 def test_tiled_bins_with_overflowing_suspect_lists(nt, monkeypatch, cap):
     """several length bins in one launch, reads dense with N, suspect lists far too short (NTC_K1H_SUS_CAP): every bin's K1f finds ITS regions overflowed and

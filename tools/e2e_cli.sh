@@ -45,6 +45,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof_trim -o t 
 f=$(find /tmp/e2e_prof_trim -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -6 "$f" | cut -c1-150
 cd $W
+echo "== the trimmed reads under a mixed k list, -k 32,64 -t 8 (round 6: the length bins stay on tiles — K1h + K1f for k = 32, K1 staging the same tiles for k = 64)"
+echo "-- reference"; time $ROOT/oracle/_ref/ntcard_ref -t 8 -k 32,64 -p ref_trim2 $W/s_*.trim.fastq
+echo "-- MI355X"; time $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32,64 -p gpu_trim2 $W/s_*.trim.fastq
+for k in 32 64; do cmp ref_trim2_k$k.hist gpu_trim2_k$k.hist && echo IDENTICAL k$k; done
+cd /tmp && rm -rf /tmp/e2e_prof_trim2
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof_trim2 -o t -- $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32,64 -p $W/proft2 $W/s_*.trim.fastq > /tmp/e2e_prof_trim2.log 2>&1
+f=$(find /tmp/e2e_prof_trim2 -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && head -7 "$f" | cut -c1-150
+cd $W
 echo "== kernels of one CLI run (rocprofv3 --kernel-trace --stats: which hash kernel the parsed reads reach)"
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/e2e_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_prof -o t -- $ROOT/ntcard_amd/bin/ntcard -t 8 -k 32 -p $W/prof $W/s_*.fq > /tmp/e2e_prof.log 2>&1
