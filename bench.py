@@ -450,7 +450,8 @@ def main():
         achieved_hash = read_bytes / (hash_ms * 1e-3) / 1e9 if hash_ms > 0 else 0.0
         if (tiled and ((all(12 <= k <= 32 for k in klist) and not args.gap) or (nk == 1 and (klist[0], args.gap) in ((12, 2), (32, 8)))) and args.s_bits >= 7
                 and args.r_bits + 1 + args.s_bits - 7 <= 32 and not args.lane_kernel):
-            kern = "sketch_k1h_kernel (K1h: one wave per tile, eight waves per CU) + k1h_fix_kernel / k1h_slow_kernel (K1f: one launch per up to 8 batches)"
+            kern = ("sketch_k1h_kernel (K1h: one wave per tile, eight waves per CU; with NTC_FLAG_DEFER_REDO up to 8 resident batches = bench steps share ONE launch, "
+                    "hash_ms is the launches' HIP-event time divided by the steps) + k1h_fix_kernel / k1h_slow_kernel (K1f: one launch per up to 8 batches)")
         else:
             kern = "sketch_hf_kernel (K1: lane per read)"
         peak_valu = 256 * 4 * 2.4e9 / 2  # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD-32 for 2 clk
@@ -478,7 +479,8 @@ def main():
                                    f"k={','.join(map(str, klist))}{', gap=%d' % args.gap if args.gap else ''}, rBits={args.r_bits}, sBits={args.s_bits}, "
                                    f"{K} steps x {R} reads per GPU, {'tiled' if tiled else 'row-major'} slots"
                                    + (f" ({nb} distinct resident batches, cycled)" if nb < K else "")
-                                   + (", RCCL all-to-all of 16-bit counter slices + value histograms to rank 0 inside the timed region" if world > 1 else ""),
+                                   + ((", RCCL all-to-all of the sampled k-mers to their counter-range owners + value histograms to rank 0 inside the timed region" if merge_mode == "owner" else
+                                       ", RCCL all-to-all of 16-bit counter slices + value histograms to rank 0 inside the timed region") if world > 1 else ""),
                        "traffic_key": traffic_key(args, R), "k": klist[0] if nk == 1 else klist, "gap": args.gap, "read_len": L, "reads_per_gpu": reads_per_rank,
                        "r_bits": args.r_bits, "s_bits": args.s_bits, "layout": args.layout, "parallelism": f"read-sharded x{world}",
                        "rccl_ranks": dist.get_world_size() if use_dist else 0},
