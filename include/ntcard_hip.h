@@ -79,8 +79,12 @@ typedef struct {
 #define NTC_FLAG_DEFER_REDO 128u    /* device-resident batches (ntc_submit_device, ntc_submit_tiled_device): the caller promises to keep every
                                       submitted buffer valid AND UNCHANGED until ntc_sync / ntc_finish returns.  The second passes over a batch's
                                       reads with non-ACGTU bytes are then shared by several batches instead of run per batch: the fix-up
-                                      kernels K1f behind up to 8 launches of the one-wave-per-tile kernel K1h.  Without the flag a buffer may be
-                                      reused as soon as the stream has passed the submit call. */
+                                      kernels K1f behind up to 8 launches of the one-wave-per-tile kernel K1h.  Since ABI 6 the HASH launches wait as
+                                      well: up to 8 tiled batches (ntc_submit_tiled_device / _ragged_device) are hashed by one launch per k, started
+                                      when the eighth arrives or when ntc_flush / ntc_sync / ntc_finish / ntc_reset / a merge / ntc_device_state needs
+                                      the counters — work submitted under this flag is only guaranteed to have been ENQUEUED after one of those calls
+                                      (a small batch then costs its share of a large launch instead of a launch of its own).  Without the flag a
+                                      buffer may be reused as soon as the stream has passed the submit call. */
 #define NTC_FLAG_REQUIRE_TILED 64u  /* validation: a tiled batch must be served by the tiled kernels for EVERY k of the list, else ntc_submit_tiled_device fails */
 #define NTC_FLAG_DIRECT_ATOMICS 2u /* no hit log: every sampled k-mer is one device atomic on the sketch
                                       (the literal form of ntcard.cpp:142-143; cross-check and A/B runs) */
@@ -146,7 +150,8 @@ uint64_t ntc_tiled_bytes(uint64_t n_reads, uint32_t read_len);
  * bases in their last 16-base piece (d_tails[tile * 16] = the reads of the tile; non-increasing in d).  The kernel masks every window that ends
  * behind a read's end with the prefix of the tile that is long enough: no per-read length array, 64 bytes per tile.  d_tails follows the rules of
  * d_tiles (device memory, valid until the stream has passed the call — until ntc_sync with NTC_FLAG_DEFER_REDO).  Fails with NTC_ERR_ARG on an
- * engine whose configuration the tiled kernels are not built for.  ntc_submit / ntc_submit_spans build such batches themselves: a host batch of
+ * engine in whose configuration NO k is the tiled kernels' (ABI 6: a list of which only a part is theirs is fine — the general kernel stages the same
+ * tiles for its k and takes every read's length from a table the engine derives from d_tails).  ntc_submit / ntc_submit_spans build such batches themselves: a host batch of
  * mixed lengths is binned by ceil(len / 16), bins of >= 1024 reads go this way, the rest takes row slots.                                      */
 int ntc_submit_tiled_ragged_device(ntc_engine *e, const void *d_tiles, uint64_t n_reads, uint32_t n_chunks, const uint32_t *d_tails);
 
