@@ -659,7 +659,17 @@ hipError_t launch_k1h_fixup(const K1fBatch& b, uint32_t n_items, unsigned cus, h
 		rows = std::max(rows, (size_t)b.item[i].a.n_tiles * b.item[i].a.n_chunks);
 		waves = std::max(waves, b.item[i].n_waves);
 	}
-	const unsigned n_f1 = (unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * 8);
+	// F1-role blocks per CU.  Round 6: TWO per CU for a launch over one batch, FOUR for one over several (round 5: eight = every resident block of the chip): with
+	// fewer of them the suspect role's blocks are resident beside the F1 role's from the start and the two streams of scattered fetches overlap instead of
+	// following each other with a ramp and a tail each — fix-up 0.068 -> 0.050 ms per step behind every launch, 0.049 -> 0.045 deferred; one per CU is too few
+	// (0.065).  profiles/r06_k1f_f1_blocks.txt.  (A/B builds override: tools/ab_build.sh <name> -DNTC_AB_F1_SINGLE=n -DNTC_AB_F1_MULTI=n.)
+#ifndef NTC_AB_F1_SINGLE
+#define NTC_AB_F1_SINGLE 2
+#endif
+#ifndef NTC_AB_F1_MULTI
+#define NTC_AB_F1_MULTI 4
+#endif
+	const unsigned n_f1 = (unsigned)std::min<size_t>((rows + 15) / 16, (size_t)cus * (n_items == 1 ? NTC_AB_F1_SINGLE : NTC_AB_F1_MULTI));
 	unsigned n_sus = waves;
 #ifdef NTC_K1F_TIME_ROLE_BUILD // timing builds only (tools/k1h_variant.sh, EXTRA=-DNTC_K1F_TIME_ROLE_BUILD): never in the product library — the results are WRONG
 	if (const char* ev = std::getenv("NTC_K1F_TIME_ROLE")) { // 1 = the F1 role alone, 2 = the suspect role alone
