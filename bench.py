@@ -332,6 +332,8 @@ def main():
     # at most `nb` distinct batches stay resident (all K when they fit in half of the free HBM); a larger K cycles over them
     free_b, _ = torch.cuda.mem_get_info(dev)
     nb = max(1, min(K, int(free_b * 0.5) // batch_bytes))
+    if K > 24:
+        nb = min(nb, 8)  # a long run (config 3: 100 steps per GPU) cycles over eight resident batches — one deferred launch's worth — instead of keeping 90 x 1.6 GB
     batches = []
     for s in range(nb):
         b = torch.empty(batch_bytes, dtype=torch.uint8, device=dev)
@@ -349,6 +351,12 @@ def main():
     base_flags = ((nt.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
                   | (nt.FLAG_LANE_KERNEL if args.lane_kernel else 0) | (nt.FLAG_ALWAYS_LOG if args.always_log else 0)
                   | (nt.FLAG_REQUIRE_TILED if tiled and nk == 1 and klist[0] == 32 and not args.gap and args.s_bits >= 7 and not args.lane_kernel else 0))
+
+    # a run whose sampled k-mers all fit a small log (sBits >= 11: 14.5 M per 125 M reads) does not need the default 4 GiB log + 8.9 GiB of partition scratch:
+    # 2^27 entries hold a rank's share of config 3 nine times over (512 MiB + 1.2 GiB); with the eight resident batches, the sketch and the hand-over arrays a
+    # rank of `--gpus 8 --config 3` stays under 20 GiB
+    if args.log_entries == 0 and args.s_bits >= 11 and K > 24:
+        args.log_entries = 1 << (27 if world > 1 else 28)  # (one GPU alone logs all 114 M keys of the 1 B reads)
 
     def make_engine(flags):
         return nt.Engine(klist, gap=args.gap, r_bits=args.r_bits, s_bits=args.s_bits, device=local_rank, stream=stream, ext_sketch=sketch, ext_f1=f1_dev,
@@ -506,6 +514,7 @@ def main():
             # N > 1: this rank's share of the one exchange step (inside the timed region): narrow to 16 bits / all-to-all of the slices / wrapping
             # sums / value histograms of the summed slice / histograms + F1 to rank 0
             "merge": (merge_t if use_dist else None),
+            "device_memory_used_gib": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 2**30, 2),  # this rank, behind the last repeat (everything resident)
             "f1_total": total_kmers,
             "sampled_increments": hits,
         }
