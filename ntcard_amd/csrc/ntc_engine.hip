@@ -925,6 +925,43 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 	bool launched_any = false;
 	const uint32_t wpg = ntc::sketch_k1h_waves();                                              // waves per workgroup (one workgroup per CU)
 	const uint32_t max_waves = (uint32_t)di.cus * wpg;
+	// what the hand-over arrays must hold for the most demanding k of the list: sized ONCE, before the first launch, so that an allocation failure can only
+	// come while nothing of these batches has been counted (a later k used to be able to fail behind an earlier k's launch)
+	size_t need_d_all = 0, need_t_all = 0;
+	uint32_t sus_cap_all = 0;
+	auto sus_cap_of = [&](uint32_t blocks_per_wave) {
+		// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
+		// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N).  The share: the
+		// blocks of a wave (plan_sketch_k1h: even shares of a workgroup's quota) + 1, all of
+		// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
+		// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
+		// 1 GiB per launch (beyond that a launch may still overflow: slow path, exact).  Round 6: the batches of ONE launch share one list — a wave's region is
+		// its number in the launch, and every batch is walked by waves of its own — so a launch over eight batches needs one list, not eight.
+		const double lone_blocks = (double)blocks_per_wave + 1.0;
+		const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
+		return (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 30) / 16u / max_waves));
+	};
+	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
+		const uint32_t k = e->klist[ki];
+		if (!e->k_tiled[ki]) continue;
+		ntc::K1hArgs hs0[ntc::kK1hSegs], pl0[ntc::kK1hSegs];
+		std::memset(hs0, 0, sizeof hs0);
+		uint32_t n0 = 0;
+		for (const auto& sg : segs)
+			if (sg.read_len >= k) {
+				hs0[n0].n_tiles = (uint32_t)((sg.n_reads + ntc::kTileReads - 1) / ntc::kTileReads);
+				hs0[n0].read_len = sg.read_len;
+				++n0;
+			}
+		if (n0 == 0) continue;
+		(void)ntc::plan_sketch_k1h(hs0, n0, k, (unsigned)di.cus, pl0);
+		for (uint32_t i = 0; i < n0; ++i) {
+			const uint32_t n_chunks = (hs0[i].read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, hs0[i].read_len);
+			need_d_all = std::max(need_d_all, (size_t)hs0[i].n_tiles * n_chunks * 256);
+			need_t_all = std::max(need_t_all, (size_t)hs0[i].n_tiles * nb * 256);
+			sus_cap_all = std::max(sus_cap_all, sus_cap_of(pl0[i].blocks_per_wave));
+		}
+	}
 	for (size_t ki = 0; ki < e->klist.size(); ++ki) {
 		const uint32_t k = e->klist[ki];
 		if (!e->k_tiled[ki]) continue; // K1's (below)
@@ -948,24 +985,9 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 			hs[i].read_len = act[i]->read_len;
 		}
 		(void)ntc::plan_sketch_k1h(hs, na, k, (unsigned)di.cus, planned);
-		// K1h + K1f: the two bit arrays between them and the suspect list are scratch of a launch pair; the sets of one launch are sized alike
-		size_t need_d = 0, need_t = 0;
-		uint32_t sus_cap = 0;
-		for (uint32_t i = 0; i < na; ++i) {
-			const uint32_t n_chunks = (act[i]->read_len + 15u) / 16u, nb = ntc::sketch_k1h_blocks(k, act[i]->read_len);
-			need_d = std::max(need_d, (size_t)hs[i].n_tiles * n_chunks * 256); // (< 2^32: larger batches were cut in two above)
-			need_t = std::max(need_t, (size_t)hs[i].n_tiles * nb * 256);
-			// Suspects per K1h wave: room for EVERY candidate of the wave's share (reads dense with non-base bytes make every candidate a suspect:
-			// with a short list the launch fell back to K1f's slow path — 15 ms per 10 M reads at 2 % N).  The share: the
-			// blocks of a wave (plan_sketch_k1h: even shares of a workgroup's quota) + 1, all of
-			// them full (2048 reads x 16 windows); ntComp's patterns pass 3 / 256 of the windows at sBits = 7, their 8-bit prefixes 2 / 256 at
-			// sBits >= 8 (ntcard.cpp:132-145), measured 1.3 x that on reads with 10 % N (ties ride along): x 1.5, + 1024, at least 2048, at most
-			// 1 GiB per launch (beyond that a launch may still overflow: slow path, exact).  Round 6: the batches of ONE launch share one list — a wave's region is
-			// its number in the launch, and every batch is walked by waves of its own — so a launch over eight batches needs one list, not eight.
-			const double lone_blocks = (double)planned[i].blocks_per_wave + 1.0;
-			const double per_block = 2048.0 * 16.0 * (e->s_bits == 7 ? 3.0 : 2.0) / 256.0;
-			sus_cap = std::max(sus_cap, (uint32_t)std::min<double>(std::max<double>(2048.0, 1.5 * lone_blocks * per_block + 1024.0), (double)((1ull << 30) / 16u / max_waves)));
-		}
+		// K1h + K1f: the two bit arrays between them and the suspect list are scratch of a launch pair; the sets are sized for the most demanding k (above)
+		const size_t need_d = need_d_all, need_t = need_t_all;
+		uint32_t sus_cap = sus_cap_all;
 		if (const char* ev = std::getenv("NTC_K1H_SUS_CAP")) { // tests: a short list forces the overflow path
 			const long v = std::strtol(ev, nullptr, 10);
 			if (v >= 1 && v <= (long)sus_cap) sus_cap = (uint32_t)v;
