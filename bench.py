@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--always-log", action="store_true", help="A/B: never switch from the hit log to direct atomics")
     ap.add_argument("--lane-kernel", action="store_true", help="A/B: the lane-per-read kernel K1 takes every batch (tiled ones re-laid out as row slots)")
     ap.add_argument("--k1h-timers", action="store_true", help="print the section clocks a K1H_EXP=timers build of K1h left behind F1 (stderr)")
+    ap.add_argument("--k1h-wave-clocks", action="store_true", help="print the spread of the per-wave first / last clocks a -DK1H_WAVE_CLOCKS build of K1h left behind (stderr; tools/k1h_variant.sh)")
     ap.add_argument("--layout", choices=["auto", "rows", "tiled"], default="auto",
                     help="slot layout of the resident batches: rows = one slot per read (ntc_submit_device: K1), tiled = the tiled layout "
                          "(ntc_submit_tiled_device: K1h + K1f); auto = tiled where K1h is built "
@@ -439,6 +440,32 @@ def main():
         tot = max(sum(tm), 1)
         print("k1h timers (clk summed over waves and launches): walk+test+push %d (%.1f%%), pack %d (%.1f%%), passes %d (%.1f%%), block end %d (%.1f%%)"
               % (tm[0], 100 * tm[0] / tot, tm[1], 100 * tm[1] / tot, tm[2], 100 * tm[2] / tot, tm[3], 100 * tm[3] / tot), file=sys.stderr)
+
+    if args.k1h_wave_clocks:
+        import ctypes
+        import numpy as np
+        wc = np.zeros(2 * 4096, dtype=np.uint64)
+        fn = getattr(nt._abi.lib(), "ntc_dbg_k1h_wave_clocks_p%d" % (klist[0] % 4))
+        fn.argtypes = [ctypes.c_void_p]
+        assert fn(wc.ctypes.data) == 0
+        if os.environ.get("K1H_WAVE_CLOCKS_OUT"):
+            np.save(os.environ["K1H_WAVE_CLOCKS_OUT"], wc)
+        t0s, t1s = wc[0::2].astype(np.int64), wc[1::2].astype(np.int64)
+        live = t1s > 0
+        t0s, t1s = t0s[live], t1s[live]
+        base, end = t0s.min(), t1s.max()
+        life = (t1s - t0s) / 100.0  # us (100 MHz)
+        fin = (t1s - base) / 100.0
+        q = lambda a, f: float(np.quantile(a, f))
+        print("k1h wave clocks of the last launch: %d waves, launch %.1f us from first start to last end; start spread %.1f us; wave life mean %.1f min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us; "
+              "finish time p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us; mean life / launch = %.3f"
+              % (len(life), (end - base) / 100.0, (t0s.max() - base) / 100.0, life.mean(), life.min(), q(life, .1), q(life, .5), q(life, .9), life.max(),
+                 q(fin, .01), q(fin, .1), q(fin, .5), q(fin, .9), q(fin, .99), fin.max(), life.mean() / ((end - base) / 100.0)), file=sys.stderr)
+        # by workgroup position: XCD = workgroup % 8 (round-robin dispatch), SIMD pair = wave % 4
+        wg = np.nonzero(live)[0] // 8
+        for x in range(8):
+            m = (wg % 8) == x
+            print("  xcd %d: mean finish %.1f us, mean life %.1f us" % (x, fin[m].mean(), life[m].mean()), file=sys.stderr)
 
     if rank == 0:
         import numpy as np

@@ -29,6 +29,9 @@ constexpr uint32_t kK1hWaves = K1H_GEN_WAVES;
 constexpr uint32_t kK1hWArea = K1H_GEN_WAREA;
 static_assert(kK1hWaves == 8, "the launch (512 threads: two waves on every SIMD) assumes eight waves per workgroup");
 constexpr uint32_t kK1hThreads = kK1hWaves * 64u;
+#ifndef K1H_OLD_SHARE
+#define K1H_OLD_SHARE 555u // (of 1024: the share of a SIMD pair's blocks that its older wave takes)
+#endif
 constexpr uint32_t kK1hTableOff = kK1hWaves * kK1hWArea;
 constexpr uint32_t k1h_table_bytes(uint32_t k) { return 2u * ((k + 2u) / 3u) * 256u; }
 constexpr uint32_t k1h_lds_bytes(uint32_t k) { return kK1hTableOff + k1h_table_bytes(k); } // the wave areas and the table
@@ -71,9 +74,16 @@ K1H_MY_VARIANTS(K1H_BODY_SPECS)
 
 } // namespace
 
+#ifdef K1H_WAVE_CLOCKS // timing experiment (tools/k1h_variant.sh, K1H_CXXFLAGS=-DK1H_WAVE_CLOCKS): every wave of the LAST launch leaves its first and last clock (100 MHz)
+static __device__ unsigned long long g_k1h_wave_clocks[2 * 4096];
+#endif
+
 template <int K, int SB, int GAP>
 __global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hMulti m)
 {
+#ifdef K1H_WAVE_CLOCKS
+	const unsigned long long wc_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 	extern __shared__ __align__(16) unsigned char smem[];
 	// the segment (batch) this workgroup walks: the segments own consecutive workgroup ranges (K1hMulti; a launch over one batch has one segment)
 	uint32_t s = 0;
@@ -94,9 +104,14 @@ __global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hMulti 
 	// are shared out evenly, as contiguous ranges of the flat sequence tile * NB + block of ITS segment.
 	const uint32_t bpw = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.blocks_per_wave);
 	const uint32_t wg_local = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x - a.first_wg));
+	// Round 6: the two waves of a SIMD are NOT equals — the SIMD issues the older wave first, and with equal shares waves 0 .. 3 (the first on their SIMDs)
+	// finished 13 % before waves 4 .. 7 in every workgroup of every launch (per-wave clocks of a -DK1H_WAVE_CLOCKS build, profiles/r06_k1h_wave_clocks.txt:
+	// 2775 against 3204 us of a 3.2 ms launch), which then ran alone at 0.8 of a pair's throughput.  The older waves take K1H_OLD_SHARE / 1024 of a pair's blocks.
 	const uint32_t quota = bpw * kK1hWaves, wg0 = wg_local * quota;
-	const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + wave * bpw));
-	const uint32_t end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + (wave + 1u) * bpw));
+	const uint32_t b_old = (2u * bpw * K1H_OLD_SHARE + 512u) >> 10, b_young = 2u * bpw - b_old;
+	const uint32_t my0 = wave < 4u ? wave * b_old : 4u * b_old + (wave - 4u) * b_young;
+	const uint32_t first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + my0));
+	const uint32_t end_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg0 + my0 + (wave < 4u ? b_old : b_young)));
 	const uint32_t wave_gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kK1hWaves + wave));
 #ifdef K1H_STATIC_PRIO // timing experiment (tools/k1h_variant.sh): the second wave of every SIMD runs at a fixed higher priority
 	if (wave >= 4) __builtin_amdgcn_s_setprio(K1H_STATIC_PRIO);
@@ -108,6 +123,12 @@ __global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hMulti 
 	const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)karg);
 	const uint32_t karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(karg >> 32));
 	K1hBody<K, SB, GAP>::run(karg_lo, karg_hi, wave_gid, n_waves, lds_wbase, first_block, end_block);
+#ifdef K1H_WAVE_CLOCKS
+	if ((threadIdx.x & 63u) == 0u && blockIdx.x * kK1hWaves + (threadIdx.x >> 6) < 4096u) {
+		g_k1h_wave_clocks[2u * (blockIdx.x * kK1hWaves + (threadIdx.x >> 6))] = wc_t0;
+		g_k1h_wave_clocks[2u * (blockIdx.x * kK1hWaves + (threadIdx.x >> 6)) + 1u] = __builtin_amdgcn_s_memrealtime();
+	}
+#endif
 }
 
 // ---- what ntc_sketch_k1h.hip calls: launch / shared-memory attribute of this part's kernels ----
@@ -128,6 +149,15 @@ hipError_t K1H_CAT(k1h_launch_part, K1H_PART)(uint32_t k, uint32_t gap, bool sb7
 	*found = false;
 	return hipSuccess;
 }
+
+#ifdef K1H_WAVE_CLOCKS
+} // namespace ntc
+extern "C" int K1H_CAT(ntc_dbg_k1h_wave_clocks_p, K1H_PART)(unsigned long long* out)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ntc::g_k1h_wave_clocks), sizeof(unsigned long long) * 2 * 4096);
+}
+namespace ntc {
+#endif
 
 hipError_t K1H_CAT(k1h_set_smem_part, K1H_PART)()
 {
