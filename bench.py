@@ -441,6 +441,14 @@ def main():
         print("k1h timers (clk summed over waves and launches): walk+test+push %d (%.1f%%), pack %d (%.1f%%), passes %d (%.1f%%), block end %d (%.1f%%)"
               % (tm[0], 100 * tm[0] / tot, tm[1], 100 * tm[1] / tot, tm[2], 100 * tm[2] / tot, tm[3], 100 * tm[3] / tot), file=sys.stderr)
 
+    if os.environ.get("NTC_SPLIT_CLOCKS_OUT"):
+        import ctypes
+        import numpy as np
+        sc = np.zeros(3 * 1024, dtype=np.uint64)
+        fn = nt._abi.lib().ntc_dbg_split_clocks
+        fn.argtypes = [ctypes.c_void_p]
+        assert fn(sc.ctypes.data) == 0
+        np.save(os.environ["NTC_SPLIT_CLOCKS_OUT"], sc)
     if args.k1h_wave_clocks:
         import ctypes
         import numpy as np

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ntc_kernels.hpp"
 
 namespace ntc {
@@ -51,22 +53,47 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 
 } // namespace
 
+// Packed runs between two partition passes (round 6): what the first pass leaves of a key — key_bits - b1 <= 21 bits — is written three to a 64-bit
+// word (bits 0 .. 20, 21 .. 41, 42 .. 62; bit 63: fewer than three keys, then bit 42 says "one" instead of "two"), 2.7 B per key written and read
+// instead of 4.  Every round pads the keys of a digit to whole words, so a word never mixes rounds and no run position is read back.
+constexpr uint32_t kPackBits = 21;
+constexpr uint32_t kPackMask = (1u << kPackBits) - 1u;
+__device__ __forceinline__ uint32_t pack_count(unsigned long long w) { return (w >> 63) ? ((w >> 42) & 1ull ? 1u : 2u) : 3u; }
+
 // A1/A2: partition the keys of this workgroup's input runs by digit = (key >> shift) & (2^bits - 1).
-template <uint32_t kSplitKeys>
-__global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
+#ifdef NTC_SPLIT_CLOCKS // timing experiment (tools/ab_build.sh <name> -DNTC_SPLIT_CLOCKS): first / last clock (100 MHz) and hardware id of every workgroup of the LAST second-pass launch
+__device__ unsigned long long g_split_clocks[3 * 1024];
+} // namespace ntc
+extern "C" int ntc_dbg_split_clocks(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ntc::g_split_clocks), sizeof(unsigned long long) * 3 * 1024); }
+namespace ntc {
+#endif
+
+template <uint32_t kSplitKeys, bool kPackIn, bool kPackOut>
+__device__ __forceinline__ void split_body(const SplitArgs& a)
 {
-	constexpr uint32_t kSplitRound = kSplitThreads * kSplitKeys;
-	// hist: digit counts of the round; excl: their exclusive scan; rel: gcur - excl (run offset of sorted position 0 of a
-	// digit); gcur: keys this workgroup has written per digit so far
-	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256];
-	__shared__ uint32_t sorted[kSplitRound];
+#ifdef NTC_SPLIT_CLOCKS
+	const unsigned long long sc_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+	// keys of one round: kSplitKeys per thread, or (packed input) kSplitKeys / 2 words of up to three (A/B: -DNTC_AB_SPLIT_WORDS_DIV=4 — one word per thread in
+	// the second pass — 546 against 476 us, profiles/r06_apply_packed_runs.txt)
+#ifndef NTC_AB_SPLIT_WORDS_DIV
+#define NTC_AB_SPLIT_WORDS_DIV 2
+#endif
+	constexpr uint32_t kWords = kSplitKeys / NTC_AB_SPLIT_WORDS_DIV;
+	constexpr uint32_t kPerThread = kPackIn ? 3u * kWords : kSplitKeys;
+	constexpr uint32_t kSplitRound = kSplitThreads * kPerThread;
+	// hist: digit counts of the round; excl: their exclusive scan (packed output: of the counts rounded up to whole words); rel: gcur - excl (run offset
+	// of sorted position 0 of a digit; packed output: in words); gcur: keys (words) this workgroup has written per digit so far; cntd: the round's counts
+	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256], cntd[256], tot[1];
+	__shared__ uint32_t sorted[kSplitRound + (kPackOut ? 2 * 256 : 0)]; // (+ the padding of a packed output's digits to whole words)
 	const uint32_t tid = threadIdx.x, w = blockIdx.x;
 	const uint32_t nb = 1u << a.bits, dmask = nb - 1u;
+	constexpr bool pack_out = kPackOut; // (SplitArgs::pack_out; a template parameter: the plain form must not pay scalar registers for it, see split_packed_kernel)
 	if (tid < 256) {
 		gcur[tid] = 0;
 		hist[tid] = 0;
 	}
-	uint32_t seg, step;
+	uint32_t seg, step, hi = 0;
 	if (a.mode == 0) {
 		seg = w;
 		step = gridDim.x;
@@ -74,70 +101,128 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 		const uint32_t b = w / a.parts, p = w % a.parts;
 		seg = p * a.nb_in + b;
 		step = a.parts * a.nb_in;
+		hi = b << a.hi_shift; // (packed input: the bits the first pass took, for the overflow fall-back's counter index)
 	}
-	uint32_t* const outw = a.out + (uint64_t)w * nb * a.out_cap;
-	uint16_t* const outw16 = reinterpret_cast<uint16_t*>(a.out) + (uint64_t)w * nb * a.out_cap;
+	// this workgroup's runs: uint32 keys, uint16 keys (narrow) or 64-bit words of three (pack_out: out_cap counts words) — ONE base pointer (scalar registers are
+	// what decides whether two of these workgroups fit a CU, see split_packed_kernel)
 	const bool narrow = a.narrow != 0;
+	const uint32_t esz_log = pack_out ? 3u : (narrow ? 1u : 2u);
+	unsigned char* const outb = reinterpret_cast<unsigned char*>(a.out) + (((uint64_t)w * nb * a.out_cap) << esz_log);
 	__syncthreads();
-	for (; seg < a.n_in; seg += step) {
-		uint32_t n = a.in_cnt[seg];
+	// mode 0 (log regions): workgroup w takes region (w + t) mod G of the t-th group of G regions, not always the w-th — K1h's wave g owns the regions g, g + W, ...
+	// and the first four waves of its workgroups log 18 % more than the last four (they walk more blocks: sketch_k1h_kernel), so with G a multiple of 8 the
+	// w-th region of every group comes from the same kind of wave
+	for (uint32_t t = 0;; ++t) {
+		if (a.mode == 0) {
+			if ((uint64_t)t * step >= a.n_in) break;
+			seg = t * step + (w + t) % step;
+			if (seg >= a.n_in) continue;
+		} else {
+			if (t) seg += step;
+			if (seg >= a.n_in) break;
+		}
+		uint32_t n = a.in_cnt[seg]; // keys, or words of a packed run
 		n = n < a.in_cap ? n : a.in_cap;
-		const uint32_t* src = a.in + (uint64_t)seg * a.in_cap;
-		uint32_t key[kSplitKeys], nxt[kSplitKeys];
-		auto fetch = [&](uint32_t base, uint32_t (&k)[kSplitKeys]) { // addresses clamped instead of predicated loads: branch-free, coalesced
+		using load_t = typename std::conditional<kPackIn, unsigned long long, uint32_t>::type;
+		const load_t* src = reinterpret_cast<const load_t*>(a.in) + (uint64_t)seg * a.in_cap;
+		constexpr uint32_t kLoads = kPackIn ? kWords : kSplitKeys;
+		constexpr uint32_t kLoadRound = kSplitThreads * kLoads;
+		load_t nxt[kLoads];
+		auto fetch = [&](uint32_t base) { // addresses clamped instead of predicated loads: branch-free, coalesced
 #pragma unroll
-			for (int j = 0; j < (int)kSplitKeys; ++j) {
+			for (int j = 0; j < (int)kLoads; ++j) {
 				const uint32_t i = base + (uint32_t)j * kSplitThreads + tid;
-				k[j] = src[i < n ? i : (n ? n - 1u : 0u)];
+				const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
+				nxt[j] = src[ic];
 			}
 		};
-		if (n) fetch(0, nxt);
-		for (uint32_t base = 0; base < n; base += kSplitRound) {
-			const uint32_t m = n - base < kSplitRound ? n - base : kSplitRound;
-			uint32_t rank[kSplitKeys];
+		if (n) fetch(0);
+		for (uint32_t base = 0; base < n; base += kLoadRound) {
+			const uint32_t m_in = n - base < kLoadRound ? n - base : kLoadRound;
+			uint32_t key[kPerThread], rank[kPerThread];
+			bool have[kPerThread];
 #pragma unroll
-			for (int j = 0; j < (int)kSplitKeys; ++j) {
-				key[j] = nxt[j];
+			for (int j = 0; j < (int)kLoads; ++j) {
 				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
-				// ONE returning LDS atomic per key gives both the digit count and the key's rank inside its digit
-				rank[j] = i < m ? atomicAdd(&hist[(key[j] >> a.shift) & dmask], 1u) : 0u;
+				if constexpr (kPackIn) {
+					const unsigned long long wd = nxt[j];
+					const uint32_t nv = i < m_in ? pack_count(wd) : 0u;
+#pragma unroll
+					for (int t = 0; t < 3; ++t) {
+						key[3 * j + t] = ((uint32_t)(wd >> (kPackBits * t)) & kPackMask) | hi;
+						have[3 * j + t] = (uint32_t)t < nv;
+					}
+				} else {
+					key[j] = (uint32_t)nxt[j];
+					have[j] = i < m_in;
+				}
 			}
-			if (base + kSplitRound < n) fetch(base + kSplitRound, nxt); // next round's keys are in flight during the sort
+#pragma unroll
+			for (int j = 0; j < (int)kPerThread; ++j) // ONE returning LDS atomic per key gives both the digit count and the key's rank inside its digit
+				rank[j] = have[j] ? atomicAdd(&hist[(key[j] >> a.shift) & dmask], 1u) : 0u;
+			if (base + kLoadRound < n) fetch(base + kLoadRound); // next round's keys are in flight during the sort
 			__syncthreads();
-			if (tid < 64) { // exclusive scan of the 256 digit counts
-				const uint32_t v0 = hist[4 * tid], v1 = hist[4 * tid + 1], v2 = hist[4 * tid + 2], v3 = hist[4 * tid + 3];
-				const uint32_t s = v0 + v1 + v2 + v3;
-				const uint32_t b0 = wave_incl_scan(s) - s;
-				excl[4 * tid] = b0;
-				excl[4 * tid + 1] = b0 + v0;
-				excl[4 * tid + 2] = b0 + v0 + v1;
-				excl[4 * tid + 3] = b0 + v0 + v1 + v2;
-				rel[4 * tid] = gcur[4 * tid] - b0;
-				rel[4 * tid + 1] = gcur[4 * tid + 1] - (b0 + v0);
-				rel[4 * tid + 2] = gcur[4 * tid + 2] - (b0 + v0 + v1);
-				rel[4 * tid + 3] = gcur[4 * tid + 3] - (b0 + v0 + v1 + v2);
+			if (tid < 64) { // exclusive scan of the 256 digit counts (packed output: rounded up to whole words of three)
+				uint32_t v[4], q[4];
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					v[t] = hist[4 * tid + t];
+					q[t] = pack_out ? (v[t] + 2u) / 3u * 3u : v[t];
+				}
+				const uint32_t s4 = q[0] + q[1] + q[2] + q[3];
+				const uint32_t incl = wave_incl_scan(s4);
+				uint32_t b0 = incl - s4;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					excl[4 * tid + t] = b0;
+					rel[4 * tid + t] = gcur[4 * tid + t] - (pack_out ? b0 / 3u : b0);
+					cntd[4 * tid + t] = v[t];
+					b0 += q[t];
+				}
+				if (tid == 63) tot[0] = incl;
 			}
 			__syncthreads();
 #pragma unroll
-			for (int j = 0; j < (int)kSplitKeys; ++j) {
-				const uint32_t i = (uint32_t)j * kSplitThreads + tid;
-				if (i < m) sorted[excl[(key[j] >> a.shift) & dmask] + rank[j]] = key[j];
-			}
+			for (int j = 0; j < (int)kPerThread; ++j)
+				if (have[j]) sorted[excl[(key[j] >> a.shift) & dmask] + rank[j]] = key[j];
 			if (tid < 256) { // every thread owns its digit's slots: book the round, clear the counts for the next one
-				gcur[tid] += hist[tid];
+				gcur[tid] += pack_out ? (hist[tid] + 2u) / 3u : hist[tid];
 				hist[tid] = 0;
 			}
 			__syncthreads();
-			for (uint32_t i = tid; i < m; i += kSplitThreads) {
-				const uint32_t kk = sorted[i];
-				const uint32_t off = rel[(kk >> a.shift) & dmask] + i;
-				if (off < a.out_cap) {
-					const uint64_t at = (uint64_t)((kk >> a.shift) & dmask) * a.out_cap + off;
-					if (narrow) outw16[at] = (uint16_t)kk;
-					else outw[at] = kk;
-				} else {
-					atomicAdd(a.sketch + kk, 1u); // run is full: apply directly (exact, slower)
-					if (a.sk_dirty) *a.sk_dirty = 1u;
+			const uint32_t m = tot[0];
+			if (pack_out) {
+				for (uint32_t j = tid; j < m / 3u; j += kSplitThreads) {
+					const uint32_t k0 = sorted[3u * j], k1 = sorted[3u * j + 1u], k2 = sorted[3u * j + 2u];
+					const uint32_t d = (k0 >> a.shift) & dmask;
+					const uint32_t left = cntd[d] - (3u * j - excl[d]); // keys of the digit from this word on
+					const uint32_t nv = left < 3u ? left : 3u;
+					const uint32_t off = rel[d] + j;
+					if (off < a.out_cap) {
+						unsigned long long wd = (unsigned long long)(k0 & kPackMask);
+						if (nv >= 2u) wd |= (unsigned long long)(k1 & kPackMask) << kPackBits;
+						if (nv == 3u) wd |= (unsigned long long)(k2 & kPackMask) << (2u * kPackBits);
+						else wd |= (1ull << 63) | (nv == 1u ? 1ull << 42 : 0ull);
+						reinterpret_cast<unsigned long long*>(outb)[(uint64_t)d * a.out_cap + off] = wd;
+					} else { // run is full: apply directly (exact, slower)
+						atomicAdd(a.sketch + k0, 1u);
+						if (nv >= 2u) atomicAdd(a.sketch + k1, 1u);
+						if (nv == 3u) atomicAdd(a.sketch + k2, 1u);
+						if (a.sk_dirty) *a.sk_dirty = 1u;
+					}
+				}
+			} else {
+				for (uint32_t i = tid; i < m; i += kSplitThreads) {
+					const uint32_t kk = sorted[i];
+					const uint32_t off = rel[(kk >> a.shift) & dmask] + i;
+					if (off < a.out_cap) {
+						const uint64_t at = (uint64_t)((kk >> a.shift) & dmask) * a.out_cap + off;
+						if (narrow) reinterpret_cast<uint16_t*>(outb)[at] = (uint16_t)kk;
+						else reinterpret_cast<uint32_t*>(outb)[at] = kk;
+					} else {
+						atomicAdd(a.sketch + kk, 1u); // run is full: apply directly (exact, slower)
+						if (a.sk_dirty) *a.sk_dirty = 1u;
+					}
 				}
 			}
 			__syncthreads(); // sorted / rel are rewritten by the next round
@@ -145,6 +230,27 @@ __global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
 	}
 	__syncthreads();
 	if (tid < nb) a.out_cnt[(uint64_t)w * nb + tid] = gcur[tid] < a.out_cap ? gcur[tid] : a.out_cap;
+#ifdef NTC_SPLIT_CLOCKS
+	if (threadIdx.x == 0 && a.mode == 1 && blockIdx.x < 1024u) {
+		const uint32_t w = blockIdx.x;
+		g_split_clocks[3 * w] = sc_t0;
+		g_split_clocks[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+		g_split_clocks[3 * w + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); // HW_ID, XCC_ID
+	}
+#endif
+}
+
+template <uint32_t kSplitKeys, bool kPackOut>
+__global__ __launch_bounds__(kSplitThreads) void split_kernel(const SplitArgs a)
+{
+	split_body<kSplitKeys, false, kPackOut>(a);
+}
+// (the packed-input form needed 81 + 6 SGPRs as the compiler allocated it: 96 per wave — and then only ONE workgroup of 1024 threads ran per CU instead of two,
+// measured with per-workgroup clocks: 512 workgroups in two rounds of 256, 0.86 ms for the pass instead of 0.5; the plain form at 78 runs two)
+template <uint32_t kSplitKeys>
+__global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_num_sgpr(80))) void split_packed_kernel(const SplitArgs a)
+{
+	split_body<kSplitKeys, true, false>(a);
 }
 
 // A3: one workgroup per slice of 2^slice_bits counters (<= 2^15): LDS histogram of the slice's keys, then
@@ -425,9 +531,19 @@ hipError_t launch_log_set_fill(uint32_t* fill, uint32_t n_regions, uint32_t regi
 
 hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st)
 {
-	static_assert(kSplitKeysMax == 8, "two instantiations");
-	if (a.bits >= 7) hipLaunchKernelGGL(split_kernel<8>, dim3(grid), dim3(kSplitThreads), 0, st, a);
-	else hipLaunchKernelGGL(split_kernel<4>, dim3(grid), dim3(kSplitThreads), 0, st, a);
+	static_assert(kSplitKeysMax == 8, "two sizes of a round");
+	if (a.pack_in) {
+		if (a.bits >= 7) hipLaunchKernelGGL(split_packed_kernel<8>, dim3(grid), dim3(kSplitThreads), 0, st, a);
+		else hipLaunchKernelGGL(split_packed_kernel<4>, dim3(grid), dim3(kSplitThreads), 0, st, a);
+	} else {
+		if (a.pack_out) {
+			if (a.bits >= 7) hipLaunchKernelGGL((split_kernel<8, true>), dim3(grid), dim3(kSplitThreads), 0, st, a);
+			else hipLaunchKernelGGL((split_kernel<4, true>), dim3(grid), dim3(kSplitThreads), 0, st, a);
+		} else {
+			if (a.bits >= 7) hipLaunchKernelGGL((split_kernel<8, false>), dim3(grid), dim3(kSplitThreads), 0, st, a);
+			else hipLaunchKernelGGL((split_kernel<4, false>), dim3(grid), dim3(kSplitThreads), 0, st, a);
+		}
+	}
 	return hipGetLastError();
 }
 

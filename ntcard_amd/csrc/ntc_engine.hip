@@ -538,6 +538,13 @@ int apply_log(ntc_engine* e)
 		s1.out_cap = ap.cap1;
 		s1.sketch = e->d_sketch;
 		s1.narrow = ap.b2 == 0;
+		// round 6: between two passes the keys travel three to a 64-bit word (what the first pass leaves of a key is <= 21 bits: 2.7 B per key written and
+		// read instead of 4; the run's capacity in words is half its capacity in keys — the same bytes)
+		const bool packed = ap.b2 != 0 && ap.key_bits - ap.b1 <= 21;
+		if (packed) {
+			s1.pack_out = 1;
+			s1.out_cap = ap.cap1 / 2;
+		}
 		HIP_TRY(ntc::launch_split(s1, ap.g1, e->stream));
 		if (ap.b2 == 0) {
 			c.in = e->d_s1;
@@ -566,6 +573,11 @@ int apply_log(ntc_engine* e)
 			s2.sketch = e->d_sketch;
 			s2.sk_dirty = e->d_skdirty;
 			s2.narrow = 1;
+			if (packed) {
+				s2.pack_in = 1;
+				s2.in_cap = ap.cap1 / 2;
+				s2.hi_shift = ap.key_bits - ap.b1;
+			}
 			HIP_TRY(ntc::launch_split(s2, nb1 * ap.parts2, e->stream));
 			c.in = e->d_s2;
 			c.in_cnt = e->d_c2;

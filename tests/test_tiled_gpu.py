@@ -44,10 +44,10 @@ class _DevArray:
 VARIANT_FLAGS = 0  # (rounds 3-4 ran every test of this module a second time through K1c, NTC_FLAG_TILED_TEAMS; round 5 retired that kernel)
 
 
-def run_tiled(nt, reads, L, k=32, r_bits=18, s_bits=7, flags=0, pieces=1):
+def run_tiled(nt, reads, L, k=32, r_bits=18, s_bits=7, flags=0, pieces=1, log_entries=0):
     # (K1h's table word holds r_bits + 1 + s_bits - 7 bits: a configuration beyond 32 is K1's, after a re-layout — the one case here that may fall back)
     req = nt.FLAG_REQUIRE_TILED if r_bits + 1 + s_bits - 7 <= 32 else 0
-    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | VARIANT_FLAGS | req) as e:
+    with nt.Engine([k], r_bits=r_bits, s_bits=s_bits, flags=flags | VARIANT_FLAGS | req, log_entries=log_entries) as e:
         step = (len(reads) + pieces - 1) // pieces
         keep = []
         for i in range(0, len(reads), step):
@@ -114,6 +114,15 @@ def test_tiled_batches_and_modes(nt):
     check(nt, reads, 150, pieces=3)
     check(nt, reads, 150, flags=nt.FLAG_DIRECT_ATOMICS)
     check(nt, reads, 150, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, pieces=2)
+
+
+@pytest.mark.parametrize("log_entries,pieces", [(0, 1), (1 << 18, 3), (1 << 20, 2)])
+def test_packed_runs_between_two_partition_passes(nt, log_entries, pieces):
+    """round 6: with two partition passes (r_bits = 24: 5 + 5 bits above the 2^15-counter slices) the first pass writes what it leaves of a key three to a
+    64-bit word and the second reads such words — words of one and two keys (small rounds), a read repeated 3000 times (its few counters overflow their
+    runs of a small log: the direct fall-back from both passes), several updates per engine (the first one writes, the later ones add)"""
+    reads = gen_host(3000, 150, 1) + [gen_host(1, 150, 0, seed=9)[0]] * 3000 + gen_host(500, 150, 0, seed=5)
+    check(nt, reads, 150, r_bits=24, flags=nt.FLAG_ALWAYS_LOG | nt.FLAG_PARTITION_ALWAYS, log_entries=log_entries, pieces=pieces)
 
 
 def test_first_apply_writes_and_later_ones_add(nt):
