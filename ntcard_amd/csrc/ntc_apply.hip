@@ -257,9 +257,19 @@ __global__ __launch_bounds__(kSplitThreads) __attribute__((amdgpu_num_sgpr(80)))
 // sketch[slice] += histogram.  The slice has exactly one writer, so the sweep needs no atomics.  The LDS counts are
 // 16 bits wide, two per dword (64 KiB per slice: two workgroups per CU overlap their phases); a pass takes at most
 // 65535 keys, so no count can carry into its neighbour, and a slice with more keys is done in several passes.
+// (round 6: the key width is a template parameter and the sweep has two straight-line forms.  As one body with `a.in16 ? ... : ...` per load and the sketch
+// loads behind `!fresh && ...` the compiler put a branch around every load and s_waitcnt vmcnt(0) in front of every key's LDS atomic and in front of EVERY
+// store of the sweep — eight stores per thread and slice, each waiting for the one before it to be acknowledged: the writes of a 64 KiB slice took as long as
+// its key phase.)
+#ifndef NTC_AB_COUNT_LOADS
+#define NTC_AB_COUNT_LOADS 8
+#endif
+constexpr uint32_t kCountLoads = NTC_AB_COUNT_LOADS;
+template <bool kIn16>
 __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 {
 	extern __shared__ __align__(16) uint32_t cnt[]; // [(1 << slice_bits) / 2]
+	using key_t = typename std::conditional<kIn16, uint16_t, uint32_t>::type;
 	const uint32_t tid = threadIdx.x, nt = blockDim.x;
 	const uint32_t n_cnt = 1u << a.slice_bits, cmask = n_cnt - 1u, n_words = n_cnt >> 1;
 	// the first apply behind a reset, and nothing has incremented the sketch directly: its counters are zero, so a slice's first pass WRITES its counts
@@ -298,29 +308,28 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 				uint32_t n = a.in_cnt[seg];
 				n = n < a.in_cap ? n : a.in_cap;
 				const uint32_t take = n - off < 65535u - taken ? n - off : 65535u - taken;
-				const uint32_t* src = a.in + (uint64_t)seg * a.in_cap + off;
-				const uint16_t* src16 = reinterpret_cast<const uint16_t*>(a.in) + (uint64_t)seg * a.in_cap + off;
-				// eight loads in flight per thread before the first LDS atomic (measured: no faster than one per turn; nor is a form that reads eight uint16
-				// keys per lane and load from up to four runs at once — profiles/r06_apply_kernels.txt — the pass is not bound by its key loads)
-				for (uint32_t base = 0; base < take; base += nt * 8u) {
-					uint32_t kq[8];
+				const key_t* src = reinterpret_cast<const key_t*>(a.in) + (uint64_t)seg * a.in_cap + off;
+				// kCountLoads loads in flight per thread before the first LDS atomic
+				for (uint32_t base = 0; base < take; base += nt * kCountLoads) {
+					uint32_t kq[kCountLoads];
 #pragma unroll
-					for (uint32_t j = 0; j < 8u; ++j) {
+					for (uint32_t j = 0; j < kCountLoads; ++j) {
 						const uint32_t i = base + j * nt + tid;
 						const uint32_t ic = i < take ? i : take - 1u; // (clamped address, not a predicated load)
-						kq[j] = a.in16 ? (uint32_t)src16[ic] : src[ic];
+						kq[j] = (uint32_t)src[ic];
 					}
 #pragma unroll
-					for (uint32_t j = 0; j < 8u; ++j) {
-						if (base + j * nt + tid >= take) continue;
+					for (uint32_t j = 0; j < kCountLoads; ++j) {
+						const bool have = base + j * nt + tid < take;
 						const uint32_t kk = kq[j] & cmask;
 						// hot counters (a few thousand distinct k-mers sampled at huge coverage: every key of a run is the same) would put all 64
 						// lanes on one LDS word, 64 serialised atomics per instruction: a wave whose keys are all equal adds their number once
-						const uint64_t act = __ballot(true);
-						const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)kk);
-						if (__ballot(kk == first) == act) {
+						const uint64_t act = __ballot(have);
+						if (act == 0) continue; // (wave-uniform)
+						const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)kk, __builtin_ctzll(act));
+						if (__ballot(have && kk == first) == act) {
 							if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&cnt[kk >> 1], (uint32_t)__popcll(act) << ((kk & 1u) * 16u));
-						} else {
+						} else if (have) {
 							atomicAdd(&cnt[kk >> 1], 1u << ((kk & 1u) * 16u));
 						}
 					}
@@ -334,31 +343,47 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 			}
 			__syncthreads();
 			if (taken != 0) {
-				// 2 dwords of LDS = 4 counters = one uint4 of the sketch; four groups per thread and turn, their sketch words loaded together
-				for (uint32_t i0 = tid; i0 < n_words / 2; i0 += nt * 4u) {
-					uint2 c[4];
-					uint4 s4[4];
+				// 2 dwords of LDS = 4 counters = one uint4 of the sketch; four groups per thread and turn
+				if (fresh) { // write-only: no load anywhere, the stores need not wait for each other
+					for (uint32_t i0 = tid; i0 < n_words / 2; i0 += nt * 4u) {
+						uint2 c[4];
 #pragma unroll
-					for (uint32_t j = 0; j < 4u; ++j) {
-						const uint32_t i = i0 + j * nt;
-						c[j] = i < n_words / 2 ? reinterpret_cast<const uint2*>(cnt)[i] : make_uint2(0, 0);
-						if ((c[j].x | c[j].y) != 0u) reinterpret_cast<uint2*>(cnt)[i] = make_uint2(0, 0);
+						for (uint32_t j = 0; j < 4u; ++j) {
+							const uint32_t i = i0 + j * nt;
+							c[j] = i < n_words / 2 ? reinterpret_cast<const uint2*>(cnt)[i] : make_uint2(0, 0);
+						}
+#pragma unroll
+						for (uint32_t j = 0; j < 4u; ++j) {
+							const uint32_t i = i0 + j * nt;
+							if ((c[j].x | c[j].y) != 0u) {
+								reinterpret_cast<uint2*>(cnt)[i] = make_uint2(0, 0);
+								reinterpret_cast<uint4*>(dst)[i] = make_uint4(c[j].x & 0xffffu, c[j].x >> 16, c[j].y & 0xffffu, c[j].y >> 16);
+							}
+						}
 					}
+				} else { // read-modify-write: the four groups' sketch words loaded together (a group without a key is loaded too — clamped, not predicated — and left alone)
+					for (uint32_t i0 = tid; i0 < n_words / 2; i0 += nt * 4u) {
+						uint2 c[4];
+						uint4 s4[4];
 #pragma unroll
-					for (uint32_t j = 0; j < 4u; ++j) {
-						const uint32_t i = i0 + j * nt;
-						s4[j] = (!fresh && (c[j].x | c[j].y) != 0u) ? reinterpret_cast<const uint4*>(dst)[i] : make_uint4(0, 0, 0, 0);
-					}
+						for (uint32_t j = 0; j < 4u; ++j) {
+							const uint32_t i = i0 + j * nt;
+							const uint32_t ic = i < n_words / 2 ? i : n_words / 2 - 1u;
+							c[j] = i < n_words / 2 ? reinterpret_cast<const uint2*>(cnt)[i] : make_uint2(0, 0);
+							s4[j] = reinterpret_cast<const uint4*>(dst)[ic];
+						}
 #pragma unroll
-					for (uint32_t j = 0; j < 4u; ++j) {
-						const uint32_t i = i0 + j * nt;
-						if ((c[j].x | c[j].y) != 0u) {
-							uint4 s = s4[j];
-							s.x += c[j].x & 0xffffu;
-							s.y += c[j].x >> 16;
-							s.z += c[j].y & 0xffffu;
-							s.w += c[j].y >> 16;
-							reinterpret_cast<uint4*>(dst)[i] = s;
+						for (uint32_t j = 0; j < 4u; ++j) {
+							const uint32_t i = i0 + j * nt;
+							if ((c[j].x | c[j].y) != 0u) {
+								reinterpret_cast<uint2*>(cnt)[i] = make_uint2(0, 0);
+								uint4 s = s4[j];
+								s.x += c[j].x & 0xffffu;
+								s.y += c[j].x >> 16;
+								s.z += c[j].y & 0xffffu;
+								s.w += c[j].y >> 16;
+								reinterpret_cast<uint4*>(dst)[i] = s;
+							}
 						}
 					}
 				}
@@ -550,13 +575,17 @@ hipError_t launch_split(const SplitArgs& a, unsigned grid, hipStream_t st)
 hipError_t launch_count(const CountArgs& a, unsigned grid, hipStream_t st)
 {
 	const size_t smem = (sizeof(uint32_t) << a.slice_bits) / 2;
-	hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(a.slice_bits >= 15 ? 1024 : 512), smem, st, a); // (two workgroups of 1024 threads or four of 512 per CU)
+	// (two workgroups of 1024 threads or four of 512 per CU)
+	if (a.in16) hipLaunchKernelGGL(count_kernel<true>, dim3(grid), dim3(a.slice_bits >= 15 ? 1024 : 512), smem, st, a);
+	else hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(a.slice_bits >= 15 ? 1024 : 512), smem, st, a);
 	return hipGetLastError();
 }
 
 hipError_t set_apply_smem_limit()
 {
-	return hipFuncSetAttribute(reinterpret_cast<const void*>(&count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+	hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&count_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+	if (rc == hipSuccess) rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&count_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+	return rc;
 }
 
 } // namespace ntc
