@@ -271,6 +271,10 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 	extern __shared__ __align__(16) uint32_t cnt[]; // [(1 << slice_bits) / 2]
 	using key_t = typename std::conditional<kIn16, uint16_t, uint32_t>::type;
 	const uint32_t tid = threadIdx.x, nt = blockDim.x;
+	// the run lengths through the scalar cache (they are uniform, and written by the kernel before this one): a vector load's s_waitcnt vmcnt(0) would also wait
+	// for every store of the previous slice's sweep — the counter is in order — four dependent round trips per slice
+	typedef const __attribute__((address_space(4))) uint32_t* scalar_ptr;
+	const scalar_ptr in_cnt = (scalar_ptr)(uintptr_t)a.in_cnt;
 	const uint32_t n_cnt = 1u << a.slice_bits, cmask = n_cnt - 1u, n_words = n_cnt >> 1;
 	// the first apply behind a reset, and nothing has incremented the sketch directly: its counters are zero, so a slice's first pass WRITES its counts
 	// (no read: half the sweep's traffic) and leaves the groups it has no key for alone
@@ -299,13 +303,13 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 		}
 		uint32_t* dst = a.sketch + ((uint64_t)slice << a.slice_bits);
 		uint32_t t = 0, off = 0; // next run, and how much of it earlier passes took (a run longer than one pass is taken in pieces)
-		while (t < seg_cnt && a.in_cnt[t * seg_mul + seg_add] == 0u) // leading empty runs (an empty log costs no LDS traffic at all)
+		while (t < seg_cnt && in_cnt[t * seg_mul + seg_add] == 0u) // leading empty runs (an empty log costs no LDS traffic at all)
 			++t;
 		while (t < seg_cnt) {
 			uint32_t taken = 0; // keys of this pass (the same for every thread): at most 65535, so that no 16-bit count wraps into its neighbour
 			while (t < seg_cnt && taken < 65535u) {
 				const uint32_t seg = t * seg_mul + seg_add;
-				uint32_t n = a.in_cnt[seg];
+				uint32_t n = in_cnt[seg];
 				n = n < a.in_cap ? n : a.in_cap;
 				const uint32_t take = n - off < 65535u - taken ? n - off : 65535u - taken;
 				const key_t* src = reinterpret_cast<const key_t*>(a.in) + (uint64_t)seg * a.in_cap + off;
