@@ -60,7 +60,13 @@ constexpr uint32_t kPackBits = 21;
 constexpr uint32_t kPackMask = (1u << kPackBits) - 1u;
 __device__ __forceinline__ uint32_t pack_count(unsigned long long w) { return (w >> 63) ? ((w >> 42) & 1ull ? 1u : 2u) : 3u; }
 
-// A1/A2: partition the keys of this workgroup's input runs by digit = (key >> shift) & (2^bits - 1).
+// A1/A2: partition the keys of this workgroup's input runs by digit = (key >> shift) & (2^bits - 1).  kPackOut: the runs are written packed (the first of two
+// passes); kPackIn: the input runs are packed (the second).
+//
+// Round 6, "flat rounds": the lengths of ALL of a workgroup's input runs are fetched at once into LDS (up to 256 at a time), and the round that is being sorted
+// always has the NEXT round's keys in flight — the next keys of the same run or the first ones of the next run that holds any.  Before, every run cost two
+// exposed round trips to memory, its length and then its first keys, one after the other: 68 regions per workgroup in the first pass (a third of them hold
+// keys), 64 runs in the second, ~2 us each.
 #ifdef NTC_SPLIT_CLOCKS // timing experiment (tools/ab_build.sh <name> -DNTC_SPLIT_CLOCKS): first / last clock (100 MHz) and hardware id of every workgroup of the LAST second-pass launch
 __device__ unsigned long long g_split_clocks[3 * 1024];
 } // namespace ntc
@@ -82,9 +88,12 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 	constexpr uint32_t kWords = kSplitKeys / NTC_AB_SPLIT_WORDS_DIV;
 	constexpr uint32_t kPerThread = kPackIn ? 3u * kWords : kSplitKeys;
 	constexpr uint32_t kSplitRound = kSplitThreads * kPerThread;
+	constexpr uint32_t kLoads = kPackIn ? kWords : kSplitKeys;
+	constexpr uint32_t kLoadRound = kSplitThreads * kLoads;
+	constexpr uint32_t kRunChunk = 256; // run lengths held in LDS at a time
 	// hist: digit counts of the round; excl: their exclusive scan (packed output: of the counts rounded up to whole words); rel: gcur - excl (run offset
 	// of sorted position 0 of a digit; packed output: in words); gcur: keys (words) this workgroup has written per digit so far; cntd: the round's counts
-	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256], cntd[256], tot[1];
+	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256], cntd[kPackOut ? 256 : 1], run_n[kRunChunk], tot[1];
 	__shared__ uint32_t sorted[kSplitRound + (kPackOut ? 2 * 256 : 0)]; // (+ the padding of a packed output's digits to whole words)
 	const uint32_t tid = threadIdx.x, w = blockIdx.x;
 	const uint32_t nb = 1u << a.bits, dmask = nb - 1u;
@@ -93,52 +102,69 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 		gcur[tid] = 0;
 		hist[tid] = 0;
 	}
-	uint32_t seg, step, hi = 0;
+	// The t-th input run of this workgroup.  mode 0 (log regions): region (w + t) mod G of the t-th group of G = gridDim.x regions, not always the w-th — K1h's
+	// wave g owns the regions g, g + W, ... and the first four waves of its workgroups log 18 % more than the last four (they walk more blocks:
+	// sketch_k1h_kernel), so with G a multiple of 8 the w-th region of every group comes from the same kind of wave.  mode 1: the runs (w1, b), w1 = p, p + parts, ...
+	uint32_t seg0, step, n_t, hi = 0;
 	if (a.mode == 0) {
-		seg = w;
+		seg0 = 0;
 		step = gridDim.x;
+		n_t = (a.n_in + step - 1u) / step;
 	} else {
 		const uint32_t b = w / a.parts, p = w % a.parts;
-		seg = p * a.nb_in + b;
+		seg0 = p * a.nb_in + b;
 		step = a.parts * a.nb_in;
+		n_t = seg0 < a.n_in ? (a.n_in - seg0 + step - 1u) / step : 0u;
 		hi = b << a.hi_shift; // (packed input: the bits the first pass took, for the overflow fall-back's counter index)
 	}
+	auto seg_of = [&](uint32_t t) -> uint32_t {
+#ifdef NTC_AB_OLD_ORDER
+		return a.mode == 0 ? t * step + w : seg0 + t * step;
+#else
+		return a.mode == 0 ? t * step + (w + t) % step : seg0 + t * step;
+#endif
+	};
 	// this workgroup's runs: uint32 keys, uint16 keys (narrow) or 64-bit words of three (pack_out: out_cap counts words) — ONE base pointer (scalar registers are
 	// what decides whether two of these workgroups fit a CU, see split_packed_kernel)
 	const bool narrow = a.narrow != 0;
 	const uint32_t esz_log = pack_out ? 3u : (narrow ? 1u : 2u);
 	unsigned char* const outb = reinterpret_cast<unsigned char*>(a.out) + (((uint64_t)w * nb * a.out_cap) << esz_log);
-	__syncthreads();
-	// mode 0 (log regions): workgroup w takes region (w + t) mod G of the t-th group of G regions, not always the w-th — K1h's wave g owns the regions g, g + W, ...
-	// and the first four waves of its workgroups log 18 % more than the last four (they walk more blocks: sketch_k1h_kernel), so with G a multiple of 8 the
-	// w-th region of every group comes from the same kind of wave
-	for (uint32_t t = 0;; ++t) {
-		if (a.mode == 0) {
-			if ((uint64_t)t * step >= a.n_in) break;
-			seg = t * step + (w + t) % step;
-			if (seg >= a.n_in) continue;
-		} else {
-			if (t) seg += step;
-			if (seg >= a.n_in) break;
+	using load_t = typename std::conditional<kPackIn, unsigned long long, uint32_t>::type;
+	for (uint32_t t0 = 0; t0 < n_t; t0 += kRunChunk) {
+		const uint32_t t_end = n_t - t0 < kRunChunk ? n_t : t0 + kRunChunk;
+		__syncthreads(); // (run_n of the chunk before is spent; first chunk: gcur / hist are set)
+		if (tid < kRunChunk && t0 + tid < t_end) {
+			const uint32_t sg = seg_of(t0 + tid);
+			const uint32_t n = sg < a.n_in ? a.in_cnt[sg] : 0u; // keys, or words of a packed run
+			run_n[tid] = n < a.in_cap ? n : a.in_cap;
 		}
-		uint32_t n = a.in_cnt[seg]; // keys, or words of a packed run
-		n = n < a.in_cap ? n : a.in_cap;
-		using load_t = typename std::conditional<kPackIn, unsigned long long, uint32_t>::type;
-		const load_t* src = reinterpret_cast<const load_t*>(a.in) + (uint64_t)seg * a.in_cap;
-		constexpr uint32_t kLoads = kPackIn ? kWords : kSplitKeys;
-		constexpr uint32_t kLoadRound = kSplitThreads * kLoads;
+		__syncthreads();
+		auto next_run = [&](uint32_t t) -> uint32_t { // the first run from t on that holds anything (t_end: none)
+			while (t < t_end && run_n[t - t0] == 0u)
+				++t;
+			return t;
+		};
 		load_t nxt[kLoads];
-		auto fetch = [&](uint32_t base) { // addresses clamped instead of predicated loads: branch-free, coalesced
+		auto fetch = [&](uint32_t t, uint32_t base) { // addresses clamped instead of predicated loads: branch-free, coalesced
+			const uint32_t n = run_n[t - t0];
+			const load_t* src = reinterpret_cast<const load_t*>(a.in) + (uint64_t)seg_of(t) * a.in_cap;
 #pragma unroll
 			for (int j = 0; j < (int)kLoads; ++j) {
 				const uint32_t i = base + (uint32_t)j * kSplitThreads + tid;
-				const uint32_t ic = i < n ? i : (n ? n - 1u : 0u);
-				nxt[j] = src[ic];
+				nxt[j] = src[i < n ? i : n - 1u];
 			}
 		};
-		if (n) fetch(0);
-		for (uint32_t base = 0; base < n; base += kLoadRound) {
+		uint32_t t = next_run(t0), base = 0;
+		if (t < t_end) fetch(t, 0);
+		while (t < t_end) {
+			const uint32_t n = run_n[t - t0];
 			const uint32_t m_in = n - base < kLoadRound ? n - base : kLoadRound;
+			// the round after this one: the same run's next keys, or the next run's first
+			uint32_t tn = t, basen = base + kLoadRound;
+			if (basen >= n) {
+				tn = next_run(t + 1u);
+				basen = 0;
+			}
 			uint32_t key[kPerThread], rank[kPerThread];
 			bool have[kPerThread];
 #pragma unroll
@@ -148,9 +174,9 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 					const unsigned long long wd = nxt[j];
 					const uint32_t nv = i < m_in ? pack_count(wd) : 0u;
 #pragma unroll
-					for (int t = 0; t < 3; ++t) {
-						key[3 * j + t] = ((uint32_t)(wd >> (kPackBits * t)) & kPackMask) | hi;
-						have[3 * j + t] = (uint32_t)t < nv;
+					for (int q = 0; q < 3; ++q) {
+						key[3 * j + q] = ((uint32_t)(wd >> (kPackBits * q)) & kPackMask) | hi;
+						have[3 * j + q] = (uint32_t)q < nv;
 					}
 				} else {
 					key[j] = (uint32_t)nxt[j];
@@ -160,24 +186,24 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 #pragma unroll
 			for (int j = 0; j < (int)kPerThread; ++j) // ONE returning LDS atomic per key gives both the digit count and the key's rank inside its digit
 				rank[j] = have[j] ? atomicAdd(&hist[(key[j] >> a.shift) & dmask], 1u) : 0u;
-			if (base + kLoadRound < n) fetch(base + kLoadRound); // next round's keys are in flight during the sort
+			if (tn < t_end) fetch(tn, basen); // the next round's keys are in flight during the sort
 			__syncthreads();
 			if (tid < 64) { // exclusive scan of the 256 digit counts (packed output: rounded up to whole words of three)
 				uint32_t v[4], q[4];
 #pragma unroll
-				for (int t = 0; t < 4; ++t) {
-					v[t] = hist[4 * tid + t];
-					q[t] = pack_out ? (v[t] + 2u) / 3u * 3u : v[t];
+				for (int u = 0; u < 4; ++u) {
+					v[u] = hist[4 * tid + u];
+					q[u] = pack_out ? (v[u] + 2u) / 3u * 3u : v[u];
 				}
 				const uint32_t s4 = q[0] + q[1] + q[2] + q[3];
 				const uint32_t incl = wave_incl_scan(s4);
 				uint32_t b0 = incl - s4;
 #pragma unroll
-				for (int t = 0; t < 4; ++t) {
-					excl[4 * tid + t] = b0;
-					rel[4 * tid + t] = gcur[4 * tid + t] - (pack_out ? b0 / 3u : b0);
-					cntd[4 * tid + t] = v[t];
-					b0 += q[t];
+				for (int u = 0; u < 4; ++u) {
+					excl[4 * tid + u] = b0;
+					rel[4 * tid + u] = gcur[4 * tid + u] - (pack_out ? b0 / 3u : b0);
+					if constexpr (kPackOut) cntd[4 * tid + u] = v[u];
+					b0 += q[u];
 				}
 				if (tid == 63) tot[0] = incl;
 			}
@@ -191,7 +217,7 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 			}
 			__syncthreads();
 			const uint32_t m = tot[0];
-			if (pack_out) {
+			if constexpr (kPackOut) {
 				for (uint32_t j = tid; j < m / 3u; j += kSplitThreads) {
 					const uint32_t k0 = sorted[3u * j], k1 = sorted[3u * j + 1u], k2 = sorted[3u * j + 2u];
 					const uint32_t d = (k0 >> a.shift) & dmask;
@@ -226,13 +252,14 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 				}
 			}
 			__syncthreads(); // sorted / rel are rewritten by the next round
+			t = tn;
+			base = basen;
 		}
 	}
 	__syncthreads();
 	if (tid < nb) a.out_cnt[(uint64_t)w * nb + tid] = gcur[tid] < a.out_cap ? gcur[tid] : a.out_cap;
 #ifdef NTC_SPLIT_CLOCKS
 	if (threadIdx.x == 0 && a.mode == 1 && blockIdx.x < 1024u) {
-		const uint32_t w = blockIdx.x;
 		g_split_clocks[3 * w] = sc_t0;
 		g_split_clocks[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
 		g_split_clocks[3 * w + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); // HW_ID, XCC_ID
@@ -365,16 +392,16 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 							}
 						}
 					}
-				} else { // read-modify-write: the four groups' sketch words loaded together (a group without a key is loaded too — clamped, not predicated — and left alone)
+				} else { // read-modify-write: the four groups' sketch words loaded together; a group without a key loads the slice's first word instead of its own (one
+				         // cached line for all of them, no branch): a slice with a handful of keys — the other planes of a multi-k sketch — must not read 128 KiB
 					for (uint32_t i0 = tid; i0 < n_words / 2; i0 += nt * 4u) {
 						uint2 c[4];
 						uint4 s4[4];
 #pragma unroll
 						for (uint32_t j = 0; j < 4u; ++j) {
 							const uint32_t i = i0 + j * nt;
-							const uint32_t ic = i < n_words / 2 ? i : n_words / 2 - 1u;
 							c[j] = i < n_words / 2 ? reinterpret_cast<const uint2*>(cnt)[i] : make_uint2(0, 0);
-							s4[j] = reinterpret_cast<const uint4*>(dst)[ic];
+							s4[j] = reinterpret_cast<const uint4*>(dst)[(c[j].x | c[j].y) != 0u ? i : 0u];
 						}
 #pragma unroll
 						for (uint32_t j = 0; j < 4u; ++j) {

@@ -32,7 +32,7 @@ for case in range(n_cases):
         klist = [k]
     else:
         klist = sorted(set(rng.choice([rng.randint(1, 40), rng.randint(12, 32), rng.randint(1, 200), rng.choice([12, 16, 31, 32, 33, 64, 96, 128])]) for _ in range(rng.choice([1, 1, 2, 4, 6]))))
-    s_bits, r_bits = rng.choice([2, 3, 5, 7, 7, 8, 11]), rng.choice([12, 16, 18])
+    s_bits, r_bits = rng.choice([2, 3, 5, 7, 7, 8, 11]), rng.choice([12, 16, 18, 23])
     mode = rng.choice(["equal", "equal", "two", "ragged", "long"])
     L = rng.choice([rng.randint(1, 300), 100, 150, 151, 250])
     n = rng.choice([70, 500, 3000, 3000, 40000])  # (40000: with NTC_BIN_MIN=1024 in the environment the length bins of a ragged batch take the tiled kernels, several per launch)

@@ -32,7 +32,7 @@ def ragged_case(case):
     else:
         klist, gap = sorted(set(int(x) for x in rng.integers(12, 33, size=int(rng.choice([1, 1, 2, 3]))))), 0
     s_bits = int(rng.choice([7, 7, 8, 11]))
-    r_bits = int(rng.choice([12, 16, 20]))
+    r_bits = int(rng.choice([12, 16, 20, 23]))
     p_bad = float(rng.choice([0.0, 0.0005, 0.005, 0.05]))
     flags = nt.FLAG_REQUIRE_TILED | (nt.FLAG_DEFER_REDO if rng.random() < 0.5 else 0)
     log_entries = int(rng.choice([0, 1 << 18, 1 << 20]))
@@ -92,7 +92,7 @@ for case in range(n_cases):
     else:
         klist = sorted(set(int(x) for x in rng.integers(12, 33, size=int(rng.choice([1, 1, 1, 2, 3])))))
     s_bits = int(rng.choice([7, 7, 8, 9, 11, 14]))
-    r_bits = int(rng.choice([12, 16, 20]))
+    r_bits = int(rng.choice([12, 16, 20, 23]))
     L = int(rng.choice([int(rng.integers(max(klist), 401)), 100, 150, 151, 250]))
     p_bad = float(rng.choice([0.0, 0.0005, 0.005, 0.05]))
     slot_bytes = (not teams) and rng.random() < 0.2
