@@ -185,7 +185,7 @@ def live_pmc(argv_inner, n_steps):
                             continue
                         kn = row["Kernel_Name"]
                         is_hash = any(x in kn for x in ("sketch_hf_kernel", "sketch_bs_kernel", "sketch_ts_kernel", "sketch_k1h_kernel", "k1h_fix_kernel", "k1h_slow_kernel", "append_slots"))
-                        is_apply = any(x in kn for x in ("split_kernel", "count_kernel", "log_atomics", "log_total", "log_probe", "log_decide"))
+                        is_apply = any(x in kn for x in ("split_kernel", "split_packed_kernel", "count_kernel", "log_atomics", "log_total", "log_probe", "log_decide"))
                         if is_hash or is_apply:
                             tot += float(row["Counter_Value"])
                             seen += 1
@@ -529,7 +529,7 @@ def main():
                        "rccl_ranks": dist.get_world_size() if use_dist else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, R),
-                         "kernel": kern + " + split_kernel / count_kernel (deferred sketch update)",
+                         "kernel": kern + " + split_kernel / split_packed_kernel / count_kernel (deferred sketch update)",
                          "avg_launch_ms": step_ms, "hash_ms": hash_ms, "apply_ms": apply_ms / max(K, 1), "fixup_ms": fix_ms / max(K, 1), "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kmers_per_launch": per_step_kmers},

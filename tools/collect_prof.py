@@ -49,14 +49,14 @@ def main():
                              (r["Name"][:48], int(r["Calls"]), n_trace, bench["warmup"], bench.get("repeats", 1), bench["steps"], float(r["TotalDurationNs"]) / n_trace / 1e6))
     hash_kernels, apply_kernels = {}, {}
     for k, v in agg.items():
-        if any(t in k for t in ("sketch_", "k1h_", "split_kernel", "count_kernel", "finalize")):
+        if any(t in k for t in ("sketch_", "k1h_", "split_kernel", "split_packed_kernel", "count_kernel", "finalize")):
             lines.append(f"== counters (separate --pmc passes), mean per dispatch | per bench step: {k}")
             for c, vals in sorted(v.items()):
                 per_step = ("%18.1f" % (sum(vals) / n_steps)) if n_steps else "-"
                 lines.append("  %-28s %18.1f  n=%d | %s" % (c, sum(vals) / len(vals), len(vals), per_step))
             if "sketch_" in k or "k1h_" in k:
                 hash_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
-            elif any(t in k for t in ("split_kernel", "count_kernel", "log_")):
+            elif any(t in k for t in ("split_kernel", "split_packed_kernel", "count_kernel", "log_")):
                 apply_kernels[k] = {c: sum(vals) / (n_steps or len(vals)) for c, vals in v.items()}
     open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
     # traffic entry: 2*FETCH_SIZE + WRITE_SIZE (KB) per bench step of the hash kernels (K1h + K1f, or K1) AND of the sketch-update kernels (split / count /
