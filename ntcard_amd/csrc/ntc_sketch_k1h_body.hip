@@ -101,12 +101,12 @@ __global__ __launch_bounds__(kK1hThreads) void sketch_k1h_kernel(const K1hMulti 
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	__syncthreads();
 	// Eight waves, two on every SIMD (round 4 ran six — two pairs and two lone waves — and weighed their shares by who sat alone): the workgroup's blocks
-	// are shared out evenly, as contiguous ranges of the flat sequence tile * NB + block of ITS segment.
+	// are shared out as contiguous ranges of the flat sequence tile * NB + block of ITS segment, a larger one for the first wave of every SIMD (below).
 	const uint32_t bpw = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.blocks_per_wave);
 	const uint32_t wg_local = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x - a.first_wg));
 	// Round 6: the two waves of a SIMD are NOT equals — the SIMD issues the older wave first, and with equal shares waves 0 .. 3 (the first on their SIMDs)
 	// finished 13 % before waves 4 .. 7 in every workgroup of every launch (per-wave clocks of a -DK1H_WAVE_CLOCKS build, profiles/r06_k1h_wave_clocks.txt:
-	// 2775 against 3204 us of a 3.2 ms launch), which then ran alone at 0.8 of a pair's throughput.  The older waves take K1H_OLD_SHARE / 1024 of a pair's blocks.
+	// 2775 against 3204 us of a 3.2 ms launch), which then ran alone at half a pair's throughput (the older wave of a pair runs as fast as a wave alone, the younger at 0.83 of that).  The older waves take K1H_OLD_SHARE / 1024 of a pair's blocks.
 	const uint32_t quota = bpw * kK1hWaves, wg0 = wg_local * quota;
 	const uint32_t b_old = (2u * bpw * K1H_OLD_SHARE + 512u) >> 10, b_young = 2u * bpw - b_old;
 	const uint32_t my0 = wave < 4u ? wave * b_old : 4u * b_old + (wave - 4u) * b_young;
