@@ -90,7 +90,10 @@ __device__ __forceinline__ void split_body(const SplitArgs& a)
 	constexpr uint32_t kSplitRound = kSplitThreads * kPerThread;
 	constexpr uint32_t kLoads = kPackIn ? kWords : kSplitKeys;
 	constexpr uint32_t kLoadRound = kSplitThreads * kLoads;
-	constexpr uint32_t kRunChunk = 256; // run lengths held in LDS at a time
+#ifndef NTC_AB_RUN_CHUNK
+#define NTC_AB_RUN_CHUNK 256
+#endif
+	constexpr uint32_t kRunChunk = NTC_AB_RUN_CHUNK; // run lengths held in LDS at a time (tests of the chunk loop: tools/ab_build.sh <name> -DNTC_AB_RUN_CHUNK=16 + NTCARD_LIB)
 	// hist: digit counts of the round; excl: their exclusive scan (packed output: of the counts rounded up to whole words); rel: gcur - excl (run offset
 	// of sorted position 0 of a digit; packed output: in words); gcur: keys (words) this workgroup has written per digit so far; cntd: the round's counts
 	__shared__ uint32_t hist[256], excl[256], rel[256], gcur[256], cntd[kPackOut ? 256 : 1], run_n[kRunChunk], tot[1];
