@@ -449,6 +449,14 @@ def main():
         fn.argtypes = [ctypes.c_void_p]
         assert fn(sc.ctypes.data) == 0
         np.save(os.environ["NTC_SPLIT_CLOCKS_OUT"], sc)
+    if os.environ.get("NTC_HF_CLOCKS_OUT"):
+        import ctypes
+        import numpy as np
+        hc = np.zeros(2 * 8192, dtype=np.uint64)
+        fn = nt._abi.lib().ntc_dbg_hf_clocks
+        fn.argtypes = [ctypes.c_void_p]
+        assert fn(hc.ctypes.data) == 0
+        np.save(os.environ["NTC_HF_CLOCKS_OUT"], hc)
     if args.k1h_wave_clocks:
         import ctypes
         import numpy as np

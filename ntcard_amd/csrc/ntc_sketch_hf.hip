@@ -112,9 +112,19 @@ __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_bal
 // kDump: validation build (ntc_hash_dump_k1_device): the filter lets EVERY window through, so the resolve stage
 // re-derives the full canonical hash of every window with the production code path, and writes it out instead of
 // sampling it (what ntHashIterator / stHashIterator enumerate, ntHashIterator.hpp:59-86, stHashIterator.hpp:60-87)
+#ifdef NTC_HF_CLOCKS // timing experiment (tools/ab_build.sh <name> -DNTC_HF_CLOCKS): first / last clock (100 MHz) of every wave of the LAST launch
+__device__ unsigned long long g_hf_clocks[2 * 8192];
+} // namespace ntc
+extern "C" int ntc_dbg_hf_clocks(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ntc::g_hf_clocks), sizeof(unsigned long long) * 2 * 8192); }
+namespace ntc {
+#endif
+
 template <bool kMulti, int kMode, int kPref, bool kDump = false, bool kTiled = false>
 __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(const HfArgs a)
 {
+#ifdef NTC_HF_CLOCKS
+	const unsigned long long hc_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 	const uint32_t n_k = kMulti ? a.n_k : 1u;
 	// Nothing but the tables and the decoded slots lives in LDS: hit masks and the compaction queue stay in registers, so that a CU's 160 KiB
 	// hold 16 waves of 150 bp reads (4 per SIMD) instead of 12.
@@ -223,7 +233,6 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	const uint32_t full_bytes = 64u * stride;
 	const uint32_t nchunk = (full_bytes + 1023u) >> 10;
 	const bool can_prefetch = nchunk <= (uint32_t)kPref;
-	const uint64_t wb_step = (uint64_t)gridDim.x * wpb;
 	uint4 pref[kPref];
 	// A TILED batch (a.tiled, round 5: the k of a list that K1h is not built for are hashed here from the same tiles, without a re-layout pass): the wave's
 	// 64 reads are 64 consecutive 16-byte pieces of every chunk row of their tile, so round c of the staging is ONE coalesced 1 KiB load — piece c of read
@@ -262,9 +271,35 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		}
 	};
 	auto is_full = [&](uint64_t wb_) { return tiled || wb_ * 64 + 64 <= n_slots; };
-	if (can_prefetch && gwave < n_wb && is_full(gwave)) load_round(gwave, 0);
-
-	for (uint64_t wb = gwave; wb < n_wb; wb += wb_step) {
+	// The wave's batches (round 6): a contiguous share of its workgroup's contiguous share of the launch's wave-batches, weighed by the wave's AGE on its SIMD.
+	// Before, wave g took the batches g, g + W, g + 2 W, ... — the same number for every wave — and the SIMDs, which issue their older waves first, finished the
+	// waves of a workgroup in the order of their age: 2090 / 2161 / 2255 us into a 2.33 ms launch with three waves per SIMD (config 4), 806 / 820 / 865 / 877 into
+	// 0.92 ms with four (per-wave clocks of a -DNTC_HF_CLOCKS build, profiles/r06_k1_wave_clocks.txt); the youngest ran on alone at the end.  Waves 4 r .. 4 r + 3 of
+	// a workgroup are the r-th on their SIMDs; the weights are the speeds those clocks showed, in 1 / 1024 of a SIMD's batches.
+	uint64_t wb_begin, wb_end;
+	{
+		static constexpr uint16_t kAgeShare[5][4] = { { 0, 0, 0, 0 }, { 1024, 0, 0, 0 }, { 530, 494, 0, 0 }, { 354, 342, 328, 0 }, { 267, 263, 249, 245 } };
+		const uint32_t ranks = (wpb + 3u) / 4u; // (1 .. 4)
+		auto cum = [&](uint32_t w) -> uint32_t { // the shares of the waves in front of wave w, in 1 / 1024 of a SIMD's batches
+			uint32_t c = 0;
+			for (uint32_t r = 0; r < ranks; ++r) {
+				const uint32_t in_rank = w > 4u * r ? (w - 4u * r < 4u ? w - 4u * r : 4u) : 0u; // waves of rank r in front of w
+				c += in_rank * (wpb % 4u == 0u ? kAgeShare[ranks][r] : 1024u / ranks);
+			}
+			return c;
+		};
+		const uint64_t per_wg = (n_wb + gridDim.x - 1) / gridDim.x;
+		const uint64_t g0 = (uint64_t)blockIdx.x * per_wg < n_wb ? (uint64_t)blockIdx.x * per_wg : n_wb;
+		const uint64_t g1 = g0 + per_wg < n_wb ? g0 + per_wg : n_wb;
+		const uint32_t total = cum(wpb);
+		wb_begin = g0 + (g1 - g0) * cum((uint32_t)wave) / total;
+		wb_end = (uint32_t)wave + 1u == wpb ? g1 : g0 + (g1 - g0) * cum((uint32_t)wave + 1u) / total;
+		wb_begin = __builtin_amdgcn_readfirstlane((uint32_t)wb_begin) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb_begin >> 32)) << 32);
+		wb_end = __builtin_amdgcn_readfirstlane((uint32_t)wb_end) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wb_end >> 32)) << 32);
+	}
+	if (can_prefetch && wb_begin < wb_end && is_full(wb_begin)) load_round(wb_begin, 0);
+	for (uint64_t wb = wb_begin; wb < wb_end; ++wb) {
+		const uint64_t wb_next = wb + 1 < wb_end ? wb + 1 : n_wb; // (n_wb: none)
 		const uint64_t slot0 = wb * 64;
 		const uint32_t nvalid = (uint32_t)((n_slots - slot0) < 64 ? (n_slots - slot0) : 64);
 		uint32_t badacc = 0;
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 		__builtin_amdgcn_wave_barrier();
 		if ((nvalid == 64 || tiled) && can_prefetch) {
 			store_round(0, badacc);
-			if (wb + wb_step < n_wb && is_full(wb + wb_step)) load_round(wb + wb_step, 0);
+			if (wb_next < n_wb && is_full(wb_next)) load_round(wb_next, 0);
 		} else if (nvalid == 64 || tiled) {
 			for (uint32_t c0 = 0; c0 < nchunk; c0 += kPref) {
 				load_round(wb, c0);
@@ -759,6 +794,12 @@ __global__ __launch_bounds__(kPref <= 10 ? 1024 : 768) void sketch_hf_kernel(con
 	for (uint32_t j = 0; j < n_k; ++j)
 		if (lane == 0 && f1_acc[j]) atomicAdd(a.ks[j].f1, (unsigned long long)f1_acc[j]);
 	if (use_log && lane == 0 && lreg < a.log_regions) a.log_fill[lreg] = lfill;
+#ifdef NTC_HF_CLOCKS
+	if (lane == 0 && gwave < 8192u) {
+		g_hf_clocks[2 * gwave] = hc_t0;
+		g_hf_clocks[2 * gwave + 1] = __builtin_amdgcn_s_memrealtime();
+	}
+#endif
 }
 
 hipError_t launch_sketch_hf(const HfArgs& a, unsigned grid, unsigned waves_per_block, size_t smem, hipStream_t st)
