@@ -313,6 +313,9 @@ __global__ __launch_bounds__(1024) void count_kernel(const CountArgs a)
 	// 0.57 -> 0.50 ms per apply of 366 M keys)
 	for (uint32_t i = tid; i < n_words / 4; i += nt)
 		reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+	if (a.clear_fill != nullptr) // (the log is spent: its regions were the first partition pass's input)
+		for (uint32_t i = blockIdx.x * nt + tid; i < a.n_clear; i += gridDim.x * nt)
+			a.clear_fill[i] = 0u;
 	__syncthreads();
 	for (uint32_t slice = blockIdx.x; slice < a.n_slices; slice += gridDim.x) {
 		bool fresh = clean; // this slice has not been written yet

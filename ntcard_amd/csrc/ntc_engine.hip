@@ -17,6 +17,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/ntcard_hip.h"
@@ -321,6 +322,9 @@ struct ntc_engine {
 	std::vector<uint64_t> pending_runs; // index-aligned with `pending`: 0 = one launch; n + 1 = a bracket of tiled launches that counts as n submits
 	uint64_t run_submits = 0;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> k1f_events; // profiling: deferred K1f launches (outside the hash kernels' events)
+	// An event record is a stream bubble of its own, so where two timed spans touch — hash bracket | K1f | hash bracket, K1f | apply — the end event of the first
+	// IS the start event of the second; the second pair then BORROWS its first event (it is destroyed as the other pair's second)
+	std::unordered_set<hipEvent_t> borrowed;
 	double k1f_ms = 0.0;
 	bool ts_ok = false;             // the tiled kernel pair K1h + K1f is built for SOME k of this configuration (k_tiled says which) ...
 	bool ts_all = false;            // ... for every k (then nothing of a tiled batch is left to K1)
@@ -368,11 +372,13 @@ struct ntc_engine {
 
 namespace {
 
-int close_run(ntc_engine* e);
+int close_run(ntc_engine* e, hipEvent_t* recorded);
+inline int close_run(ntc_engine* e) { return close_run(e, nullptr); }
 
 int drain_events(ntc_engine* e)
 {
 	if (int rc = close_run(e)) return rc;
+	// every span first (a pair may borrow its first event from another pair: ntc_engine::borrowed), then the events go
 	for (auto& pr : e->pending) {
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(pr.second));
@@ -380,29 +386,28 @@ int drain_events(ntc_engine* e)
 		e->ms_total += ms;
 		const size_t idx = (size_t)(&pr - e->pending.data());
 		e->launches += idx < e->pending_runs.size() && e->pending_runs[idx] ? e->pending_runs[idx] - 1 : 1; // (a bracket: submits + 1; 0: a single launch)
-		(void)hipEventDestroy(pr.first);
-		(void)hipEventDestroy(pr.second);
 	}
-	e->pending.clear();
-	e->pending_runs.clear();
 	for (auto& pr : e->apply_pending) {
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(pr.second));
 		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
 		e->apply_ms += ms;
-		(void)hipEventDestroy(pr.first);
-		(void)hipEventDestroy(pr.second);
 	}
-	e->apply_pending.clear();
 	for (auto& pr : e->k1f_events) {
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(pr.second));
 		HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
 		e->k1f_ms += ms;
-		(void)hipEventDestroy(pr.first);
-		(void)hipEventDestroy(pr.second);
 	}
-	e->k1f_events.clear();
+	for (auto* v : { &e->pending, &e->apply_pending, &e->k1f_events }) {
+		for (auto& pr : *v) {
+			if (!e->borrowed.count(pr.first)) (void)hipEventDestroy(pr.first);
+			(void)hipEventDestroy(pr.second);
+		}
+		v->clear();
+	}
+	e->pending_runs.clear();
+	e->borrowed.clear();
 	return 0;
 }
 
@@ -444,14 +449,16 @@ bool plan_log(ntc_engine* e, uint64_t want_entries)
 
 // K1f over the K1h launches that still wait for it (asynchronous on the engine's stream).  Before anything reads the counters or F1, touches the
 // sketch without atomics (the apply's sweep does), or hands the batches back to the caller.
-int close_run(ntc_engine* e) // the end of a bracketed run of tiled hash launches (see run_ev0)
+int close_run(ntc_engine* e, hipEvent_t* recorded) // the end of a bracketed run of tiled hash launches (see run_ev0); *recorded = the event it has just recorded (or null)
 {
+	if (recorded) *recorded = nullptr;
 	if (!e->run_ev0) return 0;
 	hipEvent_t ev1 = nullptr;
 	HIP_TRY(hipEventCreate(&ev1));
 	HIP_TRY(hipEventRecord(ev1, e->stream));
 	e->pending_runs.resize(e->pending.size(), 0);
 	e->pending.emplace_back(e->run_ev0, ev1);
+	if (recorded) *recorded = ev1;
 	e->pending_runs.push_back(e->run_submits + 1); // (+ 1: a bracket re-opened in the middle of a k list has counted its submit already and adds none)
 	e->run_ev0 = nullptr;
 	e->run_submits = 0;
@@ -460,18 +467,27 @@ int close_run(ntc_engine* e) // the end of a bracketed run of tiled hash launche
 
 int flush_deferred(ntc_engine* e); // the hash launches of the batches that wait in e->deferred (below, behind run_tiled_segs)
 
-int join_k1f(ntc_engine* e)
+int join_k1f(ntc_engine* e, hipEvent_t* last = nullptr) // *last = the event recorded behind the last thing this call launched (K1f's end, or the hash bracket's), or null
 {
+	if (last) *last = nullptr;
 	if (int rc = flush_deferred(e)) return rc;
-	if (int rc = close_run(e)) return rc;
+	hipEvent_t closed = nullptr; // (the end of the hash launches' bracket, recorded this very moment, is K1f's start too: an event record is a stream bubble of its own)
+	if (int rc = close_run(e, &closed)) return rc;
+	if (last) *last = closed;
 	if (e->k1f_n == 0) return 0;
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
 	hipEvent_t f0 = nullptr, f1 = nullptr;
+	bool f0_shared = false;
 	if (e->profiling) {
-		HIP_TRY(hipEventCreate(&f0));
 		HIP_TRY(hipEventCreate(&f1));
-		HIP_TRY(hipEventRecord(f0, e->stream));
+		if (closed) {
+			f0 = closed;
+			f0_shared = true;
+		} else {
+			HIP_TRY(hipEventCreate(&f0));
+			HIP_TRY(hipEventRecord(f0, e->stream));
+		}
 	}
 	const uint32_t n = e->k1f_n;
 	e->k1f_n = 0;
@@ -479,6 +495,10 @@ int join_k1f(ntc_engine* e)
 	if (e->profiling) {
 		HIP_TRY(hipEventRecord(f1, e->stream));
 		e->k1f_events.emplace_back(f0, f1);
+		if (f0_shared) e->borrowed.insert(f0);
+		if (last) *last = f1;
+	} else if (last) {
+		*last = nullptr;
 	}
 	return 0;
 }
@@ -486,7 +506,8 @@ int join_k1f(ntc_engine* e)
 // Apply the pending hit log to the sketch (asynchronous on the engine's stream): partition, count, add, clear.
 int apply_log(ntc_engine* e)
 {
-	if (int rc = join_k1f(e)) return rc;
+	hipEvent_t before = nullptr; // (the event behind K1f / the hash bracket, if this call has just recorded one: the apply's start)
+	if (int rc = join_k1f(e, &before)) return rc;
 	if (!e->d_log || !e->log_pending) return 0;
 	const auto& ap = e->ap;
 	const uint32_t nb1 = 1u << ap.b1, nb2 = 1u << ap.b2;
@@ -502,9 +523,14 @@ int apply_log(ntc_engine* e)
 	}
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (e->profiling) {
-		HIP_TRY(hipEventCreate(&ev0));
 		HIP_TRY(hipEventCreate(&ev1));
-		HIP_TRY(hipEventRecord(ev0, e->stream));
+		if (before) {
+			ev0 = before;
+			e->borrowed.insert(ev0);
+		} else {
+			HIP_TRY(hipEventCreate(&ev0));
+			HIP_TRY(hipEventRecord(ev0, e->stream));
+		}
 	}
 	// little in the log (decided on the device: fewer than 4 M entries): plain atomics, and the passes below find it empty
 	// (an engine whose every k is K1h's always logs, so the host's estimate of a large log is good enough to go straight to the partition passes — which are exact
@@ -593,9 +619,13 @@ int apply_log(ntc_engine* e)
 	}
 	DevInfo di;
 	if (int rc = device_info(e->device, di)) return rc;
+	if (c.mode != 0) { // (the count pass reads partition runs, not the log: it clears the log's fill words itself)
+		c.clear_fill = e->d_logfill;
+		c.n_clear = e->all_log_regions();
+	}
 	HIP_TRY(ntc::launch_count(c, std::min<unsigned>(ap.n_slices, (ap.slice_bits >= 15 ? 2u : 4u) * (unsigned)di.cus), e->stream));
 	e->sk_host_dirty = true;
-	HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->all_log_regions() * 4, e->stream));
+	if (c.mode == 0) HIP_TRY(hipMemsetAsync(e->d_logfill, 0, (size_t)e->all_log_regions() * 4, e->stream));
 	if (e->profiling) {
 		HIP_TRY(hipEventRecord(ev1, e->stream));
 		e->apply_pending.emplace_back(ev0, ev1);
@@ -928,10 +958,15 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 		e->log_pending = true;
 	}
 	// ntRead's loop over kList (ntcard.cpp:147-158): one launch per k over the same resident batches
-	auto open_run = [&]() -> int { // (again behind a K1f that had to come in the middle of the list)
+	auto open_run = [&](hipEvent_t borrow = nullptr) -> int { // (again behind a K1f that had to come in the middle of the list; borrow: the event that K1f has just left)
 		if (e->profiling && !e->run_ev0) {
-			HIP_TRY(hipEventCreate(&e->run_ev0));
-			HIP_TRY(hipEventRecord(e->run_ev0, e->stream));
+			if (borrow) {
+				e->run_ev0 = borrow;
+				e->borrowed.insert(borrow);
+			} else {
+				HIP_TRY(hipEventCreate(&e->run_ev0));
+				HIP_TRY(hipEventRecord(e->run_ev0, e->stream));
+			}
 		}
 		return 0;
 	};
@@ -984,9 +1019,10 @@ int run_tiled_segs(ntc_engine* e, const TiledSeg* segs_in, uint32_t n_in, uint64
 			if (sg.read_len >= k) act.push_back(&sg);
 		if (act.empty()) continue;
 		const uint32_t na = (uint32_t)act.size();
+		hipEvent_t after = nullptr;
 		if (e->k1f_n + na > ntc::kK1fBatch) // no sets left for these launches: K1f over the waiting ones first
-			if (int rc = join_k1f(e)) return rc;
-		if (int rc = open_run()) return rc;
+			if (int rc = join_k1f(e, &after)) return rc;
+		if (int rc = open_run(after)) return rc;
 		if (e->profiling && !counted) {
 			e->run_submits += n_submits;
 			counted = true;
@@ -1332,10 +1368,10 @@ void ntc_destroy(ntc_engine* e)
 	(void)hipSetDevice(e->device);
 	(void)hipStreamSynchronize(e->stream);
 	for (auto& pr : e->pending) {
-		(void)hipEventDestroy(pr.first);
+		if (!e->borrowed.count(pr.first)) (void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
-	if (e->run_ev0) (void)hipEventDestroy(e->run_ev0);
+	if (e->run_ev0 && !e->borrowed.count(e->run_ev0)) (void)hipEventDestroy(e->run_ev0);
 	if (e->own_sketch && e->d_sketch) (void)hipFree(e->d_sketch);
 	if (e->own_f1 && e->d_f1) (void)hipFree(e->d_f1);
 	if (e->d_phist) (void)hipFree(e->d_phist);
@@ -1346,7 +1382,7 @@ void ntc_destroy(ntc_engine* e)
 	for (void* d : {(void*)e->d_log, (void*)e->d_logfill, (void*)e->d_s1, (void*)e->d_c1, (void*)e->d_s2, (void*)e->d_c2, (void*)e->d_logmode, (void*)e->d_logstats, (void*)e->d_probe})
 		if (d) (void)hipFree(d);
 	for (auto& pr : e->apply_pending) {
-		(void)hipEventDestroy(pr.first);
+		if (!e->borrowed.count(pr.first)) (void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
 	for (void* d : e->d_t4s)
@@ -1368,7 +1404,7 @@ void ntc_destroy(ntc_engine* e)
 		for (void* d : {(void*)ks.d_dirty, (void*)ks.d_tie, (void*)ks.d_sus, (void*)ks.d_sus_count, (void*)ks.d_fix_state})
 			if (d) (void)hipFree(d);
 	for (auto& pr : e->k1f_events) {
-		(void)hipEventDestroy(pr.first);
+		if (!e->borrowed.count(pr.first)) (void)hipEventDestroy(pr.first);
 		(void)hipEventDestroy(pr.second);
 	}
 	for (void* d : e->d_t1) (void)hipFree(d);
